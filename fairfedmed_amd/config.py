@@ -1,0 +1,108 @@
+"""Shape/config records for the FairLoRA hot path.
+
+These are the few values of the reference's yacs tree that the hot path reads
+(SURVEY.md §5 "Config / flags"): CLIP geometry (clip/model.py:453-531),
+TRAINER.GLP_OT.{N, N_CTX}, TRAINER.GLP_OT_LORA.{RANK, ALPHA}, the number of
+demographic groups (trainers/GLP_OT_SVLoRA.py:775-790) and the SGD/StepLR
+settings (configs/trainers/GLP_OT/vit_b16_oph.yaml:15-22).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import Tuple
+
+# CLIP normalisation constants used by every FairLoRA yaml
+# (configs/trainers/GLP_OT/vit_b16_oph.yaml:9-13).
+CLIP_PIXEL_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_PIXEL_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@dataclass(frozen=True)
+class VisionCfg:
+    image_size: int = 224
+    patch: int = 16
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    out_dim: int = 512
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch
+
+    @property
+    def tokens(self) -> int:  # L = grid^2 + 1 (class token)
+        return self.grid * self.grid + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.width // self.heads
+
+
+@dataclass(frozen=True)
+class TextCfg:
+    context_length: int = 77
+    width: int = 512
+    heads: int = 8
+    layers: int = 12
+
+
+@dataclass(frozen=True)
+class LoraCfg:
+    rank: int = 8
+    alpha: float = 2.0
+    num_groups: int = 3       # G = len(retrieval_attributes(ATTRIBUTE_TYPE))
+    lambda_group: float = 0.7  # trainers/GLP_OT_SVLoRA.py:459
+
+    @property
+    def scaling(self) -> float:  # trainers/GLP_OT_SVLoRA.py:346
+        return self.alpha / self.rank
+
+
+@dataclass(frozen=True)
+class OptimCfg:
+    lr: float = 1e-3
+    momentum: float = 0.9
+    weight_decay: float = 5e-4
+    stepsize: int = 200
+    gamma: float = 0.1
+
+
+@dataclass(frozen=True)
+class ModelCfg:
+    vision: VisionCfg = field(default_factory=VisionCfg)
+    text: TextCfg = field(default_factory=TextCfg)
+    lora: LoraCfg = field(default_factory=LoraCfg)
+    n_prompts: int = 2         # TRAINER.GLP_OT.N
+    n_ctx: int = 4             # TRAINER.GLP_OT.N_CTX
+    n_cls: int = 2
+    # EOT position of each of the n_cls tokenised prompts (argmax of token ids,
+    # trainers/GLP_OT_SVLoRA.py:64).  Defaults: "X X X X NOT Glaucoma." -> 9,
+    # "X X X X Glaucoma." -> 8.
+    eot: Tuple[int, ...] = (9, 8)
+    pixel_mean: Tuple[float, float, float] = CLIP_PIXEL_MEAN
+    pixel_std: Tuple[float, float, float] = CLIP_PIXEL_STD
+    # 3D OCT: slices are grouped by `dim_per_3d_slice` channels
+    # (trainers/GLP_OT_SVLoRA.py:585-595); 0 = 2D input.
+    dim_per_3d_slice: int = 0
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def vit_b16(rank: int = 8, alpha: float = 2.0, num_groups: int = 3) -> ModelCfg:
+    """CLIP ViT-B/16 FairLoRA (BASELINE.json configs[1..3])."""
+    return ModelCfg(lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups))
+
+
+def vit_tiny(rank: int = 4, alpha: float = 2.0, num_groups: int = 3) -> ModelCfg:
+    """A small geometry with the same structure, for fast parity tests:
+    64x64 image, 16 patches + cls = 17 tokens, width 128 (2 heads of 64),
+    2 vision layers; text width 128 (2 heads), 2 layers, context 77 (the
+    reference's tokenizer always pads prompts to 77, clip/clip.py:180-220)."""
+    return ModelCfg(
+        vision=VisionCfg(image_size=64, patch=16, width=128, layers=2, heads=2, out_dim=128),
+        text=TextCfg(context_length=77, width=128, heads=2, layers=2),
+        lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups),
+        eot=(9, 8),
+    )

@@ -1,0 +1,207 @@
+"""Deterministic synthetic weights and batches.
+
+Pretrained CLIP weights and the FairFedMed datasets cannot be fetched (no
+network), so every parity and benchmark run uses weights produced by a
+counter-based filler keyed by the state_dict key: the same tensors can be
+regenerated in this container (for the reference import that makes the golden
+vectors) and on the GPU box without shipping 500 MB.
+
+The key set and shapes are those of the reference's ``CustomCLIP`` after
+``apply_lora_to_model`` (trainers/GLP_OT_SVLoRA.py:503-573, 575-613;
+SURVEY.md §8(b) "state_dict keys").
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .config import ModelCfg
+
+
+def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict key -> shape, in the reference's registration order."""
+    v, t, lo = cfg.vision, cfg.text, cfg.lora
+    m: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    m["logit_scale"] = ()
+    if cfg.dim_per_3d_slice:
+        m["proj_per_3d_slice.weight"] = (3, cfg.dim_per_3d_slice, 5, 5)
+        m["proj_per_3d_slice.bias"] = (3,)
+    nrow = cfg.n_prompts * cfg.n_cls
+    m["prompt_learner.ctx"] = (cfg.n_prompts, cfg.n_ctx, t.width)
+    m["prompt_learner.token_prefix"] = (nrow, 1, t.width)
+    m["prompt_learner.token_suffix"] = (nrow, t.context_length - 1 - cfg.n_ctx, t.width)
+    ie = "image_encoder."
+    m[ie + "class_embedding"] = (v.width,)
+    m[ie + "positional_embedding"] = (v.tokens, v.width)
+    m[ie + "proj"] = (v.width, v.out_dim)
+    m[ie + "conv1.weight"] = (v.width, 3, v.patch, v.patch)
+    m[ie + "ln_pre.weight"] = (v.width,)
+    m[ie + "ln_pre.bias"] = (v.width,)
+    for i in range(v.layers):
+        p = f"{ie}transformer.resblocks.{i}."
+        m[p + "attn.in_proj_weight"] = (3 * v.width, v.width)
+        m[p + "attn.in_proj_bias"] = (3 * v.width,)
+        m[p + "attn.out_proj.weight"] = (v.width, v.width)
+        m[p + "attn.out_proj.bias"] = (v.width,)
+        m[p + "ln_1.weight"] = (v.width,)
+        m[p + "ln_1.bias"] = (v.width,)
+        for name, fin, fout in (("c_fc", v.width, 4 * v.width), ("c_proj", 4 * v.width, v.width)):
+            q = f"{p}mlp.{name}."
+            m[q + "original_linear.weight"] = (fout, fin)
+            m[q + "original_linear.bias"] = (fout,)
+            m[q + "lora_A.weight"] = (fin, lo.rank)
+            m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+            m[q + "lora_B.weight"] = (lo.rank, fout)
+        m[p + "ln_2.weight"] = (v.width,)
+        m[p + "ln_2.bias"] = (v.width,)
+    m[ie + "ln_post.weight"] = (v.width,)
+    m[ie + "ln_post.bias"] = (v.width,)
+    te = "text_encoder."
+    m[te + "positional_embedding"] = (t.context_length, t.width)
+    m[te + "text_projection"] = (t.width, v.out_dim)
+    for i in range(t.layers):
+        p = f"{te}transformer.resblocks.{i}."
+        m[p + "attn.in_proj_weight"] = (3 * t.width, t.width)
+        m[p + "attn.in_proj_bias"] = (3 * t.width,)
+        m[p + "attn.out_proj.weight"] = (t.width, t.width)
+        m[p + "attn.out_proj.bias"] = (t.width,)
+        m[p + "ln_1.weight"] = (t.width,)
+        m[p + "ln_1.bias"] = (t.width,)
+        m[p + "mlp.c_fc.weight"] = (4 * t.width, t.width)
+        m[p + "mlp.c_fc.bias"] = (4 * t.width,)
+        m[p + "mlp.c_proj.weight"] = (t.width, 4 * t.width)
+        m[p + "mlp.c_proj.bias"] = (t.width,)
+        m[p + "ln_2.weight"] = (t.width,)
+        m[p + "ln_2.bias"] = (t.width,)
+    m[te + "ln_final.weight"] = (t.width,)
+    m[te + "ln_final.bias"] = (t.width,)
+    return m
+
+
+def trainable_keys(cfg: ModelCfg):
+    """Keys with requires_grad after the reference's freeze loop + LoRA
+    injection (trainers/GLP_OT_SVLoRA.py:822-842): prompt_learner.ctx,
+    proj_per_3d_slice.*, and every lora_{A,S,B}."""
+    out = []
+    for k in manifest(cfg):
+        if k == "prompt_learner.ctx" or k.startswith("proj_per_3d_slice.") or ".lora_" in k:
+            out.append(k)
+    return out
+
+
+def _rng(key: str, seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), seed & 0xFFFFFFFF]))
+
+
+def lora_s_init(rank: int, num_groups: int) -> torch.Tensor:
+    """'same+cycle' initial singular values (trainers/GLP_OT_SVLoRA.py:402-417):
+    first r/2 columns = linspace(.5,.1,r/2) shared by all groups, last r/2 =
+    the same ramp cyclically shifted by i*((r/2)//G) for group i, times 0.2."""
+    assert rank % 2 == 0 and rank >= num_groups
+    h = rank // 2
+    ramp = torch.linspace(0.5, 0.1, steps=h)
+    shift = h // num_groups
+    cyc = torch.stack([torch.cat([ramp[i * shift:], ramp[: i * shift]]) for i in range(num_groups)])
+    return torch.cat([ramp[None].repeat(num_groups, 1), cyc * 0.2], dim=1)
+
+
+def _std_for(key: str, cfg: ModelCfg) -> Tuple[str, float, float]:
+    """(kind, mean, std) per key; scales follow CLIP.initialize_parameters
+    (clip/model.py:533-560) so activations stay O(1) through 12 layers."""
+    v, t = cfg.vision, cfg.text
+    width = v.width if key.startswith("image_encoder.") else t.width
+    layers = v.layers if key.startswith("image_encoder.") else t.layers
+    if key == "logit_scale":
+        return "const", float(np.log(1 / 0.07)), 0.0
+    if key.endswith("ln_1.weight") or key.endswith("ln_2.weight") or key.endswith("ln_pre.weight") \
+            or key.endswith("ln_post.weight") or key.endswith("ln_final.weight"):
+        return "normal", 1.0, 0.1
+    if ".ln_" in key and key.endswith(".bias"):
+        return "normal", 0.0, 0.1
+    if key.endswith("attn.in_proj_weight"):
+        return "normal", 0.0, width ** -0.5
+    if key.endswith("attn.out_proj.weight") or "c_proj" in key and key.endswith("weight") and "lora" not in key:
+        return "normal", 0.0, (width ** -0.5) * ((2 * layers) ** -0.5)
+    if "c_fc" in key and key.endswith("weight") and "lora" not in key:
+        return "normal", 0.0, (2 * width) ** -0.5
+    if key.endswith("bias"):
+        return "normal", 0.0, 0.02
+    if key.endswith("conv1.weight"):
+        return "normal", 0.0, 0.02
+    if key.endswith("class_embedding") or key.endswith("image_encoder.positional_embedding") or key.endswith("image_encoder.proj"):
+        return "normal", 0.0, v.width ** -0.5
+    if key.endswith("text_encoder.positional_embedding"):
+        return "normal", 0.0, 0.01
+    if key.endswith("text_projection"):
+        return "normal", 0.0, t.width ** -0.5
+    if key.startswith("prompt_learner."):
+        return "normal", 0.0, 0.02
+    if key == "proj_per_3d_slice.weight":
+        return "normal", 0.0, cfg.dim_per_3d_slice ** -0.5
+    raise KeyError(key)
+
+
+def make_state_dict(cfg: ModelCfg, seed: int = 1, lora_init: str = "reference") -> Dict[str, torch.Tensor]:
+    """fp32 CPU state_dict with the manifest's keys.
+
+    lora_init="reference": lora_A = 0, lora_B ~ N(0,1), lora_S 'same+cycle'
+      (trainers/GLP_OT_SVLoRA.py:380-423) -> the adapter is a no-op at step 0.
+    lora_init="random": lora_A ~ N(0, 0.05) and lora_S perturbed, so every
+      gradient path (dA, dB, dS, LoRA dx) is non-trivial in a single step.
+    """
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+    lo = cfg.lora
+    for key, shape in manifest(cfg).items():
+        g = _rng(key, seed)
+        if key.endswith("lora_A.weight"):
+            if lora_init == "reference":
+                x = np.zeros(shape, np.float32)
+            else:
+                x = g.standard_normal(shape, dtype=np.float32) * 0.05
+        elif key.endswith("lora_B.weight"):
+            x = g.standard_normal(shape, dtype=np.float32)
+        elif key.endswith("lora_S.weight"):
+            x = lora_s_init(lo.rank, lo.num_groups).numpy().astype(np.float32)
+            if lora_init != "reference":
+                x = x + g.standard_normal(shape, dtype=np.float32) * 0.05
+        else:
+            kind, mean, std = _std_for(key, cfg)
+            if kind == "const":
+                x = np.full(shape, mean, np.float32)
+            else:
+                x = mean + g.standard_normal(shape, dtype=np.float32) * np.float32(std)
+        sd[key] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(shape)
+    return sd
+
+
+def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0):
+    """Synthetic batch in the reference's dict contract:
+    img f32 [B,C,H,W] raw 0..255, label i64 [B], attrs i64 [B,1].
+
+    signal > 0 adds a label-dependent mean shift on a fixed patch mask and a
+    group-dependent contrast, so AUC can move off 0.5."""
+    g = np.random.Generator(np.random.Philox(key=[0xBA7C4, seed & 0xFFFFFFFF]))
+    v = cfg.vision
+    c = 3 if not cfg.dim_per_3d_slice else None
+    assert c is not None, "use make_batch_3d for 3D inputs"
+    img = g.random((batch, 3, v.image_size, v.image_size), dtype=np.float32)
+    label = g.integers(0, cfg.n_cls, size=(batch,), dtype=np.int64)
+    attr = g.integers(0, cfg.lora.num_groups, size=(batch,), dtype=np.int64)
+    if signal > 0:
+        h = v.image_size
+        mask = np.zeros((h, h), np.float32)
+        mask[h // 4: h // 2, h // 4: h // 2] = 1.0
+        contrast = 1.0 - 0.15 * attr.astype(np.float32)
+        img = (img - 0.5) * contrast[:, None, None, None] + 0.5
+        img = img + signal * (label.astype(np.float32) * 2 - 1)[:, None, None, None] * mask[None, None]
+        img = np.clip(img, 0.0, 1.0)
+    img = img * np.float32(255.0)
+    return {
+        "img": torch.from_numpy(img),
+        "label": torch.from_numpy(label),
+        "attrs": torch.from_numpy(attr[:, None].copy()),
+    }

@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference).  Nothing here
+travels as reference source: the outputs are data (inputs are regenerated from
+seeds by fairfedmed_amd.synth; expected outputs are stored as small .npz/.json).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--vitb] [--time-ref]
+
+The reference cannot be imported unmodified: third-party
+modules absent from the image are served as stubs by a meta-path finder, and
+``Dassl.dassl.engine`` must be imported before the trainer module.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import time
+import types
+from types import SimpleNamespace as NS
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+# ---------------------------------------------------------------- stubs ----
+PREFIXES = ("torchvision", "ftfy", "tensorboard", "torch.utils.tensorboard", "gdown", "fairlearn",
+            "aif360", "prettytable", "yacs", "timm", "skimage", "datasets", "cv2")
+
+
+class _Meta(type):
+    def __getattr__(cls, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return MagicMock(name=f"{cls.__name__}.{n}")
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        o = _Meta(n, (), {"__init__": lambda s, *a, **k: None, "__call__": lambda s, *a, **k: None})
+        setattr(self, n, o)
+        return o
+
+
+class _Loader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, m):
+        pass
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path, target=None):
+        if any(name == p or name.startswith(p + ".") for p in PREFIXES):
+            return importlib.machinery.ModuleSpec(name, _Loader(), is_package=True)
+
+
+def import_reference():
+    sys.meta_path.insert(0, _Finder())
+    for k in [k for k in sys.modules if k == "datasets" or k.startswith("datasets.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF)
+    import ftfy
+    ftfy.fix_text = lambda s: s
+    from Dassl.dassl.engine import build_trainer  # noqa: F401  (must precede the trainer import)
+    import trainers.GLP_OT_SVLoRA as M
+    from clip.model import CLIP
+    import utils.fed_utils as FU
+    from evaluation.metrics import compute_auc
+    return M, CLIP, FU, compute_auc
+
+
+# ------------------------------------------------------------- helpers ----
+from fairfedmed_amd import config as C      # noqa: E402
+from fairfedmed_amd import synth            # noqa: E402
+
+
+def ref_cfg(mcfg: C.ModelCfg, lambda_fairness=0.0):
+    return NS(
+        INPUT=NS(PIXEL_MEAN=list(mcfg.pixel_mean), PIXEL_STD=list(mcfg.pixel_std),
+                 SIZE=(mcfg.vision.image_size, mcfg.vision.image_size)),
+        DATASET=NS(NAME="FairFedMed", MODALITY_TYPE="slo_fundus" if not mcfg.dim_per_3d_slice else "oct_bscans",
+                   DIM_PER_3D_SLICE=mcfg.dim_per_3d_slice, ATTRIBUTES=["race"], ATTRIBUTE_TYPE="race"),
+        TRAINER=NS(GLP_OT=NS(N_CTX=mcfg.n_ctx, CTX_INIT=False, CSC=False, N=mcfg.n_prompts,
+                             CLASS_TOKEN_POSITION="end", EPS=0.1, THRESH=1e-3, OT="None",
+                             TOP_PERCENT=1.0, MAX_ITER=100, PREC="fp32"),
+                   GLP_OT_LORA=NS(DISABLE_ATTR=False),
+                   LAMBDA_FAIRNESS=lambda_fairness),
+    )
+
+
+def build_reference_model(M, CLIP, mcfg: C.ModelCfg, sd):
+    v, t = mcfg.vision, mcfg.text
+    dd = {"trainer": "GLP_OT", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0}
+    clip_model = CLIP(v.out_dim, v.image_size, v.layers, v.width, v.patch, t.context_length, 49408,
+                      t.width, t.heads, t.layers, dd).float()
+    model = M.CustomCLIP(ref_cfg(mcfg), ["NOT Glaucoma", "Glaucoma"], clip_model)
+    for n, p in model.named_parameters():
+        p.requires_grad_("prompt_learner" in n or "proj_per_3d_slice" in n)
+    M.apply_lora_to_model(model, True, rank=mcfg.lora.rank, alpha=mcfg.lora.alpha, lora_type="FairLoRA",
+                          global_s=False, num_attrs=mcfg.lora.num_groups)
+    ref_sd = model.state_dict()
+    man = synth.manifest(mcfg)
+    assert list(ref_sd.keys()) == list(man.keys()), (
+        [k for k in ref_sd if k not in man], [k for k in man if k not in ref_sd])
+    for k, shp in man.items():
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    eot = model.tokenized_prompts.argmax(-1).tolist()
+    assert eot == list(mcfg.eot) * mcfg.n_prompts, eot
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def sub(x: torch.Tensor, n=4096):
+    """Strided subsample of a flattened tensor (<= n entries) for compact fixtures."""
+    f = x.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().astype(np.float32)
+
+
+def rng_tensor(tag: str, shape, scale=1.0):
+    g = synth._rng(tag, 7)
+    return torch.from_numpy(g.standard_normal(shape, dtype=np.float32) * np.float32(scale))
+
+
+# ------------------------------------------------------------ goldens -----
+LAYER_CASES = [
+    # name, L, Bn(=b*S), in, out, r, G, S, conv_hw
+    ("fc_small", 5, 16, 64, 256, 4, 3, 1, None),
+    ("fc_vitb", 197, 4, 768, 3072, 8, 3, 1, None),
+    ("proj_vitb_slices", 197, 4, 3072, 768, 16, 3, 2, None),
+    ("conv1x1", 49, 4, 64, 256, 8, 2, 1, (7, 7)),
+]
+
+
+def layer_inputs(name, L, Bn, fin, fout, r, G, S, hw):
+    b = Bn // S
+    x = rng_tensor(name + ".x", (L, Bn, fin))
+    g = rng_tensor(name + ".g", (L, Bn, fout))
+    W = rng_tensor(name + ".W", (fout, fin), fin ** -0.5)
+    bias = None if hw else rng_tensor(name + ".b", (fout,), 0.1)
+    A = rng_tensor(name + ".A", (fin, r), 0.1)
+    Sm = synth.lora_s_init(r, G) + rng_tensor(name + ".S", (G, r), 0.05)
+    Bm = rng_tensor(name + ".B", (r, fout))
+    attr = torch.from_numpy(synth._rng(name + ".attr", 7).integers(0, G, size=(b,), dtype=np.int64))
+    return x, g, W, bias, A, Sm, Bm, attr
+
+
+def golden_layers(M, out):
+    import torch.nn as nn
+    for case in LAYER_CASES:
+        name, L, Bn, fin, fout, r, G, S, hw = case
+        x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+        if hw:
+            lin = nn.Conv2d(fin, fout, 1, bias=False)
+            lin.weight.data = W.reshape(fout, fin, 1, 1).clone()
+            xin = x.permute(1, 2, 0).reshape(Bn, fin, hw[0], hw[1]).clone().requires_grad_(True)
+        else:
+            lin = nn.Linear(fin, fout)
+            lin.weight.data = W.clone()
+            lin.bias.data = bias.clone()
+            xin = x.clone().requires_grad_(True)
+        layer = M.FairLoRALinear(lin, rank=r, alpha=2.0, num_attrs=G)
+        layer.lora_A.weight.data = A.clone()
+        layer.lora_S.weight.data = Sm.clone()
+        layer.lora_B.weight.data = Bm.clone()
+        y = layer(xin, attr)
+        if hw:
+            gy = g.reshape(hw[0], hw[1], Bn, fout).permute(2, 3, 0, 1)
+        else:
+            gy = g
+        y.backward(gy)
+        y_tok = y.detach().reshape(Bn, fout, -1).permute(2, 0, 1) if hw else y.detach()
+        dx_tok = xin.grad.reshape(Bn, fin, -1).permute(2, 0, 1) if hw else xin.grad
+        full = y_tok.numel() <= 65536
+        out[f"layer.{name}.y"] = y_tok.numpy() if full else sub(y_tok)
+        out[f"layer.{name}.dx"] = dx_tok.numpy() if dx_tok.numel() <= 65536 else sub(dx_tok)
+        out[f"layer.{name}.dA"] = layer.lora_A.weight.grad.numpy()
+        out[f"layer.{name}.dS"] = layer.lora_S.weight.grad.numpy()
+        out[f"layer.{name}.dB"] = layer.lora_B.weight.grad.numpy()
+        print("layer", name, "y", tuple(y.shape), "|dA|", float(layer.lora_A.weight.grad.norm()))
+
+
+def golden_s_init(M, out):
+    import torch.nn as nn
+    for r in (4, 8, 12, 16, 32):
+        for G in (2, 3):
+            layer = M.FairLoRALinear(nn.Linear(8, 8), rank=r, alpha=2.0, num_attrs=G)
+            out[f"s_init.r{r}.g{G}"] = layer.lora_S.weight.detach().numpy().copy()
+            assert float(layer.lora_A.weight.abs().max()) == 0.0
+
+
+def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="random"):
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init=lora_init)
+    model = build_reference_model(M, CLIP, mcfg, sd)
+    batch = synth.make_batch(mcfg, batch_size, seed=1234)
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    n_total = sum(p.numel() for p in model.parameters())
+    meta[f"{tag}.trainable_elems"] = n_train
+    meta[f"{tag}.total_params"] = n_total
+    meta[f"{tag}.trainable_tensors"] = sum(1 for p in model.parameters() if p.requires_grad)
+
+    # trainer-level: object.__new__ + the attributes forward_backward touches
+    tr = object.__new__(M.GLP_OT_SVLoRA)
+    cfg = ref_cfg(mcfg)
+    tr.cfg = cfg
+    tr.model = model
+    tr.device = torch.device("cpu")
+    params = list(model.prompt_learner.parameters()) + list(model.image_encoder.parameters())
+    tr.optim = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, dampening=0, nesterov=False)
+    tr.sched = torch.optim.lr_scheduler.StepLR(tr.optim, step_size=200, gamma=0.1)
+    from collections import OrderedDict
+    tr._models = OrderedDict(prompt_learner=model.prompt_learner, image_encoder=model.image_encoder)
+    tr._optims = OrderedDict(prompt_learner=tr.optim, image_encoder=None)
+    tr._scheds = OrderedDict(prompt_learner=tr.sched, image_encoder=None)
+    tr._writer = None
+    tr.num_batches = 10 ** 9
+    model.train()
+
+    # step 0 by hand to capture logits and grads before the update
+    image, label, _, attr = tr.parse_batch_train(batch)
+    t0 = time.time()
+    logits = model(image, attr)
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    tr.optim.zero_grad()
+    loss.backward()
+    dt = time.time() - t0
+    out[f"{tag}.logits"] = logits.detach().numpy()
+    meta[f"{tag}.loss0"] = float(loss)
+    gn = {}
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            gr = p.grad if p.grad is not None else torch.zeros_like(p)
+            gn[n] = float(gr.norm())
+            if p.numel() <= 8192 or tag.startswith("tiny"):
+                out[f"{tag}.grad.{n}"] = gr.numpy().copy()
+            else:
+                out[f"{tag}.gradsub.{n}"] = sub(gr, 1024)
+    meta[f"{tag}.grad_norms"] = gn
+    print(tag, "loss0", float(loss), "fwd+bwd s", round(dt, 2), "trainable", n_train, "total", n_total)
+    tr.optim.zero_grad()
+
+    # K-step trajectory through the reference's own forward_backward
+    traj = []
+    for i in range(steps):
+        tr.batch_idx = i
+        s = tr.forward_backward(batch)
+        traj.append(s)
+        print(tag, "step", i, s)
+    meta[f"{tag}.traj"] = traj
+    post = model.state_dict()
+    for k in synth.trainable_keys(mcfg):
+        if post[k].numel() <= 8192 or tag.startswith("tiny"):
+            out[f"{tag}.post.{k}"] = post[k].detach().numpy().copy()
+    meta[f"{tag}.post_checksum"] = {k: float(post[k].double().sum()) for k in synth.trainable_keys(mcfg)}
+    return model
+
+
+def golden_fedavg(FU, out, meta):
+    G, r = 3, 8
+    keys = {"a.lora_S.weight": (G, r), "a.lora_A.weight": (16, r), "prompt_learner.ctx": (2, 4, 8),
+            "frozen.weight": (5, 5), "b.lora_S.weight": (G, r)}
+    for case, (epoch, shared) in {"e0_shared": (0, True), "e3_shared": (3, True), "e3_plain": (3, False)}.items():
+        w = {u: {k: rng_tensor(f"fed.{case}.{u}.{k}", s) for k, s in keys.items()} for u in range(3)}
+        w_g = {k: rng_tensor(f"fed.{case}.g.{k}", s) for k, s in keys.items()}
+        n_client = [100, 50, 25]
+        by_attr = [[50, 30, 20], [10, 20, 20], [5, 5, 15]]
+        idxs = [0, 2] if case == "e3_plain" else [0, 1, 2]
+        res = FU.average_weights_EMA(w_g, w, idxs, n_client, by_attr, epoch, 10, shared_half_s=shared)
+        for k in keys:
+            out[f"fed.{case}.{k}"] = res[k].numpy()
+        meta[f"fed.{case}"] = {"epoch": epoch, "max_epoch": 10, "shared_half_s": shared, "idxs": idxs,
+                               "n_client": n_client, "by_attr": by_attr}
+
+
+def golden_auc(compute_auc, out, meta):
+    g = synth._rng("auc", 7)
+    cases = {}
+    for name, n in (("n32", 32), ("n200", 200)):
+        y = g.integers(0, 2, size=(n,))
+        logit = g.standard_normal((n, 2)).astype(np.float32) + y[:, None] * np.array([[-0.5, 0.5]], np.float32)
+        if name == "n200":
+            logit = np.round(logit, 1)   # force ties
+        prob = torch.softmax(torch.from_numpy(logit), -1)
+        cases[name] = float(compute_auc(prob, torch.from_numpy(y)))
+        out[f"auc.{name}.prob"] = prob.numpy()
+        out[f"auc.{name}.y"] = y.astype(np.int64)
+    meta["auc"] = cases
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
+    ap.add_argument("--time-ref", action="store_true", help="time the reference CPU step at bs=32")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    M, CLIP, FU, compute_auc = import_reference()
+
+    out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
+    golden_layers(M, out)
+    golden_s_init(M, out)
+    golden_fedavg(FU, out, meta)
+    golden_auc(compute_auc, out, meta)
+    np.savez_compressed(os.path.join(HERE, "unit.npz"), **out)
+
+    out = {}
+    golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_r4", 8, 3, out, meta)
+    golden_model(M, CLIP, C.vit_tiny(rank=8, num_groups=2), "tiny_r8g2", 6, 2, out, meta)
+    golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_refinit", 8, 3, out, meta, lora_init="reference")
+    np.savez_compressed(os.path.join(HERE, "tiny.npz"), **out)
+
+    if args.vitb:
+        out = {}
+        golden_model(M, CLIP, C.vit_b16(rank=8), "vitb_r8", 8, 3, out, meta)
+        np.savez_compressed(os.path.join(HERE, "vitb.npz"), **out)
+    else:
+        prev = os.path.join(HERE, "meta.json")
+        if os.path.exists(prev):
+            old = json.load(open(prev))
+            for k, v in old.items():
+                if k.startswith("vitb") or k.startswith("ref_cpu"):
+                    meta.setdefault(k, v)
+
+    if args.time_ref:
+        mcfg = C.vit_b16(rank=8)
+        sd = synth.make_state_dict(mcfg, seed=1)
+        model = build_reference_model(M, CLIP, mcfg, sd)
+        batch = synth.make_batch(mcfg, 32, seed=1234)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        attr = batch["attrs"].t()[0]
+        times = []
+        for i in range(4):
+            t0 = time.time()
+            loss = torch.nn.functional.cross_entropy(model(batch["img"], attr), batch["label"])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            times.append(time.time() - t0)
+            print("ref step", i, times[-1])
+        meta["ref_cpu_step_s_bs32"] = times
+        meta["ref_cpu_threads"] = torch.get_num_threads()
+
+    json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1, sort_keys=True)
+    print("wrote goldens to", HERE)
+
+
+if __name__ == "__main__":
+    main()

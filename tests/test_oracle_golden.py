@@ -1,0 +1,156 @@
+"""Pin the oracle (oracle/fairlora_oracle.py) against golden vectors produced by
+the imported reference (tests/golden/make_golden.py).  fp32, rtol 1e-5 (plus a
+small atol for near-zero entries): the two sides run the same PyTorch CPU
+kernels in a different op order."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fairfedmed_amd import config as C
+from fairfedmed_amd import synth
+from oracle import fairlora_oracle as O
+
+from tests.golden.make_golden import LAYER_CASES, layer_inputs, rng_tensor, sub
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = np.abs(a - b)
+    bad = err > atol * scale + rtol * np.abs(b)
+    assert not bad.any(), f"{what}: max err {err.max():.3e} (scale {scale:.3e}), {bad.sum()} bad"
+
+
+@pytest.fixture(scope="module")
+def unit(golden_dir):
+    return np.load(os.path.join(golden_dir, "unit.npz"))
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "meta.json")))
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_fairlora_layer(unit, case):
+    name, L, Bn, fin, fout, r, G, S, hw = case
+    x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+    scaling = 2.0 / r
+    if hw:
+        xin = x.permute(1, 2, 0).reshape(Bn, fin, hw[0], hw[1])
+        y = O.fairlora_linear(xin, W.reshape(fout, fin, 1, 1), None, A, Sm, Bm, attr, scaling)
+        y = y.reshape(Bn, fout, -1).permute(2, 0, 1)
+    else:
+        y = O.fairlora_linear(x, W, bias, A, Sm, Bm, attr, scaling)
+    dx, dA, dS, dB = O.fairlora_backward(x, g, W, A, Sm, Bm, attr, scaling)
+    gy = unit[f"layer.{name}.y"]
+    close(y.numpy() if y.numel() <= 65536 else sub(y), gy, rtol=2e-5, atol=2e-6, what="y")
+    gdx = unit[f"layer.{name}.dx"]
+    close(dx.numpy() if dx.numel() <= 65536 else sub(dx), gdx, rtol=2e-5, atol=2e-6, what="dx")
+    close(dA.numpy(), unit[f"layer.{name}.dA"], rtol=2e-5, atol=2e-6, what="dA")
+    close(dS.numpy(), unit[f"layer.{name}.dS"], rtol=2e-5, atol=2e-6, what="dS")
+    close(dB.numpy(), unit[f"layer.{name}.dB"], rtol=2e-5, atol=2e-6, what="dB")
+
+
+def test_fairlora_backward_matches_autograd():
+    case = LAYER_CASES[0]
+    name, L, Bn, fin, fout, r, G, S, hw = case
+    x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+    xs = [t.double().requires_grad_(True) for t in (x, A, Sm, Bm)]
+    y = O.fairlora_linear(xs[0], W.double(), bias.double(), xs[1], xs[2], xs[3], attr, 0.5)
+    y.backward(g.double())
+    dx, dA, dS, dB = O.fairlora_backward(x.double(), g.double(), W.double(), A.double(), Sm.double(),
+                                         Bm.double(), attr, 0.5)
+    for got, ref in zip((dx, dA, dS, dB), (t.grad for t in xs)):
+        assert torch.allclose(got, ref, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("r", [4, 8, 12, 16, 32])
+@pytest.mark.parametrize("G", [2, 3])
+def test_lora_s_init(unit, r, G):
+    close(synth.lora_s_init(r, G).numpy(), unit[f"s_init.r{r}.g{G}"], rtol=0, atol=1e-7)
+
+
+def test_lora_s_init_known_rows():
+    # SURVEY.md §8(c) (ii)
+    s = synth.lora_s_init(8, 3)
+    np.testing.assert_allclose(s[0].numpy(), [.5, .3667, .2333, .1, .1, .0733, .0467, .02], atol=1e-4)
+    np.testing.assert_allclose(s[1, 4:].numpy(), [.0733, .0467, .02, .1], atol=1e-4)
+    s4 = synth.lora_s_init(4, 3)
+    for g in range(3):
+        np.testing.assert_allclose(s4[g].numpy(), [.5, .1, .1, .02], atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["e0_shared", "e3_shared", "e3_plain"])
+def test_fedavg_ema(unit, meta, case):
+    m = meta[f"fed.{case}"]
+    keys = {"a.lora_S.weight": (3, 8), "a.lora_A.weight": (16, 8), "prompt_learner.ctx": (2, 4, 8),
+            "frozen.weight": (5, 5), "b.lora_S.weight": (3, 8)}
+    w = {u: {k: rng_tensor(f"fed.{case}.{u}.{k}", s) for k, s in keys.items()} for u in range(3)}
+    w_g = {k: rng_tensor(f"fed.{case}.g.{k}", s) for k, s in keys.items()}
+    res = O.average_weights_ema(w_g, w, m["idxs"], m["n_client"], m["by_attr"], m["epoch"], m["max_epoch"],
+                                shared_half_s=m["shared_half_s"])
+    for k in keys:
+        close(res[k].numpy(), unit[f"fed.{case}.{k}"], rtol=1e-6, atol=1e-7, what=k)
+
+
+@pytest.mark.parametrize("name", ["n32", "n200"])
+def test_auc(unit, meta, name):
+    got = O.auc_binary(unit[f"auc.{name}.prob"], unit[f"auc.{name}.y"])
+    assert abs(got - meta["auc"][name]) < 1e-12
+
+
+TINY = {
+    "tiny_r4": (C.vit_tiny(rank=4), 8, "random"),
+    "tiny_r8g2": (C.vit_tiny(rank=8, num_groups=2), 6, "random"),
+    "tiny_refinit": (C.vit_tiny(rank=4), 8, "reference"),
+}
+
+
+@pytest.mark.parametrize("tag", list(TINY))
+def test_tiny_model_step_and_trajectory(golden_dir, meta, tag):
+    mcfg, bs, init = TINY[tag]
+    gold = np.load(os.path.join(golden_dir, "tiny.npz"))
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init=init)
+    batch = synth.make_batch(mcfg, bs, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    assert sum(sd[k].numel() for k in keys) == meta[f"{tag}.trainable_elems"]
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    close(logits.numpy(), gold[f"{tag}.logits"], rtol=1e-5, atol=1e-6, what="logits")
+    assert abs(float(loss) - meta[f"{tag}.loss0"]) <= 1e-5 * abs(meta[f"{tag}.loss0"])
+    for k in keys:
+        close(grads[k].numpy(), gold[f"{tag}.grad.{k}"], rtol=1e-4, atol=2e-6, what=k)
+    opt = O.SgdState()
+    for ref in meta[f"{tag}.traj"]:
+        s, _, _ = O.train_step(sd, opt, batch, mcfg, keys)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"]), (s, ref)
+        assert abs(s["acc"] - ref["acc"]) < 1e-4
+        assert abs(s["auc"] - ref["auc"]) < 1e-9
+    for k in keys:
+        close(sd[k].numpy(), gold[f"{tag}.post.{k}"], rtol=1e-5, atol=1e-6, what="post." + k)
+
+
+def test_vitb_step(golden_dir, meta):
+    path = os.path.join(golden_dir, "vitb.npz")
+    if not os.path.exists(path):
+        pytest.skip("vitb.npz not generated")
+    gold = np.load(path)
+    mcfg = C.vit_b16(rank=8)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    keys = synth.trainable_keys(mcfg)
+    assert sum(sd[k].numel() for k in keys) == meta["vitb_r8.trainable_elems"] == 741952
+    assert sum(v.numel() for k, v in sd.items() if "token_" not in k) == meta["vitb_r8.total_params"] == 125065793
+    assert len(keys) == meta["vitb_r8.trainable_tensors"] == 73
+    batch = synth.make_batch(mcfg, 8, seed=1234)
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    close(logits.numpy(), gold["vitb_r8.logits"], rtol=1e-4, atol=1e-5, what="logits")
+    assert abs(float(loss) - meta["vitb_r8.loss0"]) <= 1e-5 * abs(meta["vitb_r8.loss0"])
+    for k in keys:
+        n = float(grads[k].norm())
+        ref = meta["vitb_r8.grad_norms"][k]
+        assert abs(n - ref) <= 1e-3 * ref + 1e-9, (k, n, ref)
