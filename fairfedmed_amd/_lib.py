@@ -1,0 +1,105 @@
+"""ctypes binding of libffm_hip.so (include/ffm_hip.h).
+
+The product path has NO fallback: if the library is missing, or a call returns
+a non-zero status, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libffm_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU = 1, 2, 4, 8, 16, 32
+ABI_VERSION = 1
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a", _vp), ("b", _vp), ("c", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("lda", _i32), ("ldb", _i32), ("ldc", _i32),
+        ("flags", _i32), ("rank", _i32),
+        ("bias", _vp), ("ts", _vp), ("lw", _vp), ("res", _vp), ("c2", _vp), ("aux", _vp),
+    ]
+
+
+# name -> argtypes (restype is always int, except the two helpers)
+SIGNATURES = {
+    "ffm_abi_version": [],
+    "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
+    "ffm_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _i32, _vp],
+    "ffm_embed_lnpre": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
+                      _i32, _vp],
+    "ffm_lora_down_blocks": [_i32],
+    "ffm_lora_grad_partial": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "ffm_lora_grad_splits": [_i32],
+    "ffm_reduce_partials": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "ffm_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_ce_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_sgd_momentum": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
+    "ffm_scale_by": [_vp, _vp, _vp, _i64, _vp],
+    "ffm_fedavg_finish": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "ffm_cast_f32_to": [_vp, _vp, _i64, _i32, _vp],
+    "ffm_cast_to_f32": [_vp, _vp, _i64, _i32, _vp],
+    "ffm_transpose_cast": [_vp, _vp, _i32, _i32, _i32, _vp],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly (no CPU / PyTorch fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m fairfedmed_amd.build` "
+            "(the FairLoRA engine has no fallback path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    v = lib.ffm_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libffm_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}"
+                           + (" (invalid argument)" if status == -1 else " (unsupported size)" if status == -2
+                              else " (HIP error)"))
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

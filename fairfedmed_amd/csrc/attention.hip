@@ -1,0 +1,515 @@
+// Multi-head self-attention, head_dim 64, whole key range per workgroup
+// (L <= 256: 197 vision tokens, 77 text tokens), MFMA 16x16.
+//
+// Orientation: scores are computed transposed, S^T = K Q^T, so a lane holds one
+// query column (q = lane & 15) and 4 consecutive keys per 16-key fragment
+// (key = 16 f + 4 (lane>>4) + e).  That accumulator is directly the B operand of
+// the next product (O^T = V^T P^T, dQ^T = K^T dS^T, ...) with the k-order
+// permuted identically on the A side, so P never goes through LDS.  The A side
+// of those products needs the key (or query) index contiguous per lane, so V /
+// K / Q / dO are staged TRANSPOSED in LDS ([64 d][tokens], zero padded).
+//
+//   forward : one block per (b, h, q-split); waves own 16-row q tiles.
+//   backward: delta = rowsum(dO * O); dQ kernel (same shape as forward);
+//             dK/dV kernel: waves own 16-key tiles and sweep all queries.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+
+template <typename T> struct AT;     // per-dtype attention helpers
+template <> struct AT<bf16_t> {
+    typedef bf16x8 frag_t;
+    static constexpr int ES = 2, ROWB = 128, NCH = 8, ND = 2, CE = 8;
+    static constexpr int FPK = 2;    // 16-token fragments per second-product k-step
+    static __device__ __forceinline__ frag_t pack(const f32x4* p, int s) {
+        const f32x4 a = p[2 * s], b = p[2 * s + 1];
+        frag_t r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
+                    (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+        return r;
+    }
+    // A fragment of a transposed tile Xt[d][token] for k-step s: tokens
+    // 32 s + 16 (j>>2) + 4 g + (j&3), j = 0..7  (matches pack()).
+    static __device__ __forceinline__ frag_t tfrag(const bf16_t* xt, int ts, int d, int s, int g) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(xt + (size_t)d * ts + 32 * s + 4 * g);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(xt + (size_t)d * ts + 32 * s + 16 + 4 * g);
+        frag_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return r;
+    }
+};
+template <> struct AT<float> {
+    typedef f32x4 frag_t;
+    static constexpr int ES = 4, ROWB = 256, NCH = 16, ND = 4, CE = 4;
+    static constexpr int FPK = 1;
+    static __device__ __forceinline__ frag_t pack(const f32x4* p, int s) { return p[s]; }
+    static __device__ __forceinline__ frag_t tfrag(const float* xt, int ts, int d, int s, int g) {
+        return *reinterpret_cast<const f32x4*>(xt + (size_t)d * ts + 16 * s + 4 * g);
+    }
+};
+
+// element stride of a transposed tile row: bytes = roundup(LP*ES, 32) + 16
+// (rows 16 B apart modulo 32 B keep the 16-row fragment reads off each other's banks)
+template <typename T> __host__ __device__ inline int tstride(int LP) {
+    const int bytes = ((LP * AT<T>::ES + 31) / 32) * 32 + 16;
+    return bytes / AT<T>::ES;
+}
+
+// swizzled byte offset of 16-B chunk `c` of row `row` in a row-major [rows][64] LDS tile
+template <typename T> __device__ __forceinline__ int rm_off(int row, int c) {
+    return row * AT<T>::ROWB + ((c ^ (row & (AT<T>::NCH - 1))) << 4);
+}
+
+// row-major tile (zero rows >= L) -> LDS, swizzled
+template <typename T>
+__device__ __forceinline__ void stage_rowmajor(const T* __restrict__ src, int ld, int L, int LP, char* dst, int tid) {
+    typedef typename AT<T>::frag_t frag_t;
+    for (int idx = tid; idx < LP * AT<T>::NCH; idx += 256) {
+        const int row = idx / AT<T>::NCH, c = idx % AT<T>::NCH;
+        frag_t v;
+#pragma unroll
+        for (int e = 0; e < AT<T>::CE; ++e) v[e] = (T)0.f;
+        if (row < L) v = *reinterpret_cast<const frag_t*>(src + (size_t)row * ld + c * AT<T>::CE);
+        *reinterpret_cast<frag_t*>(dst + rm_off<T>(row, c)) = v;
+    }
+}
+
+// transposed tile Xt[d][token] (zero tokens >= L) -> LDS
+template <typename T>
+__device__ __forceinline__ void stage_transposed(const T* __restrict__ src, int ld, int L, int LP, T* dst, int ts,
+                                                 int tid) {
+    typedef typename AT<T>::frag_t frag_t;
+    // consecutive threads take consecutive tokens (conflict-free LDS writes), chunks outer
+    for (int idx = tid; idx < LP * AT<T>::NCH; idx += 256) {
+        const int c = idx / LP, tok = idx % LP;
+        frag_t v;
+#pragma unroll
+        for (int e = 0; e < AT<T>::CE; ++e) v[e] = (T)0.f;
+        if (tok < L) v = *reinterpret_cast<const frag_t*>(src + (size_t)tok * ld + c * AT<T>::CE);
+#pragma unroll
+        for (int e = 0; e < AT<T>::CE; ++e) dst[(size_t)(c * AT<T>::CE + e) * ts + tok] = v[e];
+    }
+}
+
+// 16-B operand fragment of row `row` (clamped) straight from global memory
+template <typename T>
+__device__ __forceinline__ typename AT<T>::frag_t gfrag(const T* __restrict__ src, int ld, int row, int L, int ks,
+                                                        int g) {
+    const int r = row < L ? row : L - 1;
+    return *reinterpret_cast<const typename AT<T>::frag_t*>(src + (size_t)r * ld + (ks * 4 + g) * AT<T>::CE);
+}
+
+__device__ __forceinline__ float group4_max(float v) {   // lanes l, l^16, l^32, l^48 share a column
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T, int NFP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                       float* __restrict__ lse, int L, int heads, int causal,
+                                                       int qsplit) {
+    typedef typename AT<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LP = NFP * 16;
+    const int ts = tstride<T>(LP);
+    char* Ks = smem;                                              // [LP][64] swizzled
+    T* Vt = reinterpret_cast<T*>(smem + LP * AT<T>::ROWB);        // [64][ts]
+
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+
+    stage_rowmajor<T>(base + E, ld, L, LP, Ks, tid);
+    stage_transposed<T>(base + 2 * E, ld, L, LP, Vt, ts, tid);
+    __syncthreads();
+
+    const int NF = (L + 15) / 16;
+    const int per = (NF + qsplit - 1) / qsplit;
+    const int qt0 = blockIdx.y * per;
+    const int qt1 = (qt0 + per) < NF ? (qt0 + per) : NF;
+    for (int qt = qt0 + wave; qt < qt1; qt += 4) {
+        const int q = qt * 16 + col;
+        frag_t qf[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks) qf[ks] = gfrag<T>(base, ld, q, L, ks, g);
+
+        f32x4 s[NFP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + rm_off<T>(f * 16 + col, ks * 4 + g));
+                Mma16<T>::mma(acc, kf, qf[ks]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = f * 16 + g * 4 + e;
+                float v = acc[e] * 0.125f;
+                if (key >= L || (causal && key > q)) v = -INFINITY;
+                acc[e] = v;
+                mx = fmaxf(mx, v);
+            }
+            s[f] = acc;
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads from being hoisted across f (VGPR pressure)
+        }
+        mx = group4_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int f = 0; f < NFP; ++f)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = __expf(s[f][e] - mx);
+                s[f][e] = p;
+                sum += p;
+            }
+        sum = group4_sum(sum);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+            const frag_t pf = AT<T>::pack(s, st);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const frag_t vf = AT<T>::tfrag(Vt, ts, fd * 16 + col, st, g);
+                Mma16<T>::mma(o[fd], vf, pf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < L) {
+            const float inv = 1.0f / sum;
+            T* orow = out + ((size_t)b * L + q) * E + h * HD;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                f32x4 v = o[fd];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= inv;
+                Vec4<T>::store(orow + fd * 16 + g * 4, v);
+            }
+            if (g == 0 && lse) lse[((size_t)b * heads + h) * L + q] = mx + __logf(sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward: delta[b,h,q] = sum_d dO[q][d] * O[q][d]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
+                                                         float* __restrict__ delta, int B, int L, int heads) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, l, h)
+    if (idx >= B * L * heads) return;
+    const int h = idx % heads, row = idx / heads;                 // row = b*L + l
+    const size_t off = (size_t)row * heads * HD + h * HD + lane;
+    float v = Elem<T>::to_f(o[off]) * Elem<T>::to_f(d_o[off]);
+    v = wave_sum(v);
+    if (lane == 0) {
+        const int b = row / L, l = row % L;
+        delta[((size_t)b * heads + h) * L + l] = v;
+    }
+}
+
+// dQ: same decomposition as forward.  dS^T[key][q] = P^T * (dP^T - delta[q]) * scale,
+// dQ^T[d][q] = sum_key Kt[d][key] dS^T[key][q].
+template <typename T, int NFP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                          const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                          int L, int heads, int causal, int qsplit) {
+    typedef typename AT<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LP = NFP * 16;
+    const int ts = tstride<T>(LP);
+    T* Kt = reinterpret_cast<T*>(smem);                           // [64][ts]
+
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + h * HD;
+    const T* dob = d_o + (size_t)b * L * E + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+
+    stage_transposed<T>(base + E, ld, L, LP, Kt, ts, tid);
+    __syncthreads();
+
+    const int NF = (L + 15) / 16;
+    const int per = (NF + qsplit - 1) / qsplit;
+    const int qt0 = blockIdx.y * per;
+    const int qt1 = (qt0 + per) < NF ? (qt0 + per) : NF;
+    for (int qt = qt0 + wave; qt < qt1; qt += 4) {
+        // the K/V fragment loads below do not depend on qt: without this compiler-level fence LICM
+        // hoists all of them out of the loop and keeps NFP*ND*2 fragments live (spills)
+        asm volatile("" ::: "memory");
+        const int q = qt * 16 + col;
+        const int qc = q < L ? q : L - 1;
+        frag_t qf[AT<T>::ND], dof[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks) {
+            qf[ks] = gfrag<T>(base, ld, q, L, ks, g);
+            dof[ks] = gfrag<T>(dob, E, q, L, ks, g);
+        }
+        const float lq = lse[((size_t)b * heads + h) * L + qc];
+        const float dl = delta[((size_t)b * heads + h) * L + qc];
+
+        f32x4 ds[NFP];
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                const frag_t kf = gfrag<T>(base + E, ld, f * 16 + col, L, ks, g);
+                const frag_t vf = gfrag<T>(base + 2 * E, ld, f * 16 + col, L, ks, g);
+                Mma16<T>::mma(sa, kf, qf[ks]);
+                Mma16<T>::mma(pa, vf, dof[ks]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = f * 16 + g * 4 + e;
+                float v = 0.f;
+                if (key < L && !(causal && key > q)) {
+                    const float p = __expf(sa[e] * 0.125f - lq);
+                    v = p * (pa[e] - dl) * 0.125f;
+                }
+                sa[e] = v;
+            }
+            ds[f] = sa;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+            const frag_t pf = AT<T>::pack(ds, st);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const frag_t kf = AT<T>::tfrag(Kt, ts, fd * 16 + col, st, g);
+                Mma16<T>::mma(o[fd], kf, pf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < L) {
+            T* drow = dqkv + ((size_t)b * L + q) * ld + h * HD;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) Vec4<T>::store(drow + fd * 16 + g * 4, o[fd]);
+        }
+    }
+}
+
+// dK/dV: waves own 16-key tiles; a lane holds key = lane&15 and 4 consecutive
+// queries per fragment.  S[q][key] = Q K^T (A = Q rows), dP[q][key] = dO V^T,
+// dV^T[d][key] = sum_q dOt[d][q] P[q][key],  dK^T[d][key] = sum_q Qt[d][q] dS[q][key].
+template <typename T, int NFP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                           const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                           int L, int heads, int causal, int ksplit) {
+    typedef typename AT<T>::frag_t frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LP = NFP * 16;
+    const int ts = tstride<T>(LP);
+    T* Qt = reinterpret_cast<T*>(smem);                           // [64][ts]
+    T* dOt = Qt + (size_t)HD * ts;                                // [64][ts]
+    float* lse_s = reinterpret_cast<float*>(dOt + (size_t)HD * ts);   // [LP]
+    float* del_s = lse_s + LP;                                    // [LP]
+
+    const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + h * HD;
+    const T* dob = d_o + (size_t)b * L * E + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+
+    stage_transposed<T>(base, ld, L, LP, Qt, ts, tid);
+    stage_transposed<T>(dob, E, L, LP, dOt, ts, tid);
+    for (int i = tid; i < LP; i += 256) {
+        lse_s[i] = i < L ? lse[((size_t)b * heads + h) * L + i] : 0.f;
+        del_s[i] = i < L ? delta[((size_t)b * heads + h) * L + i] : 0.f;
+    }
+    __syncthreads();
+
+    const int NF = (L + 15) / 16;
+    const int per = (NF + ksplit - 1) / ksplit;
+    const int kt0 = blockIdx.y * per;
+    const int kt1 = (kt0 + per) < NF ? (kt0 + per) : NF;
+    for (int kt = kt0 + wave; kt < kt1; kt += 4) {
+        asm volatile("" ::: "memory");   // same LICM fence as in the dQ kernel (Q / dO fragments)
+        const int key = kt * 16 + col;
+        frag_t kf[AT<T>::ND], vf[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks) {
+            kf[ks] = gfrag<T>(base + E, ld, key, L, ks, g);
+            vf[ks] = gfrag<T>(base + 2 * E, ld, key, L, ks, g);
+        }
+        f32x4 pp[NFP], ds[NFP];
+#pragma unroll
+        for (int f = 0; f < NFP; ++f) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                const frag_t qf = gfrag<T>(base, ld, f * 16 + col, L, ks, g);
+                const frag_t dof = gfrag<T>(dob, E, f * 16 + col, L, ks, g);
+                Mma16<T>::mma(sa, qf, kf[ks]);
+                Mma16<T>::mma(pa, dof, vf[ks]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = f * 16 + g * 4 + e;
+                float p = 0.f, d = 0.f;
+                if (q < L && key < L && !(causal && key > q)) {
+                    p = __expf(sa[e] * 0.125f - lse_s[q]);
+                    d = p * (pa[e] - del_s[q]) * 0.125f;
+                }
+                sa[e] = p;
+                pa[e] = d;
+            }
+            pp[f] = sa;
+            ds[f] = pa;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) { dv[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+            const frag_t pf = AT<T>::pack(pp, st);
+            const frag_t df = AT<T>::pack(ds, st);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const frag_t a1 = AT<T>::tfrag(dOt, ts, fd * 16 + col, st, g);
+                const frag_t a2 = AT<T>::tfrag(Qt, ts, fd * 16 + col, st, g);
+                Mma16<T>::mma(dv[fd], a1, pf);
+                Mma16<T>::mma(dk[fd], a2, df);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (key < L) {
+            T* drow = dqkv + ((size_t)b * L + key) * ld + h * HD;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                Vec4<T>::store(drow + E + fd * 16 + g * 4, dk[fd]);
+                Vec4<T>::store(drow + 2 * E + fd * 16 + g * 4, dv[fd]);
+            }
+        }
+    }
+}
+
+template <typename T> int lds_fwd(int NFP) { return NFP * 16 * AT<T>::ROWB + HD * tstride<T>(NFP * 16) * AT<T>::ES; }
+template <typename T> int lds_dq(int NFP) { return HD * tstride<T>(NFP * 16) * AT<T>::ES; }
+template <typename T> int lds_dkv(int NFP) { return 2 * HD * tstride<T>(NFP * 16) * AT<T>::ES + 2 * NFP * 16 * 4; }
+
+template <typename F> int set_lds(F fn, int bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+inline int pick_split(int bh, int NF) {
+    // aim for >= ~3 blocks per CU while keeping >= 4 tiles (one per wave) per block
+    int s = 1;
+    while (bh * s < 768 && (NF + s) / (s + 1) >= 4) ++s;
+    return s;
+}
+
+template <typename T, int NFP>
+int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int causal, hipStream_t s) {
+    const int NF = (L + 15) / 16, split = pick_split(B * heads, NF);
+    const int lds = lds_fwd<T>(NFP);
+    int e = set_lds(attn_fwd_kernel<T, NFP>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv, (T*)out,
+                       lse, L, heads, causal, split);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+template <typename T, int NFP>
+int run_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+            int L, int heads, int causal, hipStream_t s) {
+    const int NF = (L + 15) / 16, split = pick_split(B * heads, NF);
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((B * L * heads + 3) / 4), dim3(256), 0, s, (const T*)out,
+                       (const T*)dout, delta, B, L, heads);
+    FFM_CHECK_LAUNCH();
+    int lds = lds_dq<T>(NFP);
+    int e = set_lds(attn_bwd_dq_kernel<T, NFP>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv,
+                       (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal, split);
+    FFM_CHECK_LAUNCH();
+    lds = lds_dkv<T>(NFP);
+    e = set_lds(attn_bwd_dkv_kernel<T, NFP>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv,
+                       (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal, split);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+#define NFP_SWITCH(CALL)                 \
+    switch (nfp) {                       \
+        case 2: return CALL(2);          \
+        case 4: return CALL(4);          \
+        case 6: return CALL(6);          \
+        case 8: return CALL(8);          \
+        case 10: return CALL(10);        \
+        case 12: return CALL(12);        \
+        case 14: return CALL(14);        \
+        case 16: return CALL(16);        \
+        default: return FFM_EUNSUP;      \
+    }
+
+template <typename T>
+int dispatch_fwd(int nfp, const void* qkv, void* out, float* lse, int B, int L, int heads, int causal, hipStream_t s) {
+#define CALL(N) run_fwd<T, N>(qkv, out, lse, B, L, heads, causal, s)
+    NFP_SWITCH(CALL)
+#undef CALL
+}
+template <typename T>
+int dispatch_bwd(int nfp, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                 void* dqkv, int B, int L, int heads, int causal, hipStream_t s) {
+#define CALL(N) run_bwd<T, N>(qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s)
+    NFP_SWITCH(CALL)
+#undef CALL
+}
+
+}  // namespace
+
+extern "C" int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int causal,
+                                 int dtype, void* stream) {
+    if (!qkv || !out || B <= 0 || L <= 0 || heads <= 0) return FFM_EINVAL;
+    if (L > 256) return FFM_EUNSUP;
+    if (((uintptr_t)qkv | (uintptr_t)out) & 15) return FFM_EINVAL;
+    const int nfp = (((L + 15) / 16) + 1) & ~1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16) return dispatch_fwd<bf16_t>(nfp, qkv, out, lse, B, L, heads, causal, s);
+    if (dtype == FFM_F32) return dispatch_fwd<float>(nfp, qkv, out, lse, B, L, heads, causal, s);
+    return FFM_EINVAL;
+}
+
+extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                 void* dqkv, int B, int L, int heads, int causal, int dtype, void* stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv || B <= 0 || L <= 0 || heads <= 0) return FFM_EINVAL;
+    if (L > 256) return FFM_EUNSUP;
+    if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return FFM_EINVAL;
+    const int nfp = (((L + 15) / 16) + 1) & ~1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16) return dispatch_bwd<bf16_t>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
+    if (dtype == FFM_F32) return dispatch_bwd<float>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
+    return FFM_EINVAL;
+}

@@ -1,0 +1,156 @@
+// Flat-buffer parameter kernels: fused SGD-momentum over all trainable tensors,
+// the FedAvg round-boundary helpers, and load-time dtype casts / transposes.
+#include "common.h"
+
+namespace {
+
+// torch.optim.SGD, dampening 0, no nesterov (Dassl/dassl/optim/optimizer.py:105-113)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, int64_t n, float lr, float mu, float wd,
+                                                  int first) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float d = g[i] + wd * pi;
+        const float b = first ? d : mu * buf[i] + d;
+        buf[i] = b;
+        p[i] = pi - lr * b;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                       float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = p[i] * w[i];
+}
+
+// utils/fed_utils.py:88-98: optional shared_half_s, then EMA with the previous global
+__global__ __launch_bounds__(256) void shared_half_kernel(float* __restrict__ avg, const int64_t* __restrict__ offs,
+                                                          int n_s, int G, int r) {
+    const int blk = blockIdx.x;
+    if (blk >= n_s) return;
+    float* s = avg + offs[blk];
+    const int half = r / 2;
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        float m = 0.f;
+        for (int g = 0; g < G; ++g) m += s[g * r + j];
+        m /= (float)G;
+        for (int g = 0; g < G; ++g) s[g * r + j] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(const float* __restrict__ avg, const float* __restrict__ prev,
+                                                  float* __restrict__ out, int64_t n, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (1.0f - beta) * avg[i] + beta * prev[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = Elem<T>::from_f(src[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                          int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = Elem<T>::to_f(src[i]);
+}
+
+// dst[c][r] = src[r][c], 32x32 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                             int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * rows + r] = Elem<T>::from_f(tile[tx][i]);
+    }
+}
+
+inline int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int ffm_abi_version(void) { return FFM_ABI_VERSION; }
+
+extern "C" int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                float weight_decay, int first_step, void* stream) {
+    if (!p || !g || !buf || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
+                       weight_decay, first_step);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_scale_by(const float* p, const float* w, float* out, int64_t n, void* stream) {
+    if (!p || !w || !out || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, w, out, n);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_fedavg_finish(float* avg, const float* prev, float* out, int64_t n, const int64_t* s_offsets,
+                                 int n_s, int G, int r, int shared_half_s, float beta, void* stream) {
+    if (!avg || !prev || !out || n <= 0) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (shared_half_s && n_s > 0) {
+        if (!s_offsets || G <= 0 || r <= 0) return FFM_EINVAL;
+        hipLaunchKernelGGL(shared_half_kernel, dim3(n_s), dim3(64), 0, s, avg, s_offsets, n_s, G, r);
+        FFM_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, s, avg, prev, out, n, beta);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_cast_f32_to(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    if (!src || !dst || n <= 0) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((cast_from_f32_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, src, (bf16_t*)dst, n);
+    else if (dtype == FFM_F32)
+        hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, src, (float*)dst, n);
+    else
+        return FFM_EINVAL;
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream) {
+    if (!src || !dst || n <= 0) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((cast_to_f32_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)src, dst, n);
+    else if (dtype == FFM_F32)
+        hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)src, dst, n);
+    else
+        return FFM_EINVAL;
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_transpose_cast(const float* src, void* dst, int rows, int cols, int dtype, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((transpose_cast_kernel<bf16_t>), grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols);
+    else if (dtype == FFM_F32)
+        hipLaunchKernelGGL((transpose_cast_kernel<float>), grid, dim3(256), 0, s, src, (float*)dst, rows, cols);
+    else
+        return FFM_EINVAL;
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}

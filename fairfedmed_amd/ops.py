@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C ABI (include/ffm_hip.h).
+
+Each function takes CUDA (ROCm) tensors, checks device/dtype/contiguity and
+enqueues the kernel on PyTorch's current stream.  There is no fallback: a CPU
+tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fairfedmed_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32(t: Optional[Tensor]):
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise TypeError("expected a contiguous fp32 tensor")
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor"
+    return t.stride(0)
+
+
+def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
+            gelu_out=None, dgelu_aux=None) -> Tensor:
+    """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype)."""
+    _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux)
+    assert a.dtype == b.dtype == out.dtype
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and tuple(out.shape) == (M, N)
+    flags, rank = 0, 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+        _f32(bias)
+    if ts is not None:
+        flags |= L.EPI_LORA | (L.EPI_LORA_KR if lw_is_kr else 0)
+        _f32(ts), _f32(lw)
+        rank = ts.shape[1]
+        assert ts.shape[0] >= M and lw.numel() == rank * N
+    for extra in (res, gelu_out, dgelu_aux):
+        if extra is not None:
+            assert extra.dtype == out.dtype and _ld(extra) == _ld(out)
+    if res is not None:
+        flags |= L.EPI_RESIDUAL
+    if gelu_out is not None:
+        flags |= L.EPI_GELU
+    if dgelu_aux is not None:
+        flags |= L.EPI_DGELU
+    args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
+                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux))
+    L.check(L.load().ffm_gemm_nt(C.byref(args), L.dtype_code(a.dtype), L.stream_ptr()), "ffm_gemm_nt")
+    return out
+
+
+def layernorm_fwd(x: Tensor, y: Tensor, gamma: Tensor, beta: Tensor, mean: Optional[Tensor] = None,
+                  rstd: Optional[Tensor] = None) -> Tensor:
+    _dev(x, y, gamma, beta, mean, rstd)
+    rows, width = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype
+    L.check(L.load().ffm_layernorm_fwd(L.ptr(x), L.ptr(y), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(_f32(mean)),
+                                       L.ptr(_f32(rstd)), rows, width, L.dtype_code(x.dtype), L.stream_ptr()),
+            "ffm_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, res: Optional[Tensor],
+                  out: Tensor) -> Tensor:
+    _dev(dy, x, gamma, mean, rstd, res, out)
+    rows, width = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and out.is_contiguous()
+    assert dy.dtype == x.dtype == out.dtype and (res is None or (res.dtype == x.dtype and res.is_contiguous()))
+    L.check(L.load().ffm_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
+                                       L.ptr(res), L.ptr(out), rows, width, L.dtype_code(x.dtype), L.stream_ptr()),
+            "ffm_layernorm_bwd")
+    return out
+
+
+def patchify(img: Tensor, cols: Tensor, patch: int, mean3, std3, prenormalised: bool = False) -> Tensor:
+    _dev(img, cols)
+    B, Cc, H, W = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and cols.is_contiguous()
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    L.check(L.load().ffm_patchify(L.ptr(img), L.ptr(cols), B, H, W, patch, m, s, int(prenormalised),
+                                  L.dtype_code(cols.dtype), L.stream_ptr()), "ffm_patchify")
+    return cols
+
+
+def embed_lnpre(patch: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Tensor, x: Tensor, B: int,
+                Ltok: int) -> Tensor:
+    _dev(patch, cls, pos, gamma, beta, x)
+    width = x.shape[1]
+    assert patch.dtype == cls.dtype == pos.dtype == x.dtype
+    L.check(L.load().ffm_embed_lnpre(L.ptr(patch), L.ptr(cls), L.ptr(pos), L.ptr(_f32(gamma)), L.ptr(_f32(beta)),
+                                     L.ptr(x), B, Ltok, width, L.dtype_code(x.dtype), L.stream_ptr()),
+            "ffm_embed_lnpre")
+    return x
+
+
+def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok: int, heads: int,
+                  causal: bool = False) -> Tensor:
+    _dev(qkv, out, lse)
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == out.dtype
+    assert qkv.shape[1] == 3 * heads * 64 and out.shape[1] == heads * 64
+    L.check(L.load().ffm_attention_fwd(L.ptr(qkv), L.ptr(out), L.ptr(_f32(lse)), B, Ltok, heads, int(causal),
+                                       L.dtype_code(qkv.dtype), L.stream_ptr()), "ffm_attention_fwd")
+    return out
+
+
+def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, delta: Tensor, dqkv: Tensor, B: int,
+                  Ltok: int, heads: int, causal: bool = False) -> Tensor:
+    _dev(qkv, out, dout, lse, delta, dqkv)
+    for t in (qkv, out, dout, dqkv):
+        assert t.is_contiguous() and t.dtype == qkv.dtype
+    L.check(L.load().ffm_attention_bwd(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(_f32(lse)), L.ptr(_f32(delta)),
+                                       L.ptr(dqkv), B, Ltok, heads, int(causal), L.dtype_code(qkv.dtype),
+                                       L.stream_ptr()), "ffm_attention_bwd")
+    return dqkv
+
+
+def lora_down_blocks(M: int) -> int:
+    return L.load().ffm_lora_down_blocks(M)
+
+
+def lora_grad_splits(M: int) -> int:
+    return L.load().ffm_lora_grad_splits(M)
+
+
+def lora_down(x: Tensor, P: Tensor, layout_rk: bool, S: Tensor, attr: Optional[Tensor], r: int, G: int,
+              rows_per_sample: int, scaling: float, lambda_group: float, t: Optional[Tensor], ts: Optional[Tensor],
+              t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None) -> None:
+    _dev(x, P, S, attr, t, ts, t_fwd, ds_part)
+    M, K = x.shape
+    if attr is not None:
+        assert attr.dtype == torch.int32
+    L.check(L.load().ffm_lora_down(L.ptr(x), _ld(x), L.ptr(_f32(P)), int(layout_rk), L.ptr(_f32(S)), L.ptr(attr), M,
+                                   K, r, G, rows_per_sample, scaling, lambda_group, L.ptr(_f32(t)), L.ptr(_f32(ts)),
+                                   L.ptr(_f32(t_fwd)), L.ptr(_f32(ds_part)), L.dtype_code(x.dtype), L.stream_ptr()),
+            "ffm_lora_down")
+
+
+def lora_grad_partial(x: Tensor, v: Tensor, r: int, part: Tensor) -> None:
+    _dev(x, v, part)
+    M, K = x.shape
+    L.check(L.load().ffm_lora_grad_partial(L.ptr(x), _ld(x), L.ptr(_f32(v)), M, K, r, L.ptr(_f32(part)),
+                                           L.dtype_code(x.dtype), L.stream_ptr()), "ffm_lora_grad_partial")
+
+
+def reduce_partials(part: Tensor, nsplit: int, n: int, out: Tensor, transpose_K: int = 0, transpose_r: int = 0,
+                    accumulate: bool = False) -> None:
+    _dev(part, out)
+    L.check(L.load().ffm_reduce_partials(L.ptr(_f32(part)), nsplit, n, L.ptr(out), transpose_K, transpose_r,
+                                         int(accumulate), L.stream_ptr()), "ffm_reduce_partials")
+
+
+def head_fwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: Tensor, logits_img: Tensor, B: int,
+             Ltok: int, n_cls: int) -> None:
+    _dev(f, tbar, logit_scale, fbar, rnorm, logits_img)
+    D = f.shape[1]
+    assert f.is_contiguous()
+    L.check(L.load().ffm_head_fwd(L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
+                                  L.ptr(_f32(rnorm)), L.ptr(_f32(logits_img)), B, Ltok, D, n_cls,
+                                  L.dtype_code(f.dtype), L.stream_ptr()), "ffm_head_fwd")
+
+
+def ce_loss(logits_img: Tensor, label: Tensor, logits: Tensor, prob: Tensor, loss: Tensor, dlogits_img: Tensor,
+            finite: Optional[Tensor], nb: int, S: int, n_cls: int) -> None:
+    _dev(logits_img, label, logits, prob, loss, dlogits_img, finite)
+    assert label.dtype == torch.int64 and (finite is None or finite.dtype == torch.int32)
+    L.check(L.load().ffm_ce_loss(L.ptr(_f32(logits_img)), L.ptr(label), L.ptr(_f32(logits)), L.ptr(_f32(prob)),
+                                 L.ptr(_f32(loss)), L.ptr(_f32(dlogits_img)), L.ptr(finite), nb, S, n_cls,
+                                 L.stream_ptr()), "ffm_ce_loss")
+
+
+def head_bwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: Tensor, dlogits_img: Tensor,
+             df: Tensor, dtbar: Tensor, B: int, Ltok: int, n_cls: int) -> None:
+    _dev(f, tbar, logit_scale, fbar, rnorm, dlogits_img, df, dtbar)
+    D = f.shape[1]
+    assert f.dtype == df.dtype and df.is_contiguous()
+    L.check(L.load().ffm_head_bwd(L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
+                                  L.ptr(_f32(rnorm)), L.ptr(_f32(dlogits_img)), L.ptr(df), L.ptr(_f32(dtbar)), B,
+                                  Ltok, D, n_cls, L.dtype_code(f.dtype), L.stream_ptr()), "ffm_head_bwd")
+
+
+def sgd_momentum(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, weight_decay: float,
+                 first_step: bool) -> None:
+    _dev(p, g, buf)
+    L.check(L.load().ffm_sgd_momentum(L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
+                                      weight_decay, int(first_step), L.stream_ptr()), "ffm_sgd_momentum")
+
+
+def scale_by(p: Tensor, w: Tensor, out: Tensor) -> None:
+    _dev(p, w, out)
+    L.check(L.load().ffm_scale_by(L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(out)), p.numel(), L.stream_ptr()),
+            "ffm_scale_by")
+
+
+def fedavg_finish(avg: Tensor, prev: Tensor, out: Tensor, s_offsets: Optional[Tensor], G: int, r: int,
+                  shared_half_s: bool, beta: float) -> None:
+    _dev(avg, prev, out, s_offsets)
+    n_s = 0 if s_offsets is None else s_offsets.numel()
+    if s_offsets is not None:
+        assert s_offsets.dtype == torch.int64
+    L.check(L.load().ffm_fedavg_finish(L.ptr(_f32(avg)), L.ptr(_f32(prev)), L.ptr(_f32(out)), avg.numel(),
+                                       L.ptr(s_offsets), n_s, G, r, int(shared_half_s), beta, L.stream_ptr()),
+            "ffm_fedavg_finish")
+
+
+def cast_from_f32(src: Tensor, dtype: torch.dtype) -> Tensor:
+    _dev(src)
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.check(L.load().ffm_cast_f32_to(L.ptr(_f32(src.contiguous())), L.ptr(dst), src.numel(), L.dtype_code(dtype),
+                                     L.stream_ptr()), "ffm_cast_f32_to")
+    return dst
+
+
+def cast_to_f32(src: Tensor) -> Tensor:
+    _dev(src)
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    L.check(L.load().ffm_cast_to_f32(L.ptr(src.contiguous()), L.ptr(dst), src.numel(), L.dtype_code(src.dtype),
+                                     L.stream_ptr()), "ffm_cast_to_f32")
+    return dst
+
+
+def transpose_cast(src: Tensor, dtype: torch.dtype) -> Tensor:
+    """[rows, cols] fp32 -> [cols, rows] dtype."""
+    _dev(src)
+    rows, cols = src.shape
+    dst = torch.empty((cols, rows), dtype=dtype, device=src.device)
+    L.check(L.load().ffm_transpose_cast(L.ptr(_f32(src.contiguous())), L.ptr(dst), rows, cols, L.dtype_code(dtype),
+                                        L.stream_ptr()), "ffm_transpose_cast")
+    return dst

@@ -1,0 +1,227 @@
+/*
+ * ffm_hip.h — C ABI of libffm_hip.so, the MI355X (gfx950) kernels behind the
+ * FairLoRA local-training hot path.
+ *
+ * The reference (Harvard-AI-and-Robotics-Lab/FairFedMed) has no FFI: its hot
+ * path is PyTorch calls.  Each entry point below replaces the PyTorch ops named
+ * in its comment (reference file:line); INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's
+ *     allocator); the library allocates nothing and keeps no global state;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work;
+ *   - `dtype` selects the activation / frozen-weight type: FFM_F32 or FFM_BF16.
+ *     LoRA parameters, LayerNorm parameters, biases, statistics, logits and
+ *     all gradients of trainable tensors are always fp32;
+ *   - activations are row-major [rows, features]; a row of the ViT token matrix
+ *     is (image b, token l) -> row b*L + l ("image-major"; the reference's
+ *     [L, B, d] tensors are the same data permuted);
+ *   - return value: 0 ok, FFM_EINVAL (-1) bad shape/alignment/dtype,
+ *     FFM_EUNSUP (-2) unsupported size, otherwise a positive hipError_t.
+ */
+#ifndef FFM_HIP_H
+#define FFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFM_F32 0
+#define FFM_BF16 1
+
+#define FFM_OK 0
+#define FFM_EINVAL (-1)
+#define FFM_EUNSUP (-2)
+
+#define FFM_MAX_RANK 32
+#define FFM_MAX_GROUPS 8
+
+/* library / build identification: returns FFM_ABI_VERSION */
+#define FFM_ABI_VERSION 1
+int ffm_abi_version(void);
+
+/* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
+#define FFM_EPI_BIAS      1   /* + bias[n]                         (fp32 [N])        */
+#define FFM_EPI_LORA      2   /* + sum_j ts[m][j] * lw[j][n]       (rank-r update)   */
+#define FFM_EPI_LORA_KR   4   /* lw is stored [N, r] (lora_A) instead of [r, N]      */
+#define FFM_EPI_RESIDUAL  8   /* + res[m][n]                       (dtype, ld = ldc) */
+#define FFM_EPI_GELU      16  /* also write c2 = quick_gelu(c)                        */
+#define FFM_EPI_DGELU     32  /* c *= quick_gelu'(aux[m][n])       (aux dtype, ldc)  */
+
+typedef struct ffm_gemm_args {
+    const void* a;      /* [M, K] dtype, row stride lda (elements) */
+    const void* b;      /* [N, K] dtype, row stride ldb: C = A * B^T */
+    void*       c;      /* [M, N] dtype, row stride ldc */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t flags;
+    int32_t rank;       /* r, <= FFM_MAX_RANK (LORA only) */
+    const float* bias;  /* [N] */
+    const float* ts;    /* [M, r] fp32: scaling * (xA) * s_b rows (fwd) or scaling * (gB^T) * s_b (bwd) */
+    const float* lw;    /* LoRA matrix, [r, N] or (LORA_KR) [N, r], fp32 */
+    const void*  res;   /* residual [M, N] dtype, stride ldc */
+    void*        c2;    /* GELU: activated output [M, N] dtype, stride ldc */
+    const void*  aux;   /* DGELU: pre-activation [M, N] dtype, stride ldc */
+} ffm_gemm_args;
+
+/*
+ * C = epilogue(A * B^T).  Replaces nn.Linear / F.linear on frozen weights
+ * (trainers/GLP_OT_SVLoRA.py:451; clip/model.py:352 in/out projections, :445
+ * final proj) and, with B = W^T prepared once at load time, the dX products
+ * autograd derives from them.  With FFM_EPI_LORA it is the fused
+ * (W + A diag(s_b) B) x forward / LoRA-dx backward of FairLoRALinear
+ * (trainers/GLP_OT_SVLoRA.py:450-482): the dense dW is never formed.
+ * Requires K*sizeof(dtype) % 128 == 0, N % 8 == 0, 16-byte aligned rows.
+ */
+int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
+
+/*
+ * LayerNorm over the last dimension, fp32 statistics, eps 1e-5
+ * (clip/model.py:304-310).  y = (x-mean)*rstd*gamma + beta; mean/rstd saved
+ * for the backward pass (either may be NULL at inference).
+ */
+int ffm_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta,
+                      float* mean, float* rstd, int rows, int width, int dtype, void* stream);
+
+/*
+ * dx = LayerNorm backward w.r.t. the input only (gamma/beta are frozen),
+ * plus an optional residual gradient: out = (res ? res : 0) + dx.
+ */
+int ffm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, const void* res, void* out, int rows, int width,
+                      int dtype, void* stream);
+
+/*
+ * Patch gather with the input normalisation fused in:
+ *   cols[b*gh*gw + p][c*ps*ps + ky*ps + kx] = ((img/255 - mean[c]) / std[c])
+ * (trainers/GLP_OT_SVLoRA.py:680,692-693 + the im2col view of conv1,
+ * clip/model.py:431).  img is fp32 [B, 3, H, W] raw 0..255.  If
+ * prenormalised != 0 the image is taken as already normalised (3D path).
+ */
+int ffm_patchify(const float* img, void* cols, int B, int H, int W, int patch,
+                 const float* mean3, const float* std3, int prenormalised, int dtype, void* stream);
+
+/*
+ * Token assembly + ln_pre (clip/model.py:432-436): row (b,0) = cls + pos[0],
+ * row (b,1+p) = patch[b*P+p] + pos[1+p]; x = LayerNorm(row).
+ * cls [width] / pos [L, width] are dtype; gamma/beta fp32.
+ */
+int ffm_embed_lnpre(const void* patch, const void* cls, const void* pos, const float* gamma,
+                    const float* beta, void* x, int B, int L, int width, int dtype, void* stream);
+
+/*
+ * Multi-head self-attention core, softmax(Q K^T / sqrt(64)) V, head_dim 64,
+ * optional causal mask (text tower, clip/model.py:562-568); no dropout.
+ * qkv: [B*L, 3*heads*64] rows (b,l) with q|k|v concatenated as nn.MultiheadAttention's
+ * packed in-projection produces them (clip/model.py:352).  out: [B*L, heads*64].
+ * lse: [B, heads, L] fp32 log-sum-exp of the scaled scores (saved for backward).
+ */
+int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads,
+                      int causal, int dtype, void* stream);
+
+/*
+ * Backward of the above: given dout, recomputes P from qkv and lse and writes
+ * dqkv [B*L, 3*heads*64].  delta: [B, heads, L] fp32 scratch.
+ */
+int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                      float* delta, void* dqkv, int B, int L, int heads, int causal,
+                      int dtype, void* stream);
+
+/*
+ * Rank-r down projection with the group-mixed singular values applied
+ * (trainers/GLP_OT_SVLoRA.py:453-477):
+ *   t[m][j]  = sum_k x[m][k] * P[k][j]        (P = lora_A [K,r], layout_rk = 0)
+ *            = sum_k x[m][k] * P[j][k]        (P = lora_B [r,K], layout_rk = 1: u = g B^T)
+ *   ts[m][j] = scaling * t[m][j] * s_b[j],  s_b = pi_b . S,  b = m / rows_per_sample
+ * attr: int32 [nsamples] group index, or NULL for the uniform 1/G mix (:462).
+ * If t_fwd != NULL also accumulates the dS partials
+ *   ds_part[blk][g][j] = sum_{m in blk} pi_{b(m)}[g] * scaling * t_fwd[m][j] * t[m][j]
+ * (ds_part has ffm_lora_down_blocks(M) * G * r floats).
+ */
+int ffm_lora_down(const void* x, int ldx, const float* P, int layout_rk, const float* S,
+                  const int32_t* attr, int M, int K, int r, int G, int rows_per_sample,
+                  float scaling, float lambda_group, float* t, float* ts,
+                  const float* t_fwd, float* ds_part, int dtype, void* stream);
+int ffm_lora_down_blocks(int M);
+
+/*
+ * Rank-r gradient reduction over the token rows (the dA / dB sums of
+ * FairLoRALinear's backward) without forming dW:
+ *   part[s][k][j] = sum_{m in split s} x[m][k] * v[m][j]
+ * v = ts-style rows (already scaled by scaling * s_b).  part has
+ * ffm_lora_grad_splits(M) * K * r floats.
+ */
+int ffm_lora_grad_partial(const void* x, int ldx, const float* v, int M, int K, int r,
+                          float* part, int dtype, void* stream);
+int ffm_lora_grad_splits(int M);
+
+/*
+ * out[i] (+)= sum_s part[s][i] for i < n, optionally transposing a [K, r]
+ * partial into an [r, K] destination (lora_B.grad).  accumulate != 0 adds to out.
+ */
+int ffm_reduce_partials(const float* part, int nsplit, int n, float* out, int transpose_K,
+                        int transpose_r, int accumulate, void* stream);
+
+/*
+ * Logits head with OT='None' (trainers/GLP_OT_SVLoRA.py:713-757):
+ *   fbar[b] = mean_{l>=1} f[b,l] / max(|f[b,l]|, 1e-12)
+ *   logits_img[b][c] = exp(logit_scale) * <fbar[b], tbar[c]>
+ * f: [B*L, D] dtype; tbar: [n_cls, D] fp32 = mean_n normalize(text[n,c]).
+ * rnorm: [B*L] fp32 (saved), fbar: [B, D] fp32 (saved).
+ */
+int ffm_head_fwd(const void* f, const float* tbar, const float* logit_scale, float* fbar,
+                 float* rnorm, float* logits_img, int B, int L, int D, int n_cls, int dtype,
+                 void* stream);
+
+/*
+ * Slice-mean + softmax cross-entropy (trainers/GLP_OT_SVLoRA.py:753-754,908):
+ *   logits[b][c] = mean_s logits_img[b*S+s][c];  loss = mean_b CE(logits[b], label[b])
+ * Writes logits [nb, n_cls], prob [nb, n_cls], loss [1], dlogits_img [nb*S, n_cls]
+ * (= dloss/dlogits_img), and sets *finite_flag = 0 if the loss is not finite
+ * (Dassl/dassl/engine/trainer.py:260-262 raises on the host from it).
+ */
+int ffm_ce_loss(const float* logits_img, const int64_t* label, float* logits, float* prob,
+                float* loss, float* dlogits_img, int32_t* finite_flag, int nb, int S, int n_cls,
+                void* stream);
+
+/*
+ * Head backward: df [B*L, D] dtype (row l = 0 gets zeros) and
+ * dtbar [n_cls, D] fp32.
+ */
+int ffm_head_bwd(const void* f, const float* tbar, const float* logit_scale, const float* fbar,
+                 const float* rnorm, const float* dlogits_img, void* df, float* dtbar, int B,
+                 int L, int D, int n_cls, int dtype, void* stream);
+
+/*
+ * torch.optim.SGD(momentum, weight_decay, dampening=0) over one flat fp32
+ * buffer (Dassl/dassl/optim/optimizer.py:105-113): d = g + wd*p;
+ * buf = first_step ? d : mu*buf + d; p -= lr*buf.
+ */
+int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                     float weight_decay, int first_step, void* stream);
+
+/*
+ * Round boundary helpers (utils/fed_utils.py:42-100) on the flat trainable
+ * buffer: out[i] = p[i] * w[i] (per-element FedAvg weights: n_k/N, or
+ * n_{k,g}/N_g on lora_S rows) ...
+ */
+int ffm_scale_by(const float* p, const float* w, float* out, int64_t n, void* stream);
+/* ... and, after the all-reduce: shared_half_s column means on each lora_S
+ * block listed in s_offsets (offset of a [G, r] block in the flat buffer),
+ * then EMA with the previous global: p = (1-beta)*avg + beta*prev. */
+int ffm_fedavg_finish(float* avg, const float* prev, float* out, int64_t n, const int64_t* s_offsets,
+                      int n_s, int G, int r, int shared_half_s, float beta, void* stream);
+
+/* dtype conversion helpers (weight preparation at load time). */
+int ffm_cast_f32_to(const float* src, void* dst, int64_t n, int dtype, void* stream);
+int ffm_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, void* stream);
+/* dst[c][r] = src[r][c] as dtype (W^T copies of frozen weights for the dX products). */
+int ffm_transpose_cast(const float* src, void* dst, int rows, int cols, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFM_HIP_H */

@@ -1,0 +1,324 @@
+"""Per-kernel parity of the HIP library (through the C ABI) against plain
+PyTorch fp32/fp64 references of the same op, on the GPU.
+
+Tolerances: fp32 kernels run exact-f32 MFMA / VALU with a different reduction
+order than PyTorch -> rtol 2e-5 of the output scale; bf16 kernels are compared
+with a reference computed from the SAME bf16-rounded inputs in fp32, so only
+accumulation order and the final rounding differ -> 1e-2 of the output scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+IDS = ["f32", "bf16"]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 1.2e-2
+
+
+def rel_err(got, ref):
+    got, ref = got.double(), ref.double()
+    scale = ref.abs().max().clamp_min(1e-30)
+    return float((got - ref).abs().max() / scale)
+
+
+def check(got, ref, t, what):
+    e = rel_err(got, ref)
+    assert math.isfinite(e) and e <= t, f"{what}: max err / scale = {e:.3e} > {t:.1e}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fairfedmed_amd import ops
+    return ops
+
+
+def rnd(*shape, dt=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dt)
+
+
+# ------------------------------------------------------------------ GEMM ---
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 264, 192), (6304, 768, 768), (1000, 512, 3072)])
+def test_gemm_plain(ops, dt, M, N, K):
+    a, b = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, out)
+    check(out, a.double() @ b.double().t(), tol(dt), "gemm")
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_gemm_asymmetric_identity(ops, dt):
+    # A = I, asymmetric B: catches a transposed C write or a wrong k mapping exactly
+    n = 128
+    a = torch.eye(n, device="cuda", dtype=dt)
+    b = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 251 - 125).to(dt)
+    out = torch.zeros(n, n, device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, out)
+    assert torch.equal(out.float(), b.float().t())
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("r,kr", [(4, False), (8, False), (8, True), (16, False), (32, True)])
+def test_gemm_fused_epilogue(ops, dt, r, kr):
+    M, N, K = 333, 384, 256
+    a, b = rnd(M, K, dt=dt, seed=3), rnd(N, K, dt=dt, scale=K ** -0.5, seed=4)
+    bias = rnd(N, seed=5)
+    ts = rnd(M, r, seed=6)
+    lw = rnd(N, r, seed=7) if kr else rnd(r, N, seed=7)
+    res = rnd(M, N, dt=dt, seed=8)
+    lwm = lw.t() if kr else lw
+    ref = a.double() @ b.double().t() + bias.double() + ts.double() @ lwm.double() + res.double()
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, out, bias=bias, ts=ts, lw=lw, lw_is_kr=kr, res=res)
+    check(out, ref, tol(dt), "gemm+bias+lora+res")
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_gemm_gelu_and_dgelu(ops, dt):
+    M, N, K = 260, 256, 128
+    a, b = rnd(M, K, dt=dt, seed=9), rnd(N, K, dt=dt, scale=K ** -0.5 * 2, seed=10)
+    bias = rnd(N, seed=11)
+    pre = torch.empty(M, N, device="cuda", dtype=dt)
+    act = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, pre, bias=bias, gelu_out=act)
+    ref_pre = a.double() @ b.double().t() + bias.double()
+    check(pre, ref_pre, tol(dt), "pre")
+    p = pre.double()
+    check(act, p * torch.sigmoid(1.702 * p), tol(dt), "quick_gelu(pre)")
+    # dgelu: out = (a b^T) * gelu'(aux)
+    aux = rnd(M, N, dt=dt, seed=12)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, out, dgelu_aux=aux)
+    x = aux.double()
+    s = torch.sigmoid(1.702 * x)
+    check(out, (a.double() @ b.double().t()) * (s * (1 + 1.702 * x * (1 - s))), tol(dt), "dgelu")
+
+
+# ------------------------------------------------------------- LayerNorm ---
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("rows,width", [(6304, 768), (308, 512), (37, 128), (5, 2048)])
+def test_layernorm_fwd_bwd(ops, dt, rows, width):
+    x = rnd(rows, width, dt=dt, seed=13) * 2 + 0.5
+    gamma, beta = 1 + 0.1 * rnd(width, seed=14), 0.1 * rnd(width, seed=15)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, y, gamma, beta, mean, rstd)
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (width,), gamma.double(), beta.double(), 1e-5)
+    check(y, ref.detach(), tol(dt), "ln fwd")
+    check(mean, x.double().mean(1), 1e-5, "mean")
+    dy = rnd(rows, width, dt=dt, seed=16)
+    res = rnd(rows, width, dt=dt, seed=17)
+    ref.backward(dy.double())
+    out = torch.empty_like(x)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, res, out)
+    check(out, xd.grad + res.double(), tol(dt), "ln bwd + res")
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, out)
+    check(out, xd.grad, tol(dt), "ln bwd")
+
+
+# ---------------------------------------------------- patchify / embed ----
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_patchify_and_embed(ops, dt):
+    B, H, ps, width = 3, 64, 16, 128
+    img = torch.rand(B, 3, H, H, device="cuda") * 255
+    mean3, std3 = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    P = (H // ps) ** 2
+    cols = torch.empty(B * P, 3 * ps * ps, device="cuda", dtype=dt)
+    ops.patchify(img, cols, ps, mean3, std3)
+    x = (img / 255.0 - torch.tensor(mean3, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std3, device="cuda").view(1, 3, 1, 1)
+    ref = torch.nn.functional.unfold(x, kernel_size=ps, stride=ps).transpose(1, 2).reshape(B * P, -1)
+    check(cols, ref, 1e-6 if dt == torch.float32 else 8e-3, "patchify")
+    # conv1 as a GEMM over the gathered patches == F.conv2d
+    w = rnd(width, 3, ps, ps, scale=0.02, seed=18)
+    out = torch.empty(B * P, width, device="cuda", dtype=dt)
+    ops.gemm_nt(cols, w.reshape(width, -1).to(dt), out)
+    conv = torch.nn.functional.conv2d(x.double(), w.to(dt).double(), stride=ps).reshape(B, width, P).permute(0, 2, 1)
+    check(out, conv.reshape(B * P, width), tol(dt) * 2, "patch-embed")
+    # token assembly + ln_pre
+    cls, pos = rnd(width, dt=dt, scale=0.1, seed=19), rnd(P + 1, width, dt=dt, scale=0.1, seed=20)
+    gamma, beta = 1 + 0.1 * rnd(width, seed=21), 0.1 * rnd(width, seed=22)
+    xt = torch.empty(B * (P + 1), width, device="cuda", dtype=dt)
+    ops.embed_lnpre(out, cls, pos, gamma, beta, xt, B, P + 1)
+    tok = torch.cat([cls.to(dt).expand(B, 1, width), out.reshape(B, P, width)], 1) + pos
+    ref = torch.nn.functional.layer_norm(tok.double(), (width,), gamma.double(), beta.double(), 1e-5)
+    check(xt, ref.reshape(-1, width), tol(dt), "embed+ln_pre")
+
+
+# ------------------------------------------------------------- attention ---
+def ref_attention(qkv, B, L, heads, causal):
+    E = heads * 64
+    q, k, v = qkv.double().reshape(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), device=qkv.device, dtype=torch.float64).triu_(1)
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * L, E)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("B,L,heads,causal", [(2, 17, 2, False), (3, 197, 12, False), (4, 77, 8, True), (2, 64, 1, False),
+                                               (1, 256, 2, True)])
+def test_attention_fwd_bwd(ops, dt, B, L, heads, causal):
+    E = heads * 64
+    qkv = rnd(B * L, 3 * E, dt=dt, seed=23)
+    out = torch.full((B * L, E), float("nan"), device="cuda", dtype=dt)
+    lse = torch.empty(B, heads, L, device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, L, heads, causal)
+    qd = qkv.double().requires_grad_(True)
+    ref, ref_lse = ref_attention(qd, B, L, heads, causal)
+    check(out, ref.detach(), tol(dt), "attn out")
+    check(lse, ref_lse.detach(), 1e-5 if dt == torch.float32 else 2e-3, "lse")
+    dout = rnd(B * L, E, dt=dt, seed=24)
+    ref.backward(dout.double())
+    dqkv = torch.full((B * L, 3 * E), float("nan"), device="cuda", dtype=dt)
+    delta = torch.empty(B, heads, L, device="cuda")
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, causal)
+    t = tol(dt) * (1 if dt == torch.float32 else 2)
+    check(dqkv[:, :E], qd.grad[:, :E], t, "dq")
+    check(dqkv[:, E:2 * E], qd.grad[:, E:2 * E], t, "dk")
+    check(dqkv[:, 2 * E:], qd.grad[:, 2 * E:], t, "dv")
+
+
+# ------------------------------------------------------------------ LoRA ---
+def mix(attr, G, lam=0.7):
+    if attr is None:
+        return torch.full((1, G), 1.0 / G, device="cuda", dtype=torch.float64)
+    oh = torch.nn.functional.one_hot(attr.long(), G).double()
+    return oh * lam + (1 - oh) * (1 - lam) / (G - 1)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,K,r,G,rps,rk,use_attr", [(1000, 768, 8, 3, 197, False, True), (333, 3072, 16, 3, 50, True, True),
+                                                      (70, 128, 4, 2, 17, False, False), (300, 256, 32, 3, 100, True, True),
+                                                      (300, 256, 12, 3, 100, False, True)])
+def test_lora_down(ops, dt, M, K, r, G, rps, rk, use_attr):
+    x = rnd(M, K, dt=dt, seed=25)
+    P = rnd(r, K, scale=0.1, seed=26) if rk else rnd(K, r, scale=0.1, seed=26)
+    S = rnd(G, r, seed=27)
+    nsamp = (M + rps - 1) // rps
+    attr = torch.randint(0, G, (nsamp,), device="cuda", dtype=torch.int32) if use_attr else None
+    t = torch.empty(M, r, device="cuda")
+    ts = torch.empty(M, r, device="cuda")
+    t_fwd = rnd(M, r, seed=28)
+    nb = ops.lora_down_blocks(M)
+    ds_part = torch.full((nb, G, r), float("nan"), device="cuda")
+    ops.lora_down(x, P, rk, S, attr, r, G, rps, 0.25, 0.7, t, ts, t_fwd, ds_part)
+    Pm = P.double().t() if rk else P.double()
+    ref_t = x.double() @ Pm
+    pi = mix(attr, G)
+    sample = torch.arange(M, device="cuda") // rps
+    pi_rows = pi[sample] if attr is not None else pi.expand(M, G)
+    sb = pi_rows @ S.double()
+    check(t, ref_t, 2e-5, "t")                      # fp32 accumulate of exact products in both dtypes
+    check(ts, 0.25 * ref_t * sb, 2e-5, "ts")
+    ref_ds = pi_rows.t() @ (0.25 * t_fwd.double() * ref_t)
+    check(ds_part.double().sum(0), ref_ds, 5e-5, "dS")
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,K,r", [(1000, 768, 8), (197, 3072, 16), (64, 128, 4), (130, 260, 32)])
+def test_lora_grad(ops, dt, M, K, r):
+    x = rnd(M, K, dt=dt, seed=29)
+    v = rnd(M, r, seed=30)
+    ns = ops.lora_grad_splits(M)
+    part = torch.full((ns, K, r), float("nan"), device="cuda")
+    ops.lora_grad_partial(x, v, r, part)
+    ref = x.double().t() @ v.double()
+    out = torch.empty(K, r, device="cuda")
+    ops.reduce_partials(part, ns, K * r, out)
+    check(out, ref, 3e-5, "dA-style [K,r]")
+    out_t = torch.empty(r, K, device="cuda")
+    ops.reduce_partials(part, ns, K * r, out_t, transpose_K=K, transpose_r=r)
+    check(out_t, ref.t(), 3e-5, "dB-style [r,K]")
+    ops.reduce_partials(part, ns, K * r, out, accumulate=True)
+    check(out, 2 * ref, 3e-5, "accumulate")
+
+
+# ------------------------------------------------------------------ head ---
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("B,L,D,S", [(8, 197, 512, 1), (6, 17, 128, 2)])
+def test_head_and_loss(ops, dt, B, L, D, S):
+    n_cls = 2
+    f = rnd(B * L, D, dt=dt, seed=31)
+    tbar = rnd(n_cls, D, scale=D ** -0.5, seed=32)
+    ls = torch.tensor([math.log(1 / 0.07)], device="cuda")
+    fbar = torch.empty(B, D, device="cuda")
+    rnorm = torch.empty(B * L, device="cuda")
+    logits_img = torch.empty(B, n_cls, device="cuda")
+    ops.head_fwd(f, tbar, ls, fbar, rnorm, logits_img, B, L, n_cls)
+    fd = f.double().requires_grad_(True)
+    td = tbar.double().requires_grad_(True)
+    feats = torch.nn.functional.normalize(fd.reshape(B, L, D)[:, 1:], dim=2)
+    ref_img = ls.double().exp() * torch.einsum("bmd,cd->bc", feats, td) / (L - 1)
+    check(logits_img, ref_img.detach(), 2e-5 if dt == torch.float32 else 1e-4, "logits_img")
+    nb = B // S
+    label = torch.randint(0, n_cls, (nb,), device="cuda")
+    logits = torch.empty(nb, n_cls, device="cuda")
+    prob = torch.empty(nb, n_cls, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    dl = torch.empty(B, n_cls, device="cuda")
+    fin = torch.zeros(1, device="cuda", dtype=torch.int32)
+    ops.ce_loss(logits_img, label, logits, prob, loss, dl, fin, nb, S, n_cls)
+    ref_logits = ref_img.reshape(nb, S, n_cls).mean(1)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, label)
+    check(logits, ref_logits.detach(), 2e-5 if dt == torch.float32 else 1e-4, "logits")
+    assert abs(float(loss) - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)) + (0 if dt == torch.float32 else 1e-4)
+    assert int(fin) == 1
+    check(prob, torch.softmax(ref_logits, -1).detach(), 1e-4, "prob")
+    ref_loss.backward()
+    df = torch.empty_like(f)
+    dtbar = torch.empty_like(tbar)
+    ops.head_bwd(f, tbar, ls, fbar, rnorm, dl, df, dtbar, B, L, n_cls)
+    check(df, fd.grad, 2e-4 if dt == torch.float32 else 1.5e-2, "df")
+    check(dtbar, td.grad, 2e-4 if dt == torch.float32 else 1e-3, "dtbar")
+
+
+# ----------------------------------------------------------- optimizer ----
+def test_sgd_matches_torch(ops):
+    n = 741952
+    p = rnd(n, seed=33)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref_p], lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    buf = torch.zeros(n, device="cuda")
+    for step in range(3):
+        g = rnd(n, seed=34 + step)
+        ref_p.grad = g.clone()
+        opt.step()
+        ops.sgd_momentum(p, g, buf, 1e-3, 0.9, 5e-4, step == 0)
+        check(p, ref_p.detach(), 1e-6, f"sgd step {step}")
+
+
+def test_fedavg_helpers(ops):
+    G, r, n = 3, 8, 1000
+    p, w = rnd(n, seed=40), torch.rand(n, device="cuda")
+    out = torch.empty(n, device="cuda")
+    ops.scale_by(p, w, out)
+    assert torch.allclose(out, p * w)
+    avg, prev = rnd(n, seed=41), rnd(n, seed=42)
+    offs = torch.tensor([100, 500], device="cuda", dtype=torch.int64)
+    ref = avg.clone()
+    for o in (100, 500):
+        blk = ref[o:o + G * r].view(G, r)
+        blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
+    ref = (1 - 0.3) * ref + 0.3 * prev
+    res = torch.empty(n, device="cuda")
+    ops.fedavg_finish(avg, prev, res, offs, G, r, True, 0.3)
+    check(res, ref, 1e-6, "fedavg_finish")
+
+
+def test_casts(ops):
+    x = rnd(37, 53, seed=43)
+    assert torch.equal(ops.cast_from_f32(x, torch.bfloat16), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast_to_f32(x.to(torch.bfloat16)), x.to(torch.bfloat16).float())
+    assert torch.equal(ops.transpose_cast(x, torch.bfloat16), x.t().contiguous().to(torch.bfloat16))
+    assert torch.equal(ops.transpose_cast(x, torch.float32), x.t().contiguous())
