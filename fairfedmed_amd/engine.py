@@ -1,0 +1,425 @@
+"""FairLoRA local-training engine: one training step of the reference's
+``GLP_OT_SVLoRA.forward_backward`` (trainers/GLP_OT_SVLoRA.py:883-975) as a
+fixed sequence of HIP kernel launches over preallocated HBM buffers.
+
+Data layout in HBM (all row-major):
+  * token matrices [rows, width], row = image*L + token (image-major);
+  * frozen weights twice, in the compute dtype: W [out, in] for the forward
+    product and W^T [in, out] for the dX product (both are the "B[N,K]" operand
+    of ffm_gemm_nt, K contiguous) — weights are frozen so W^T is built once;
+  * every trainable tensor (prompt ctx, lora_A/S/B of the 24 wrapped linears)
+    is a view into ONE flat fp32 buffer `flat`, with matching `grad` and
+    `momentum` buffers: the SGD step is one kernel and the FedAvg exchange is
+    one all-reduce of `flat`;
+  * activations saved for the backward pass live in per-layer buffers sized
+    once for `max_images` (no allocation inside a step).
+
+Backward computes dX only (every dense weight is frozen): LoRA gradients come
+from rank-r reductions (ffm_lora_grad_partial) and the LoRA dx term is an
+epilogue of the dX GEMM, so the dense dW = A diag(s) B is never formed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .config import ModelCfg
+from .synth import manifest, trainable_keys
+
+Tensor = torch.Tensor
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class FlatParams:
+    """All trainable tensors as views of one flat fp32 buffer (+ grad, momentum)."""
+
+    def __init__(self, cfg: ModelCfg, device):
+        shapes = manifest(cfg)
+        self.keys = trainable_keys(cfg)
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for k in self.keys:
+            shp = tuple(shapes[k])
+            n = 1
+            for s in shp:
+                n *= s
+            self.offsets[k] = (off, shp)
+            off = _round_up(off + n, 4)
+        self.numel = off
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.momentum = torch.zeros(off, device=device, dtype=torch.float32)
+        self.steps = 0
+
+    def view(self, key: str, which: str = "flat") -> Tensor:
+        off, shp = self.offsets[key]
+        n = 1
+        for s in shp:
+            n *= s
+        return getattr(self, which)[off:off + n].view(shp)
+
+    def load(self, sd: Dict[str, Tensor]) -> None:
+        for k in self.keys:
+            self.view(k).copy_(sd[k].to(self.flat.device, torch.float32))
+
+    def lora_s_offsets(self) -> Tensor:
+        return torch.tensor([self.offsets[k][0] for k in self.keys if k.endswith("lora_S.weight")],
+                            dtype=torch.int64, device=self.flat.device)
+
+
+@dataclass
+class _Block:
+    """Frozen weights of one residual attention block in the compute dtype."""
+    w_in: Tensor
+    w_in_t: Tensor
+    b_in: Tensor
+    w_out: Tensor
+    w_out_t: Tensor
+    b_out: Tensor
+    ln1_w: Tensor
+    ln1_b: Tensor
+    ln2_w: Tensor
+    ln2_b: Tensor
+    w_fc: Tensor
+    w_fc_t: Tensor
+    b_fc: Tensor
+    w_proj: Tensor
+    w_proj_t: Tensor
+    b_proj: Tensor
+    lora: Optional[Dict[str, str]] = None      # role -> flat key, vision blocks only
+
+
+class _Stack:
+    """A transformer tower (vision with FairLoRA, or text) with its saved activations."""
+
+    def __init__(self, width: int, heads: int, layers: int, tokens: int, max_images: int, causal: bool,
+                 rank: int, dtype, device):
+        self.width, self.heads, self.layers, self.L = width, heads, layers, tokens
+        self.causal, self.rank, self.dtype = causal, rank, dtype
+        self.blocks: List[_Block] = []
+        T = max_images * tokens
+        self.max_rows = T
+        e = lambda *s: torch.zeros(*s, device=device, dtype=dtype)
+        f = lambda *s: torch.zeros(*s, device=device, dtype=torch.float32)
+        w = width
+        self.x = [e(T, w) for _ in range(layers + 1)]        # block inputs; x[layers] = tower output
+        self.xm = [e(T, w) for _ in range(layers)]           # after the attention residual
+        self.qkv = [e(T, 3 * w) for _ in range(layers)]
+        self.o = [e(T, w) for _ in range(layers)]
+        self.lse = [f(max_images * heads * tokens) for _ in range(layers)]
+        self.st1 = [(f(T), f(T)) for _ in range(layers)]
+        self.st2 = [(f(T), f(T)) for _ in range(layers)]
+        self.h2 = [e(T, w) for _ in range(layers)]
+        self.pre = [e(T, 4 * w) for _ in range(layers)]
+        self.act = [e(T, 4 * w) for _ in range(layers)]
+        if rank:
+            self.t1 = [f(T, rank) for _ in range(layers)]
+            self.ts1 = [f(T, rank) for _ in range(layers)]
+            self.t2 = [f(T, rank) for _ in range(layers)]
+            self.ts2 = [f(T, rank) for _ in range(layers)]
+        # transient buffers
+        self.h = e(T, w)
+        self.g = e(T, w)          # running gradient w.r.t. the residual stream
+        self.g1 = e(T, w)
+        self.dh = e(T, w)
+        self.do = e(T, w)
+        self.dqkv = e(T, 3 * w)
+        self.dpre = e(T, 4 * w)
+        self.delta = f(max_images * heads * tokens)
+        if rank:
+            self.u = f(T, rank)
+            self.us = f(T, rank)
+            self.part = f(ops.lora_grad_splits(T) * 4 * w * rank)
+            self.ds_part = f(ops.lora_down_blocks(T) * 8 * rank)
+
+
+class FairLoRAEngine:
+    """HIP execution engine for CustomCLIP(+FairLoRA) training and inference."""
+
+    def __init__(self, cfg: ModelCfg, state_dict: Dict[str, Tensor], dtype=torch.bfloat16, max_images: int = 32,
+                 device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FairLoRAEngine needs an MI355X GPU; there is no CPU path")
+        from . import _lib
+        _lib.load()                                   # fail loudly if the HIP library is missing
+        if cfg.vision.head_dim != 64 or cfg.text.width // cfg.text.heads != 64:
+            raise ValueError("attention kernels are built for head_dim 64 (all CLIP towers)")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.max_images = max_images
+        v, t = cfg.vision, cfg.text
+        self.params = FlatParams(cfg, self.device)
+        self.params.load(state_dict)
+        self.vis = _Stack(v.width, v.heads, v.layers, v.tokens, max_images, False, cfg.lora.rank, dtype, self.device)
+        self.n_text = cfg.n_prompts * cfg.n_cls
+        self.txt = _Stack(t.width, t.heads, t.layers, t.context_length, self.n_text, True, 0, dtype, self.device)
+        self.load_frozen(state_dict)
+        dev, f32 = self.device, torch.float32
+        P = v.grid * v.grid
+        self.cols = torch.zeros(max_images * P, 3 * v.patch * v.patch, device=dev, dtype=dtype)
+        self.patch_out = torch.zeros(max_images * P, v.width, device=dev, dtype=dtype)
+        self.hpost = torch.zeros(max_images * v.tokens, v.width, device=dev, dtype=dtype)
+        self.post_stats = (torch.zeros(max_images * v.tokens, device=dev), torch.zeros(max_images * v.tokens, device=dev))
+        self.feat = torch.zeros(max_images * v.tokens, v.out_dim, device=dev, dtype=dtype)
+        self.dfeat = torch.zeros_like(self.feat)
+        self.fbar = torch.zeros(max_images, v.out_dim, device=dev, dtype=f32)
+        self.rnorm = torch.zeros(max_images * v.tokens, device=dev, dtype=f32)
+        self.logits_img = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
+        self.dlogits_img = torch.zeros_like(self.logits_img)
+        self.logits = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
+        self.prob = torch.zeros_like(self.logits)
+        self.loss = torch.zeros(1, device=dev, dtype=f32)
+        self.finite = torch.ones(1, device=dev, dtype=torch.int32)
+        self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
+        self.eot_rows = torch.tensor([i * t.context_length + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
+                                     device=dev, dtype=torch.int64)
+
+    # ------------------------------------------------------------ weights --
+    def _w(self, x: Tensor) -> Tensor:
+        return ops.cast_from_f32(x.to(self.device, torch.float32).contiguous(), self.dtype)
+
+    def _wt(self, x: Tensor) -> Tensor:
+        return ops.transpose_cast(x.to(self.device, torch.float32).contiguous(), self.dtype)
+
+    def _f(self, x: Tensor) -> Tensor:
+        return x.to(self.device, torch.float32).contiguous().clone()
+
+    def _load_stack(self, stack: _Stack, sd, prefix: str, lora: bool) -> None:
+        stack.blocks = []
+        for i in range(stack.layers):
+            p = f"{prefix}transformer.resblocks.{i}."
+            fc = "mlp.c_fc.original_linear." if lora else "mlp.c_fc."
+            pj = "mlp.c_proj.original_linear." if lora else "mlp.c_proj."
+            blk = _Block(
+                w_in=self._w(sd[p + "attn.in_proj_weight"]), w_in_t=self._wt(sd[p + "attn.in_proj_weight"]),
+                b_in=self._f(sd[p + "attn.in_proj_bias"]),
+                w_out=self._w(sd[p + "attn.out_proj.weight"]), w_out_t=self._wt(sd[p + "attn.out_proj.weight"]),
+                b_out=self._f(sd[p + "attn.out_proj.bias"]),
+                ln1_w=self._f(sd[p + "ln_1.weight"]), ln1_b=self._f(sd[p + "ln_1.bias"]),
+                ln2_w=self._f(sd[p + "ln_2.weight"]), ln2_b=self._f(sd[p + "ln_2.bias"]),
+                w_fc=self._w(sd[p + fc + "weight"]), w_fc_t=self._wt(sd[p + fc + "weight"]),
+                b_fc=self._f(sd[p + fc + "bias"]),
+                w_proj=self._w(sd[p + pj + "weight"]), w_proj_t=self._wt(sd[p + pj + "weight"]),
+                b_proj=self._f(sd[p + pj + "bias"]),
+            )
+            if lora:
+                blk.lora = {f"{n}_{m}": f"{p}mlp.c_{n}.lora_{m}.weight" for n in ("fc", "proj") for m in "ASB"}
+            stack.blocks.append(blk)
+
+    def load_frozen(self, sd: Dict[str, Tensor]) -> None:
+        """(Re)build the compute-dtype copies of every frozen tensor."""
+        cfg, v = self.cfg, self.cfg.vision
+        ie, te = "image_encoder.", "text_encoder."
+        self._load_stack(self.vis, sd, ie, True)
+        self._load_stack(self.txt, sd, te, False)
+        self.conv_w = self._w(sd[ie + "conv1.weight"].reshape(v.width, -1))
+        self.cls = self._w(sd[ie + "class_embedding"])
+        self.pos = self._w(sd[ie + "positional_embedding"])
+        self.lnpre = (self._f(sd[ie + "ln_pre.weight"]), self._f(sd[ie + "ln_pre.bias"]))
+        self.lnpost = (self._f(sd[ie + "ln_post.weight"]), self._f(sd[ie + "ln_post.bias"]))
+        self.proj = self._w(sd[ie + "proj"])                      # [width, out]: B operand of dh = df proj^T
+        self.proj_t = self._wt(sd[ie + "proj"])                   # [out, width]: B operand of f = h proj
+        self.logit_scale = self._f(sd["logit_scale"].reshape(1))
+        # text side constants stay fp32 (tiny): prompt pieces, ln_final, projection
+        self.tok_prefix = self._f(sd["prompt_learner.token_prefix"])
+        self.tok_suffix = self._f(sd["prompt_learner.token_suffix"])
+        self.txt_pos = self._f(sd[te + "positional_embedding"])
+        self.lnfinal = (self._f(sd[te + "ln_final.weight"]), self._f(sd[te + "ln_final.bias"]))
+        self.text_proj = self._f(sd[te + "text_projection"])
+
+    # -------------------------------------------------------------- tower --
+    def _lora_view(self, blk: _Block, role: str) -> Tensor:
+        return self.params.view(blk.lora[role])
+
+    def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
+                       save: bool = True) -> Tensor:
+        """x[0][:rows] holds the tower input; returns the tower output view."""
+        lo = self.cfg.lora
+        r, G = st.rank, lo.num_groups
+        for i, blk in enumerate(st.blocks):
+            x, xm = st.x[i][:rows], st.xm[i][:rows]
+            qkv, o, h2 = st.qkv[i][:rows], st.o[i][:rows], st.h2[i][:rows]
+            pre, act = st.pre[i][:rows], st.act[i][:rows]
+            h = st.h[:rows]
+            ops.layernorm_fwd(x, h, blk.ln1_w, blk.ln1_b, st.st1[i][0], st.st1[i][1])
+            ops.gemm_nt(h, blk.w_in, qkv, bias=blk.b_in)
+            ops.attention_fwd(qkv, o, st.lse[i], images, st.L, st.heads, st.causal)
+            ops.gemm_nt(o, blk.w_out, xm, bias=blk.b_out, res=x)
+            ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
+            if r:
+                ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._lora_view(blk, "fc_S"), attr, r, G,
+                              rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
+                ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, ts=st.ts1[i], lw=self._lora_view(blk, "fc_B"),
+                            gelu_out=act)
+                ops.lora_down(act, self._lora_view(blk, "proj_A"), False, self._lora_view(blk, "proj_S"), attr, r, G,
+                              rows_per_sample, lo.scaling, lo.lambda_group, st.t2[i], st.ts2[i])
+                ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, ts=st.ts2[i],
+                            lw=self._lora_view(blk, "proj_B"), res=xm)
+            else:
+                ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, gelu_out=act)
+                ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, res=xm)
+        return st.x[st.layers][:rows]
+
+    def _stack_backward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
+                        need_input_grad: bool) -> Tensor:
+        """st.g[:rows] holds dL/d(tower output); on return it holds dL/d(tower input)
+        (if need_input_grad).  LoRA gradients are written into params.grad."""
+        lo = self.cfg.lora
+        r, G, w = st.rank, lo.num_groups, st.width
+        g, g1 = st.g[:rows], st.g1[:rows]
+        for i in range(st.layers - 1, -1, -1):
+            blk = st.blocks[i]
+            x, xm = st.x[i][:rows], st.xm[i][:rows]
+            pre, act, h2 = st.pre[i][:rows], st.act[i][:rows], st.h2[i][:rows]
+            dpre = st.dpre[:rows]
+            last = (i == 0) and not need_input_grad
+            if r:
+                u, us = st.u[:rows], st.us[:rows]
+                nsp, nbl = ops.lora_grad_splits(rows), ops.lora_down_blocks(rows)
+                gv = lambda role: self.params.view(blk.lora[role], "grad")
+                # ---- c_proj:  g = dL/dy [rows, w]
+                ops.lora_down(g, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t2[i][:rows], st.ds_part)
+                ops.reduce_partials(st.ds_part, nbl, G * r, gv("proj_S"))
+                ops.gemm_nt(g, blk.w_proj_t, dpre, ts=us, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
+                            dgelu_aux=pre)
+                ops.lora_grad_partial(g, st.ts2[i][:rows], r, st.part)
+                ops.reduce_partials(st.part, nsp, w * r, gv("proj_B"), transpose_K=w, transpose_r=r)
+                ops.lora_grad_partial(act, us, r, st.part)
+                ops.reduce_partials(st.part, nsp, 4 * w * r, gv("proj_A"))
+                # ---- c_fc:  dpre = dL/d(pre) [rows, 4w]
+                ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t1[i][:rows], st.ds_part)
+                ops.reduce_partials(st.ds_part, nbl, G * r, gv("fc_S"))
+                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, st.part)
+                ops.reduce_partials(st.part, nsp, 4 * w * r, gv("fc_B"), transpose_K=4 * w, transpose_r=r)
+                ops.lora_grad_partial(h2, us, r, st.part)
+                ops.reduce_partials(st.part, nsp, w * r, gv("fc_A"))
+                if last:
+                    break
+                ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True)
+            else:
+                ops.gemm_nt(g, blk.w_proj_t, dpre, dgelu_aux=pre)
+                ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows])
+            ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], g, g1)
+            ops.gemm_nt(g1, blk.w_out_t, st.do[:rows])
+            ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
+                              images, st.L, st.heads, st.causal)
+            ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows])
+            ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, g)
+        return g
+
+    # --------------------------------------------------------------- text --
+    def _text_features(self, with_grad: bool):
+        """tbar [n_cls, D] = mean_n normalize(text_encoder(prompts))  (trainers/GLP_OT_SVLoRA.py:55-66,
+        131-152, 709-715).  The 12 transformer blocks run on the HIP kernels; only the tiny ends
+        (prompt concat, EOT gather, ln_final on n_text rows, projection, normalise) are PyTorch glue."""
+        cfg, t = self.cfg, self.cfg.text
+        ctx = self.params.view("prompt_learner.ctx")
+        n_ctx = cfg.n_ctx
+        ctx_rows = ctx.unsqueeze(1).expand(cfg.n_prompts, cfg.n_cls, n_ctx, t.width).reshape(self.n_text, n_ctx, t.width)
+        prompts = torch.cat([self.tok_prefix, ctx_rows, self.tok_suffix], dim=1) + self.txt_pos
+        rows = self.n_text * t.context_length
+        self.txt.x[0][:rows].copy_(prompts.reshape(rows, t.width))
+        out = self._stack_forward(self.txt, rows, self.n_text, None, t.context_length)
+        xe = out[self.eot_rows].float()
+        if with_grad:
+            xe.requires_grad_(True)
+        y = torch.nn.functional.layer_norm(xe, (t.width,), self.lnfinal[0], self.lnfinal[1], 1e-5)
+        tf = (y @ self.text_proj).view(cfg.n_prompts, cfg.n_cls, -1)
+        tbar = torch.nn.functional.normalize(tf, dim=2).mean(0)
+        return tbar, xe
+
+    def _text_backward(self, tbar: Tensor, xe: Tensor, dtbar: Tensor) -> None:
+        cfg, t = self.cfg, self.cfg.text
+        rows = self.n_text * t.context_length
+        tbar.backward(dtbar)
+        g = self.txt.g[:rows]
+        g.zero_()
+        g[self.eot_rows] = xe.grad.to(self.dtype)
+        g0 = self._stack_backward(self.txt, rows, self.n_text, None, t.context_length, True)
+        d = g0.float().view(cfg.n_prompts, cfg.n_cls, t.context_length, t.width)[:, :, 1:1 + cfg.n_ctx, :].sum(1)
+        self.params.view("prompt_learner.ctx", "grad").copy_(d)
+
+    # ------------------------------------------------------------- vision --
+    def _check_batch(self, image: Tensor) -> Tuple[int, int]:
+        cfg, v = self.cfg, self.cfg.vision
+        if not image.is_cuda or image.dtype != torch.float32:
+            raise TypeError("image must be a float32 CUDA tensor of raw 0..255 values")
+        b, c, h, w = image.shape
+        if cfg.dim_per_3d_slice:
+            raise NotImplementedError("3D OCT slice projection is not built yet (SURVEY.md §8 a4)")
+        if c != 3 or h != v.image_size or w != v.image_size:
+            raise ValueError(f"expected [B,3,{v.image_size},{v.image_size}], got {tuple(image.shape)}")
+        if b > self.max_images:
+            raise ValueError(f"batch {b} exceeds the engine's max_images={self.max_images}")
+        return b, 1
+
+    def _vision_forward(self, image: Tensor, attr: Optional[Tensor], tbar: Tensor) -> Tensor:
+        cfg, v = self.cfg, self.cfg.vision
+        b, S = self._check_batch(image)
+        images = b * S
+        P, L = v.grid * v.grid, v.tokens
+        rows = images * L
+        a32 = None
+        if attr is not None:
+            a32 = self.attr_i32[:b]
+            a32.copy_(attr.to(torch.int32))
+        ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
+        ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
+        ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
+                        self.vis.x[0][:rows], images, L)
+        out = self._stack_forward(self.vis, rows, images, a32, L * S)
+        ops.layernorm_fwd(out, self.hpost[:rows], self.lnpost[0], self.lnpost[1], self.post_stats[0],
+                          self.post_stats[1])
+        ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows])
+        ops.head_fwd(self.feat[:rows], tbar, self.logit_scale, self.fbar, self.rnorm, self.logits_img, images, L,
+                     cfg.n_cls)
+        self._last = (b, S, images, rows, a32)
+        return self.logits_img[:images]
+
+    # ---------------------------------------------------------------- API --
+    @torch.no_grad()
+    def forward(self, image: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        """CustomCLIP.forward(image, attr) -> logits [B, n_cls] (inference)."""
+        tbar, _ = self._text_features(False)
+        li = self._vision_forward(image, attr, tbar.contiguous())
+        b, S = self._last[0], self._last[1]
+        return li.view(b, S, -1).mean(1)
+
+    def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:
+        """Forward, CE loss, backward; gradients of every trainable tensor land in params.grad.
+        Returns device tensors (no host sync): loss [1], logits [B,n_cls], prob [B,n_cls], finite [1]."""
+        cfg, v = self.cfg, self.cfg.vision
+        with torch.enable_grad():
+            tbar, xe = self._text_features(True)
+        tb = tbar.detach().contiguous()
+        with torch.no_grad():
+            self._vision_forward(image, attr, tb)
+            b, S, images, rows, a32 = self._last
+            L = v.tokens
+            ops.ce_loss(self.logits_img, label, self.logits, self.prob, self.loss, self.dlogits_img, self.finite, b,
+                        S, cfg.n_cls)
+            ops.head_bwd(self.feat[:rows], tb, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
+                         self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
+            ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
+            ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
+                              self.post_stats[1], None, self.vis.g[:rows])
+            self._stack_backward(self.vis, rows, images, a32, L * S, False)
+        self._text_backward(tbar, xe, self.dtbar)
+        return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
+
+    @torch.no_grad()
+    def sgd_step(self, lr: float, momentum: float, weight_decay: float) -> None:
+        p = self.params
+        ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0)
+        p.steps += 1
+
+    def trainable_state(self) -> Dict[str, Tensor]:
+        return {k: self.params.view(k) for k in self.params.keys}
