@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the FairLoRA local-training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one GLP_OT_SVLoRA.forward_backward on a synthetic batch already
+resident in HBM: CLIP ViT-B/16 image encoder with FairLoRA r=8 (G=3) + text
+tower + logits head + cross-entropy, full backward (dX + LoRA/ctx gradients)
+and the fused SGD-momentum update, bf16 activations/frozen weights with fp32
+accumulation and fp32 trainable tensors, batch 32 of 224x224x3
+(BASELINE.json configs[1]).  With N > 1 every rank is one federated client
+(one process per GPU, weak scaling) and the K steps end with the round-boundary
+FedAvg all-reduce of the LoRA/ctx parameters over RCCL.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      achieved TFLOP/s of the dominant kernel (the MFMA GEMM), timed
+                per launch with HIP events in a second pass over the same K steps
+  cpu_baseline  the oracle (CPU restatement of the reference) timed on the host
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+BATCH = 32
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--rank", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """Wraps ops.gemm_nt: one HIP event pair per launch on the launching stream."""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.rec = ops, ops.gemm_nt, []
+
+    def __enter__(self):
+        def timed(a, b, out, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(a, b, out, **kw)
+            e1.record()
+            M, K = a.shape
+            N = b.shape[0]
+            fl = 2.0 * M * N * K
+            if kw.get("ts") is not None:
+                fl += 2.0 * M * N * kw["ts"].shape[1]
+            self.rec.append((e0, e1, fl))
+            return r
+        self.ops.gemm_nt = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops.gemm_nt = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        fl = sum(f for _, _, f in self.rec)
+        return len(self.rec), ms, fl
+
+
+def usable_cores() -> int:
+    """Cores this process may actually run on: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes the BLAS thread pool)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(mcfg, budget_s=30.0):
+    """Oracle train step (fp32, bs 32) on the host cores: 1 warm-up + up to 3 timed steps."""
+    from fairfedmed_amd import synth
+    from oracle import fairlora_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+    batch = synth.make_batch(mcfg, BATCH, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    opt = O.SgdState()
+    t_start = time.time()
+    O.train_step(sd, opt, batch, mcfg, keys)                     # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        O.train_step(sd, opt, batch, mcfg, keys)
+        times.append(time.time() - t0)
+        if time.time() - t_start > budget_s:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": BATCH / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed steps (after 1 warm-up) of the oracle's fp32 train step, batch {BATCH}, "
+                      f"same ViT-B/16 FairLoRA r=8 workload; median {med:.3f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+
+    from fairfedmed_amd import config as C
+    from fairfedmed_amd import ops, synth
+    from fairfedmed_amd.engine import FairLoRAEngine
+    from fairfedmed_amd.fedavg import FedAvgAggregator
+
+    mcfg = C.vit_b16(rank=args.rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+    eng = FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=BATCH, device=dev)
+    del sd
+    batch = synth.make_batch(mcfg, BATCH, seed=1234 + rank)
+    img, attr, label = batch["img"].to(dev), batch["attrs"].t()[0].contiguous().to(dev), batch["label"].to(dev)
+    opt = C.OptimCfg()
+    agg = None
+    if world > 1:
+        agg = FedAvgAggregator(eng.params.flat, eng.params.offsets, mcfg.lora.num_groups, mcfg.lora.rank)
+    n_client = [1024] * world
+    by_attr = [[400, 300, 324]] * world
+
+    def step():
+        eng.forward_backward(img, attr, label)
+        eng.sgd_step(opt.lr, opt.momentum, opt.weight_decay)
+
+    def round_boundary():
+        if agg is not None:
+            agg.aggregate(rank, list(range(world)), n_client, by_attr, 1, 50)
+
+    for _ in range(args.warmup):
+        step()
+    round_boundary()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    round_boundary()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    finite = int(eng.finite)
+    loss = float(eng.loss)
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        with GemmTimer(ops) as gt:
+            for _ in range(args.steps):
+                step()
+            n, ms, fl = gt.summary()
+        peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % args.dtype, "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "launches_per_step": n // args.steps, "avg_launch_us": ms * 1e3 / n,
+                "gemm_ms_per_step": ms / args.steps,
+                "measured": "HIP events around every ffm_gemm_nt launch on the launching stream, "
+                            "second pass over the same K steps (value comes from the un-instrumented pass)"}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        res = {
+            "metric": "images/sec per client-round, ViT-B/16 FairLoRA r=8, bs=32 224^2",
+            "value": BATCH * args.steps * world / dt,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: 1-client ViT-B/16 FairLoRA rank=%d G=3, bs=32 synthetic 224x224x3, "
+                                   "fwd+bwd+SGD per step%s" % (args.rank, "" if world == 1 else
+                                                               "; one client per GPU, FedAvg all-reduce at the round end"),
+                       "global_batch": BATCH * world, "clients": world,
+                       "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite},
+        }
+        if roof:
+            res["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(mcfg)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""Round boundary: weighted FedAvg + EMA of the trainable tensors as ONE
+all-reduce of the flat parameter buffer.
+
+Restates ``average_weights_EMA`` (utils/fed_utils.py:42-100) for one client per
+rank: every rank pre-multiplies its flat buffer by its own weights
+(n_k / sum n for ordinary entries, n_{k,g} / sum_k n_{k,g} for row g of every
+lora_S block), one all_reduce(SUM) over RCCL/xGMI (gloo on CPU) gives the
+average, then shared_half_s and the EMA with the previous global run locally
+and identically on all ranks.
+
+The reference averages the full state_dict, frozen tensors included
+(utils/fed_utils.py:76-86); frozen tensors are identical on every client, so
+their weighted mean is the tensor itself up to one rounding — they are left
+untouched here.
+
+On a GPU the three elementwise passes are HIP kernels (ffm_scale_by,
+ffm_fedavg_finish); for BASELINE.json configs[0] (CPU/gloo plumbing, no GPU)
+the same three passes run as host tensor arithmetic.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def element_weights(offsets: Dict[str, Tuple[int, Tuple[int, ...]]], numel: int, client: int,
+                    participants: Sequence[int], n_client: Sequence[int],
+                    n_client_by_attr: Optional[Sequence[Sequence[int]]]) -> Tensor:
+    """Per-element FedAvg weight of `client` over the flat buffer (fp32, CPU)."""
+    w = torch.zeros(numel, dtype=torch.float32)
+    if client not in participants:
+        return w                                            # frac < 1: non-selected ranks contribute 0
+    total = float(sum(n_client[u] for u in participants))
+    f = torch.tensor(n_client[client] / total, dtype=torch.float32)
+    w.fill_(float(f))
+    if n_client_by_attr is not None:
+        by = torch.tensor(n_client_by_attr)
+        tot = by[list(participants)].sum(0)
+        fg = (by[client] / tot).to(torch.float32)           # same fp32 division as the reference
+        G = by.shape[1]
+        for key, (off, shp) in offsets.items():
+            if "lora_S" in key and shp[0] == G:
+                r = shp[1]
+                w[off:off + G * r] = fg[:, None].expand(G, r).reshape(-1)
+    return w
+
+
+class FedAvgAggregator:
+    def __init__(self, flat: Tensor, offsets: Dict[str, Tuple[int, Tuple[int, ...]]], num_groups: int, rank_dim: int,
+                 shared_half_s: bool = True, beta: float = 0.999, group=None):
+        self.flat, self.offsets = flat, offsets
+        self.G, self.r = num_groups, rank_dim
+        self.shared_half_s, self.beta, self.group = shared_half_s, beta, group
+        self.global_prev = flat.detach().clone()            # w_g: the global weights before round 0
+        self.buf = torch.empty_like(flat)
+        self.s_offsets = torch.tensor(
+            [off for k, (off, shp) in offsets.items() if "lora_S" in k and shp[0] == num_groups],
+            dtype=torch.int64, device=flat.device)
+
+    @torch.no_grad()
+    def aggregate(self, client: int, participants: Sequence[int], n_client: Sequence[int],
+                  n_client_by_attr: Optional[Sequence[Sequence[int]]], epoch: int, max_epoch: int) -> Tensor:
+        """All ranks call this at the round boundary; afterwards `flat` holds the new global
+        weights on every rank (utils/fed_utils.py:98 semantic: w = (1-b)*avg + b*w_g)."""
+        w = element_weights(self.offsets, self.flat.numel(), client, participants, n_client, n_client_by_attr)
+        w = w.to(self.flat.device)
+        beta_decay = self.beta * (epoch / max(max_epoch, 1))
+        use_half = self.shared_half_s and n_client_by_attr is not None
+        if self.flat.is_cuda:
+            from . import ops
+            ops.scale_by(self.flat, w, self.buf)
+        else:
+            torch.mul(self.flat, w, out=self.buf)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+        if self.flat.is_cuda:
+            from . import ops
+            ops.fedavg_finish(self.buf, self.global_prev, self.flat, self.s_offsets if use_half else None,
+                              self.G, self.r, use_half, float(beta_decay))
+        else:
+            if use_half:
+                G, r = self.G, self.r
+                for off in self.s_offsets.tolist():
+                    blk = self.buf[off:off + G * r].view(G, r)
+                    blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
+            self.flat.copy_((1 - beta_decay) * self.buf + beta_decay * self.global_prev)
+        self.global_prev.copy_(self.flat)
+        return self.flat
