@@ -31,6 +31,11 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("part", _vp), ("out", _vp), ("nsplit", _i32), ("n", _i32), ("transpose_K", _i32),
+                ("transpose_r", _i32)]
+
+
 # name -> argtypes (restype is always int, except the two helpers)
 SIGNATURES = {
     "ffm_abi_version": [],
@@ -43,10 +48,11 @@ SIGNATURES = {
     "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
                       _i32, _vp],
-    "ffm_lora_down_blocks": [_i32],
+    "ffm_lora_down_blocks": [_i32, _i32, _i32, _i32],
     "ffm_lora_grad_partial": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_lora_grad_splits": [_i32],
     "ffm_reduce_partials": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
+    "ffm_reduce_partials_multi": [_vp, _i32, _i32, _vp],
     "ffm_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_ce_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

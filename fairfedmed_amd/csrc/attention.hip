@@ -60,34 +60,52 @@ template <typename T> __device__ __forceinline__ int rm_off(int row, int c) {
     return row * AT<T>::ROWB + ((c ^ (row & (AT<T>::NCH - 1))) << 4);
 }
 
-// row-major tile (zero rows >= L) -> LDS, swizzled
-template <typename T>
-__device__ __forceinline__ void stage_rowmajor(const T* __restrict__ src, int ld, int L, int LP, char* dst, int tid) {
+// row-major tile (zero rows >= L) -> LDS, swizzled.  All global loads are issued before the
+// first LDS write (one memory round trip per tile instead of one per loop iteration).
+template <typename T, int LP, int NT>
+__device__ __forceinline__ void stage_rowmajor(const T* __restrict__ src, int ld, int L, char* dst, int tid) {
     typedef typename AT<T>::frag_t frag_t;
-    for (int idx = tid; idx < LP * AT<T>::NCH; idx += 256) {
-        const int row = idx / AT<T>::NCH, c = idx % AT<T>::NCH;
-        frag_t v;
+    constexpr int TOTAL = LP * AT<T>::NCH, NIT = (TOTAL + NT - 1) / NT;
+    frag_t buf[NIT];
 #pragma unroll
-        for (int e = 0; e < AT<T>::CE; ++e) v[e] = (T)0.f;
-        if (row < L) v = *reinterpret_cast<const frag_t*>(src + (size_t)row * ld + c * AT<T>::CE);
-        *reinterpret_cast<frag_t*>(dst + rm_off<T>(row, c)) = v;
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        const int row = idx / AT<T>::NCH, c = idx % AT<T>::NCH;
+#pragma unroll
+        for (int e = 0; e < AT<T>::CE; ++e) buf[it][e] = (T)0.f;
+        if (idx < TOTAL && row < L) buf[it] = *reinterpret_cast<const frag_t*>(src + (size_t)row * ld + c * AT<T>::CE);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        const int row = idx / AT<T>::NCH, c = idx % AT<T>::NCH;
+        if (idx < TOTAL) *reinterpret_cast<frag_t*>(dst + rm_off<T>(row, c)) = buf[it];
     }
 }
 
 // transposed tile Xt[d][token] (zero tokens >= L) -> LDS
-template <typename T>
-__device__ __forceinline__ void stage_transposed(const T* __restrict__ src, int ld, int L, int LP, T* dst, int ts,
-                                                 int tid) {
+template <typename T, int LP, int NT>
+__device__ __forceinline__ void stage_transposed(const T* __restrict__ src, int ld, int L, T* dst, int ts, int tid) {
     typedef typename AT<T>::frag_t frag_t;
     // consecutive threads take consecutive tokens (conflict-free LDS writes), chunks outer
-    for (int idx = tid; idx < LP * AT<T>::NCH; idx += 256) {
+    constexpr int TOTAL = LP * AT<T>::NCH, NIT = (TOTAL + NT - 1) / NT;
+    frag_t buf[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
         const int c = idx / LP, tok = idx % LP;
-        frag_t v;
 #pragma unroll
-        for (int e = 0; e < AT<T>::CE; ++e) v[e] = (T)0.f;
-        if (tok < L) v = *reinterpret_cast<const frag_t*>(src + (size_t)tok * ld + c * AT<T>::CE);
+        for (int e = 0; e < AT<T>::CE; ++e) buf[it][e] = (T)0.f;
+        if (idx < TOTAL && tok < L) buf[it] = *reinterpret_cast<const frag_t*>(src + (size_t)tok * ld + c * AT<T>::CE);
+    }
 #pragma unroll
-        for (int e = 0; e < AT<T>::CE; ++e) dst[(size_t)(c * AT<T>::CE + e) * ts + tok] = v[e];
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * NT;
+        const int c = idx / LP, tok = idx % LP;
+        if (idx < TOTAL) {
+#pragma unroll
+            for (int e = 0; e < AT<T>::CE; ++e) dst[(size_t)(c * AT<T>::CE + e) * ts + tok] = buf[it][e];
+        }
     }
 }
 
@@ -128,8 +146,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    stage_rowmajor<T>(base + E, ld, L, LP, Ks, tid);
-    stage_transposed<T>(base + 2 * E, ld, L, LP, Vt, ts, tid);
+    stage_rowmajor<T, LP, 256>(base + E, ld, L, Ks, tid);
+    stage_transposed<T, LP, 256>(base + 2 * E, ld, L, Vt, ts, tid);
     __syncthreads();
 
     const int NF = (L + 15) / 16;
@@ -222,18 +240,33 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     }
 }
 
-// dQ: same decomposition as forward.  dS^T[key][q] = P^T * (dP^T - delta[q]) * scale,
-// dQ^T[d][q] = sum_key Kt[d][key] dS^T[key][q].
-template <typename T, int NFP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                          int L, int heads, int causal, int qsplit) {
+// Backward kernels: 8 waves per block, one block per (b, h).  With STAGED (bf16) the row-major
+// operand tiles live in LDS next to the transposed ones; the f32 parity mode would need > 160 KB
+// for that and reads those fragments from global memory (L2) instead.
+
+template <typename T, bool STAGED>
+__device__ __forceinline__ typename AT<T>::frag_t opfrag(const char* lds_tile, const T* __restrict__ src, int ld,
+                                                        int row, int L, int ks, int g) {
+    if constexpr (STAGED)
+        return *reinterpret_cast<const typename AT<T>::frag_t*>(lds_tile + rm_off<T>(row, ks * 4 + g));
+    else
+        return gfrag<T>(src, ld, row, L, ks, g);
+}
+
+// dQ: dS^T[key][q] = P^T * (dP^T - delta[q]) * scale,  dQ^T[d][q] = sum_key Kt[d][key] dS^T[key][q].
+template <typename T, int NFP, bool STAGED, int BW_THREADS>
+__global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
+                                                                 const T* __restrict__ d_o,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta,
+                                                                 T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LP = NFP * 16;
     const int ts = tstride<T>(LP);
     T* Kt = reinterpret_cast<T*>(smem);                           // [64][ts]
+    char* Ks = smem + (size_t)HD * ts * AT<T>::ES;                // [LP][64] swizzled (STAGED)
+    char* Vs = Ks + LP * AT<T>::ROWB;
 
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -242,16 +275,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    stage_transposed<T>(base + E, ld, L, LP, Kt, ts, tid);
+    stage_transposed<T, LP, BW_THREADS>(base + E, ld, L, Kt, ts, tid);
+    if constexpr (STAGED) {
+        stage_rowmajor<T, LP, BW_THREADS>(base + E, ld, L, Ks, tid);
+        stage_rowmajor<T, LP, BW_THREADS>(base + 2 * E, ld, L, Vs, tid);
+    }
     __syncthreads();
 
     const int NF = (L + 15) / 16;
-    const int per = (NF + qsplit - 1) / qsplit;
-    const int qt0 = blockIdx.y * per;
-    const int qt1 = (qt0 + per) < NF ? (qt0 + per) : NF;
-    for (int qt = qt0 + wave; qt < qt1; qt += 4) {
-        // the K/V fragment loads below do not depend on qt: without this compiler-level fence LICM
-        // hoists all of them out of the loop and keeps NFP*ND*2 fragments live (spills)
+    for (int qt = wave; qt < NF; qt += BW_THREADS / 64) {
+        // (f32 path) the K/V fragment loads below do not depend on qt: without this compiler-level
+        // fence LICM hoists all of them out of the loop and keeps NFP*ND*2 fragments live (spills)
         asm volatile("" ::: "memory");
         const int q = qt * 16 + col;
         const int qc = q < L ? q : L - 1;
@@ -270,8 +304,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                const frag_t kf = gfrag<T>(base + E, ld, f * 16 + col, L, ks, g);
-                const frag_t vf = gfrag<T>(base + 2 * E, ld, f * 16 + col, L, ks, g);
+                const frag_t kf = opfrag<T, STAGED>(Ks, base + E, ld, f * 16 + col, L, ks, g);
+                const frag_t vf = opfrag<T, STAGED>(Vs, base + 2 * E, ld, f * 16 + col, L, ks, g);
                 Mma16<T>::mma(sa, kf, qf[ks]);
                 Mma16<T>::mma(pa, vf, dof[ks]);
             }
@@ -312,11 +346,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 // dK/dV: waves own 16-key tiles; a lane holds key = lane&15 and 4 consecutive
 // queries per fragment.  S[q][key] = Q K^T (A = Q rows), dP[q][key] = dO V^T,
 // dV^T[d][key] = sum_q dOt[d][q] P[q][key],  dK^T[d][key] = sum_q Qt[d][q] dS[q][key].
-template <typename T, int NFP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
-                                                           const float* __restrict__ lse,
-                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                           int L, int heads, int causal, int ksplit) {
+template <typename T, int NFP, bool STAGED, int BW_THREADS>
+__global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
+                                                                  const T* __restrict__ d_o,
+                                                                  const float* __restrict__ lse,
+                                                                  const float* __restrict__ delta,
+                                                                  T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LP = NFP * 16;
@@ -325,6 +360,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     T* dOt = Qt + (size_t)HD * ts;                                // [64][ts]
     float* lse_s = reinterpret_cast<float*>(dOt + (size_t)HD * ts);   // [LP]
     float* del_s = lse_s + LP;                                    // [LP]
+    char* Qs = reinterpret_cast<char*>(del_s + LP);               // [LP][64] swizzled (STAGED)
+    char* dOs = Qs + LP * AT<T>::ROWB;
 
     const int bh = blockIdx.x, b = bh / heads, h = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -333,19 +370,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    stage_transposed<T>(base, ld, L, LP, Qt, ts, tid);
-    stage_transposed<T>(dob, E, L, LP, dOt, ts, tid);
-    for (int i = tid; i < LP; i += 256) {
+    stage_transposed<T, LP, BW_THREADS>(base, ld, L, Qt, ts, tid);
+    stage_transposed<T, LP, BW_THREADS>(dob, E, L, dOt, ts, tid);
+    if constexpr (STAGED) {
+        stage_rowmajor<T, LP, BW_THREADS>(base, ld, L, Qs, tid);
+        stage_rowmajor<T, LP, BW_THREADS>(dob, E, L, dOs, tid);
+    }
+    for (int i = tid; i < LP; i += BW_THREADS) {
         lse_s[i] = i < L ? lse[((size_t)b * heads + h) * L + i] : 0.f;
         del_s[i] = i < L ? delta[((size_t)b * heads + h) * L + i] : 0.f;
     }
     __syncthreads();
 
     const int NF = (L + 15) / 16;
-    const int per = (NF + ksplit - 1) / ksplit;
-    const int kt0 = blockIdx.y * per;
-    const int kt1 = (kt0 + per) < NF ? (kt0 + per) : NF;
-    for (int kt = kt0 + wave; kt < kt1; kt += 4) {
+    for (int kt = wave; kt < NF; kt += BW_THREADS / 64) {
         asm volatile("" ::: "memory");   // same LICM fence as in the dQ kernel (Q / dO fragments)
         const int key = kt * 16 + col;
         frag_t kf[AT<T>::ND], vf[AT<T>::ND];
@@ -360,8 +398,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                const frag_t qf = gfrag<T>(base, ld, f * 16 + col, L, ks, g);
-                const frag_t dof = gfrag<T>(dob, E, f * 16 + col, L, ks, g);
+                const frag_t qf = opfrag<T, STAGED>(Qs, base, ld, f * 16 + col, L, ks, g);
+                const frag_t dof = opfrag<T, STAGED>(dOs, dob, E, f * 16 + col, L, ks, g);
                 Mma16<T>::mma(sa, qf, kf[ks]);
                 Mma16<T>::mma(pa, dof, vf[ks]);
             }
@@ -407,9 +445,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     }
 }
 
+template <typename T> constexpr bool kStaged() { return sizeof(T) == 2; }
+template <typename T> constexpr int kBwThreads() { return sizeof(T) == 2 ? 512 : 256; }   // f32 needs the 512-VGPR budget
 template <typename T> int lds_fwd(int NFP) { return NFP * 16 * AT<T>::ROWB + HD * tstride<T>(NFP * 16) * AT<T>::ES; }
-template <typename T> int lds_dq(int NFP) { return HD * tstride<T>(NFP * 16) * AT<T>::ES; }
-template <typename T> int lds_dkv(int NFP) { return 2 * HD * tstride<T>(NFP * 16) * AT<T>::ES + 2 * NFP * 16 * 4; }
+template <typename T> int lds_dq(int NFP) {
+    return HD * tstride<T>(NFP * 16) * AT<T>::ES + (kStaged<T>() ? 2 * NFP * 16 * AT<T>::ROWB : 0);
+}
+template <typename T> int lds_dkv(int NFP) {
+    return 2 * HD * tstride<T>(NFP * 16) * AT<T>::ES + 2 * NFP * 16 * 4 + (kStaged<T>() ? 2 * NFP * 16 * AT<T>::ROWB : 0);
+}
 
 template <typename F> int set_lds(F fn, int bytes) {
     if (bytes > 65536) {
@@ -442,21 +486,20 @@ int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int
 template <typename T, int NFP>
 int run_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
             int L, int heads, int causal, hipStream_t s) {
-    const int NF = (L + 15) / 16, split = pick_split(B * heads, NF);
     hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((B * L * heads + 3) / 4), dim3(256), 0, s, (const T*)out,
                        (const T*)dout, delta, B, L, heads);
     FFM_CHECK_LAUNCH();
     int lds = lds_dq<T>(NFP);
-    int e = set_lds(attn_bwd_dq_kernel<T, NFP>, lds);
+    int e = set_lds(attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv,
-                       (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal, split);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>), dim3(B * heads), dim3(kBwThreads<T>()), lds, s,
+                       (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal);
     FFM_CHECK_LAUNCH();
     lds = lds_dkv<T>(NFP);
-    e = set_lds(attn_bwd_dkv_kernel<T, NFP>, lds);
+    e = set_lds(attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv,
-                       (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal, split);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>), dim3(B * heads), dim3(kBwThreads<T>()), lds, s,
+                       (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

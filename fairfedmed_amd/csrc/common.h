@@ -131,12 +131,27 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float quick_gelu_f(float x) {
     // clip/model.py:313-315: x * sigmoid(1.702 x)
-    return x / (1.0f + __expf(-1.702f * x));
+    return x / (1.0f + expf(-1.702f * x));
 }
 __device__ __forceinline__ float quick_gelu_grad_f(float x) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    float s = 1.0f / (1.0f + expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+
+// QuickGELU in the epilogues: exact-ish libm path for the f32 parity mode, hardware exp/rcp for bf16
+// (the result is rounded to 8 mantissa bits anyway).
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static __device__ __forceinline__ float gelu(float x) { return quick_gelu_f(x); }
+    static __device__ __forceinline__ float gelu_grad(float x) { return quick_gelu_grad_f(x); }
+};
+template <> struct Act<bf16_t> {
+    static __device__ __forceinline__ float gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
+    static __device__ __forceinline__ float gelu_grad(float x) {
+        const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
+        return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+};
 
 // pi_b[g]: 0.7 on the sample's own group, 0.3/(G-1) elsewhere; uniform when
 // attr is NULL (trainers/GLP_OT_SVLoRA.py:453-462).

@@ -145,46 +145,67 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
         __syncthreads();
         const int gn = n0 + ecol;
         if (gn < p.N) {
-            float bias8[8];
+            float v[4][8];
+            {
+                float bias8[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) bias8[c] = (p.flags & FFM_EPI_BIAS) ? p.bias[gn + c] : 0.f;
+                for (int c = 0; c < 8; ++c) bias8[c] = (p.flags & FFM_EPI_BIAS) ? p.bias[gn + c] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int lrow = erow0 + 16 * i;
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol]);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol + 4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { v[i][c] = c0[c] + bias8[c]; v[i][4 + c] = c1[c] + bias8[4 + c]; }
+                }
+            }
+            if (has_lora) {
+                // rank-r update: this thread's 8 columns of the LoRA matrix stay in registers
+                for (int j0 = 0; j0 < r; j0 += 8) {
+                    float lreg[8][8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = (j0 + jj) < r ? (j0 + jj) : (r - 1);
+                        const f32x4 l0 = *reinterpret_cast<const f32x4*>(&Ls[j * BN + ecol]);
+                        const f32x4 l1 = *reinterpret_cast<const f32x4*>(&Ls[j * BN + ecol + 4]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { lreg[jj][c] = l0[c]; lreg[jj][4 + c] = l1[c]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int lrow = erow0 + 16 * i;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const float tj = (j0 + jj) < r ? Ts[lrow * r + j0 + jj] : 0.f;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) v[i][c] += tj * lreg[jj][c];
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int lrow = erow0 + 16 * i;
                 const int gm = m0 + half * 64 + lrow;
                 if (gm >= p.M) continue;
-                float v[8];
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol]);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol + 4]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { v[c] = c0[c] + bias8[c]; v[4 + c] = c1[c] + bias8[4 + c]; }
-                if (has_lora) {
-                    for (int j = 0; j < r; ++j) {
-                        const float tj = Ts[lrow * r + j];
-                        const f32x4 l0 = *reinterpret_cast<const f32x4*>(&Ls[j * BN + ecol]);
-                        const f32x4 l1 = *reinterpret_cast<const f32x4*>(&Ls[j * BN + ecol + 4]);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { v[c] += tj * l0[c]; v[4 + c] += tj * l1[c]; }
-                    }
-                }
                 const size_t off = (size_t)gm * p.ldc + gn;
                 if (p.flags & FFM_EPI_RESIDUAL) {
                     float rr[8];
                     Vec8<T>::load(reinterpret_cast<const T*>(p.res) + off, rr);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] += rr[c];
+                    for (int c = 0; c < 8; ++c) v[i][c] += rr[c];
                 }
                 if (p.flags & FFM_EPI_DGELU) {
                     float pre[8];
                     Vec8<T>::load(reinterpret_cast<const T*>(p.aux) + off, pre);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] *= quick_gelu_grad_f(pre[c]);
+                    for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(pre[c]);
                 }
-                Vec8<T>::store(C + off, v);
+                Vec8<T>::store(C + off, v[i]);
                 if (p.flags & FFM_EPI_GELU) {
                     float a[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) a[c] = quick_gelu_f(Elem<T>::to_f(Elem<T>::from_f(v[c])));
+                    for (int c = 0; c < 8; ++c) a[c] = Act<T>::gelu(Elem<T>::to_f(Elem<T>::from_f(v[i][c])));
                     Vec8<T>::store(reinterpret_cast<T*>(p.c2) + off, a);
                 }
             }

@@ -1,216 +1,370 @@
-// Rank-r FairLoRA kernels (HBM-bound, VALU + LDS + wave shuffles; no MFMA):
-//   lora_down         t = x P (P staged in LDS tiles), ts = scaling * t * s_b, dS partials
+// Rank-r FairLoRA kernels (HBM-bound; VALU + wave shuffles + LDS, no MFMA):
+//   lora_down         t = x P, ts = scaling * t * s_b, dS partials
 //   lora_grad_partial part[s] = sum_{rows of split s} x^T v   (dA / dB without forming dW)
 //   reduce_partials   deterministic second stage
+//
+// Both streaming kernels use "column-owner" lanes: a lane owns 16 bytes of every
+// row it visits (8 bf16 / 4 f32 columns), so each wave-instruction reads 1 KiB
+// of one row, fully coalesced, and the rank-r operand of that lane lives in
+// registers for the whole kernel.
 #include "common.h"
 
 namespace {
 
 // ---------------------------------------------------------------------------
-// lora_down: block = 4 waves x 8 rows; lane -> (row = lane & 7, kgroup = lane >> 3).
-// Per step a wave reads 8 rows x 128 contiguous bytes (full lines); the K-tile
-// of P lives in LDS as Ps[k][RP] and lanes of one k-group broadcast-read it.
+// lora_down.  Block = LD_WAVES waves; the rank-r operand P is staged ONCE per
+// block in LDS (in the activation dtype, laid out so that the 64 lanes of a
+// wave read consecutive 16-byte units).  Each wave owns RSUB = 64/RP rows and
+// sweeps the whole K: per 16-byte chunk it loads the RSUB rows, reads that
+// chunk's P slice from LDS once and reuses it for all RSUB rows.  The
+// RSUB x RP partial sums are combined across the 64 lanes by a butterfly
+// reduce-scatter (63 shuffles for 64 values) that leaves value (row, j) on lane
+// row*RP + j, which then writes t / ts directly.
 // ---------------------------------------------------------------------------
-constexpr int LD_ROWS = 32;     // rows per block
-constexpr int LD_NIT = 8;       // 16-byte loads in flight per lane per K-tile
+constexpr int LD_WAVES = 8;
+constexpr int LD_LDS_BUDGET = 64 * 1024;
 
-template <typename T, int RP>
-__global__ __launch_bounds__(256) void lora_down_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ P,
-                                                        int layout_rk, const float* __restrict__ S,
-                                                        const int32_t* __restrict__ attr, int M, int K, int r, int G,
-                                                        int rows_per_sample, float scaling, float lambda_group,
-                                                        float* __restrict__ t_out, float* __restrict__ ts_out,
-                                                        const float* __restrict__ t_fwd, float* __restrict__ ds_part) {
-    constexpr int CE = Elem<T>::kPerChunk;          // elements per 16 B
-    constexpr int KSTEP = 8 * CE;                    // k covered by one wave step
-    constexpr int KT = LD_NIT * KSTEP;               // k per LDS tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ps = reinterpret_cast<float*>(smem);      // [KT][RP]
-    float* Vs = Ps + KT * RP;                        // [32][RP] dS staging
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rsub = lane & 7, kg = lane >> 3;
-    const int row = blockIdx.x * LD_ROWS + wave * 8 + rsub;
-    const int lrow = row < M ? row : M - 1;
-    const T* xr = x + (size_t)lrow * ldx;
-
-    float acc[RP];
+template <int V>
+__device__ __forceinline__ void reduce_scatter64(float (&vals)[V], int lane) {
+    // V == 64: afterwards vals[0] on lane l is the sum over all lanes of vals[l].
 #pragma unroll
-    for (int j = 0; j < RP; ++j) acc[j] = 0.f;
-
-    for (int k0 = 0; k0 < K; k0 += KT) {
-        const int kt = (K - k0) < KT ? (K - k0) : KT;
-        __syncthreads();
-        // stage P[k0 .. k0+kt) -> Ps[kk][j], zero-padding j >= r
-        for (int idx = tid; idx < kt * RP; idx += 256) {
-            float v = 0.f;
-            if (layout_rk) {
-                const int j = idx / kt, kk = idx % kt;       // read along k (contiguous in P[j][:])
-                if (j < r) v = P[(size_t)j * K + k0 + kk];
-                Ps[kk * RP + j] = v;
-            } else {
-                const int kk = idx / RP, j = idx % RP;
-                if (j < r) v = P[(size_t)(k0 + kk) * r + j];
-                Ps[idx] = v;
-            }
-        }
-        // issue this lane's loads for the tile
-        typename Elem<T>::chunk_t xv[LD_NIT];
+    for (int n = V, o = 32; o >= 1; n >>= 1, o >>= 1) {
+        const bool up = (lane & o) != 0;
 #pragma unroll
-        for (int it = 0; it < LD_NIT; ++it) {
-            const int k = k0 + it * KSTEP + kg * CE;
-            if (k < K) xv[it] = *reinterpret_cast<const typename Elem<T>::chunk_t*>(xr + k);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < LD_NIT; ++it) {
-            const int kk0 = it * KSTEP + kg * CE;
-            if (k0 + kk0 < K) {
-#pragma unroll
-                for (int e = 0; e < CE; ++e) {
-                    const float xe = Elem<T>::to_f(xv[it][e]);
-                    const float* pr = Ps + (kk0 + e) * RP;
-#pragma unroll
-                    for (int j4 = 0; j4 < RP / 4; ++j4) {
-                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pr + j4 * 4);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[j4 * 4 + c] += xe * pv[c];
-                    }
-                }
-            }
-        }
-    }
-    // reduce across the 8 k-groups (lanes differing in bits 3..5)
-#pragma unroll
-    for (int j = 0; j < RP; ++j) {
-        float v = acc[j];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[j] = v;
-    }
-    const bool writer = (kg == 0) && (row < M);
-    const int sample = lrow / rows_per_sample;
-    if (writer) {
-        for (int j = 0; j < r; ++j) {
-            float sb = 0.f;
-            for (int g = 0; g < G; ++g) sb += group_mix_w(attr, sample, g, G, lambda_group) * S[g * r + j];
-            if (t_out) t_out[(size_t)row * r + j] = acc[j];
-            if (ts_out) ts_out[(size_t)row * r + j] = scaling * acc[j] * sb;
-        }
-    }
-    if (t_fwd && ds_part) {
-        __syncthreads();
-        if (kg == 0) {
-            for (int j = 0; j < r; ++j)
-                Vs[(wave * 8 + rsub) * RP + j] = (row < M) ? scaling * t_fwd[(size_t)row * r + j] * acc[j] : 0.f;
-        }
-        __syncthreads();
-        if (tid < G * r) {
-            const int g = tid / r, j = tid % r;
-            float s = 0.f;
-            for (int rr = 0; rr < LD_ROWS; ++rr) {
-                const int grow = blockIdx.x * LD_ROWS + rr;
-                if (grow < M) s += group_mix_w(attr, grow / rows_per_sample, g, G, lambda_group) * Vs[rr * RP + j];
-            }
-            ds_part[((size_t)blockIdx.x * G + g) * r + j] = s;
+        for (int i = 0; i < n / 2; ++i) {
+            const float a = vals[i], b = vals[i + n / 2];
+            const float keep = up ? b : a, send = up ? a : b;
+            vals[i] = keep + __shfl_xor(send, o, 64);
         }
     }
 }
 
 template <typename T, int RP>
+__global__ __launch_bounds__(LD_WAVES * 64) void lora_down_kernel(
+    const T* __restrict__ x, int ldx, const float* __restrict__ P, int layout_rk, const float* __restrict__ S,
+    const int32_t* __restrict__ attr, int M, int K, int r, int G, int rows_per_sample, float scaling,
+    float lambda_group, float* __restrict__ t_out, float* __restrict__ ts_out, const float* __restrict__ t_fwd,
+    float* __restrict__ ds_part, int ktile, int rs, int j0, int kq_n) {
+    // r = columns handled by this pass (<= RP), starting at column j0 of arrays whose rank stride is rs.
+    // The block's 8 waves are (8/kq_n) row groups x kq_n slices of K; slices are summed through LDS.
+    typedef typename Elem<T>::chunk_t chunk_t;
+    constexpr int CE = Elem<T>::kPerChunk;           // columns per 16-byte chunk of x
+    constexpr int NQ = RP / CE;                       // 16-byte units of P per column (RP values of type T)
+    constexpr int RSUB = 64 / RP;                     // rows per row group
+    constexpr int ROWS = LD_WAVES * RSUB;             // max rows per block (kq_n = 1)
+    static_assert(RP % CE == 0 && 64 % RP == 0, "rank padding must be a multiple of the chunk width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    chunk_t* Ps = reinterpret_cast<chunk_t*>(smem);   // unit index ((e*NQ + q) * nch + ch): P[ch*CE+e][q*CE .. +CE)
+    __shared__ float Vs[ROWS * RP];
+    __shared__ float Red[LD_WAVES * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave % kq_n, rg = wave / kq_n;
+    const int rows_blk = (LD_WAVES / kq_n) * RSUB;
+    const int row0 = blockIdx.x * rows_blk + rg * RSUB;
+    float vals[RSUB * RP];
+#pragma unroll
+    for (int i = 0; i < RSUB * RP; ++i) vals[i] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += ktile) {
+        const int kt = (K - k0) < ktile ? (K - k0) : ktile;
+        const int nch = kt / CE;                      // chunks in this tile
+        __syncthreads();
+        // stage P[k0 .. k0+kt) as T.  A thread converts 4 consecutive columns at a time from 16-byte
+        // loads that are all in flight together (the tile is read once per block, so its latency is
+        // exposed: keep it to one round trip).
+        const bool vec_ok = ((rs & 3) == 0) && ((j0 & 3) == 0) && ((K & 3) == 0) && ((k0 & 3) == 0);
+#pragma unroll 2
+        for (int g4 = tid; g4 < (kt + 3) / 4; g4 += LD_WAVES * 64) {
+            float pv4[4][RP];                          // [column u][rank j]
+            if (vec_ok && 4 * g4 + 3 < kt) {
+                if (layout_rk) {
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (j < r) v = *reinterpret_cast<const f32x4*>(P + (size_t)(j0 + j) * K + k0 + 4 * g4);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pv4[u][j] = v[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int jq = 0; jq < RP / 4; ++jq) {
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                            if (jq * 4 < r)
+                                v = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + 4 * g4 + u) * rs + j0 + jq * 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) pv4[u][jq * 4 + c] = (jq * 4 + c) < r ? v[c] : 0.f;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) {
+                        const int kk = 4 * g4 + u;
+                        float v = 0.f;
+                        if (kk < kt && j < r)
+                            v = layout_rk ? P[(size_t)(j0 + j) * K + k0 + kk] : P[(size_t)(k0 + kk) * rs + j0 + j];
+                        pv4[u][j] = v;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = 4 * g4 + u;
+                if (kk < kt) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        chunk_t w;
+#pragma unroll
+                        for (int c = 0; c < CE; ++c) w[c] = Elem<T>::from_f(pv4[u][q * CE + c]);
+                        Ps[((kk % CE) * NQ + q) * nch + kk / CE] = w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int cpw = ((nch + kq_n - 1) / kq_n + 63) / 64 * 64;      // chunks per K slice
+        const int ch_end = (kq + 1) * cpw < nch ? (kq + 1) * cpw : nch;
+#pragma unroll 1
+        for (int ch = kq * cpw + lane; ch < ch_end; ch += 64) {
+            chunk_t xv[RSUB];
+#pragma unroll
+            for (int i = 0; i < RSUB; ++i) {
+                int row = row0 + i;
+                row = row < M ? row : M - 1;
+                xv[i] = *reinterpret_cast<const chunk_t*>(x + (size_t)row * ldx + k0 + ch * CE);
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float pv[RP];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const chunk_t u = Ps[(e * NQ + q) * nch + ch];
+#pragma unroll
+                    for (int c = 0; c < CE; ++c) pv[q * CE + c] = Elem<T>::to_f(u[c]);
+                }
+#pragma unroll
+                for (int i = 0; i < RSUB; ++i) {
+                    const float xe = Elem<T>::to_f(xv[i][e]);
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) vals[i * RP + j] += xe * pv[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the per-element working set small (VGPR pressure)
+            }
+        }
+    }
+    reduce_scatter64<RSUB * RP>(vals, lane);
+    float tval = vals[0];
+    if (kq_n > 1) {                                   // sum the K slices of this row group
+        Red[wave * 64 + lane] = tval;
+        __syncthreads();
+        tval = 0.f;
+        for (int q = 0; q < kq_n; ++q) tval += Red[(rg * kq_n + q) * 64 + lane];
+    }
+    const int oj = lane % RP;
+    const int orow = row0 + lane / RP;
+    const bool writer = (kq == 0) && orow < M && oj < r;
+    if (writer) {
+        const int sample = orow / rows_per_sample;
+        float sbv = 0.f;
+        for (int g = 0; g < G; ++g) sbv += group_mix_w(attr, sample, g, G, lambda_group) * S[g * rs + j0 + oj];
+        if (t_out) t_out[(size_t)orow * rs + j0 + oj] = tval;
+        if (ts_out) ts_out[(size_t)orow * rs + j0 + oj] = scaling * tval * sbv;
+    }
+    if (t_fwd && ds_part) {
+        if (kq == 0)
+            Vs[(rg * RSUB + lane / RP) * RP + oj] = writer ? scaling * t_fwd[(size_t)orow * rs + j0 + oj] * tval : 0.f;
+        __syncthreads();
+        if (tid < G * r) {
+            const int g = tid / r, j = tid % r;
+            float s = 0.f;
+            for (int rr = 0; rr < rows_blk; ++rr) {
+                const int grow = blockIdx.x * rows_blk + rr;
+                if (grow < M) s += group_mix_w(attr, grow / rows_per_sample, g, G, lambda_group) * Vs[rr * RP + j];
+            }
+            ds_part[((size_t)blockIdx.x * G + g) * rs + j0 + j] = s;
+        }
+    }
+}
+
+// K slices per block: enough waves to fill the chip (>= ~2000) while every lane of a slice has work
+static int down_kq(int K, int es) {
+    const int nch = K * es / 16;
+    return nch >= 256 ? 4 : nch >= 96 ? 2 : 1;
+}
+static int down_rp(int r, int dtype) { return r <= 4 && dtype == FFM_F32 ? 4 : r <= 8 ? 8 : 16; }
+
+template <typename T, int RP>
 int launch_down(const void* x, int ldx, const float* P, int layout_rk, const float* S, const int32_t* attr, int M,
                 int K, int r, int G, int rps, float scaling, float lam, float* t, float* ts, const float* t_fwd,
-                float* ds_part, hipStream_t s) {
-    constexpr int KT = LD_NIT * 8 * Elem<T>::kPerChunk;
-    const int lds = (KT * RP + LD_ROWS * RP) * 4;
-    const int blocks = (M + LD_ROWS - 1) / LD_ROWS;
-    hipLaunchKernelGGL((lora_down_kernel<T, RP>), dim3(blocks), dim3(256), lds, s, (const T*)x, ldx, P, layout_rk, S,
-                       attr, M, K, r, G, rps, scaling, lam, t, ts, t_fwd, ds_part);
+                float* ds_part, int rs, int j0, hipStream_t s) {
+    constexpr int CE = Elem<T>::kPerChunk;
+    // K tile: whole K if its P image fits the LDS budget, else the largest multiple of 64 chunks that does
+    int ktile = K;
+    const int per_col = RP * (int)sizeof(T);
+    if (K * per_col > LD_LDS_BUDGET) ktile = (LD_LDS_BUDGET / per_col) / (64 * CE) * (64 * CE);
+    const int lds = ktile * per_col;
+    const int kq = down_kq(K, (int)sizeof(T));
+    const int rows = (LD_WAVES / kq) * (64 / RP);
+    const int blocks = (M + rows - 1) / rows;
+    hipLaunchKernelGGL((lora_down_kernel<T, RP>), dim3(blocks), dim3(LD_WAVES * 64), lds, s, (const T*)x, ldx, P,
+                       layout_rk, S, attr, M, K, r, G, rps, scaling, lam, t, ts, t_fwd, ds_part, ktile, rs, j0, kq);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
 
 // ---------------------------------------------------------------------------
-// lora_grad_partial: one wave per (256-column group, 64-row split); lane owns 4
-// consecutive columns, v[m][:] is wave-uniform (scalar loads).
+// lora_grad_partial.  Block = LG_WAVES waves over the same 64*CE columns, each
+// wave sums LG_RPW rows (v[m][:] is wave-uniform -> scalar loads), then the
+// waves are combined by an LDS tree; one partial per (column group, row block).
 // ---------------------------------------------------------------------------
-constexpr int LG_ROWS = 64;
+constexpr int LG_WAVES = 4;
+constexpr int LG_RPW = 32;
+constexpr int LG_ROWS = LG_WAVES * LG_RPW;      // rows per block (= rows per partial)
 
 template <typename T, int RP>
-__global__ __launch_bounds__(64) void lora_grad_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ v,
-                                                       int M, int K, int r, float* __restrict__ part) {
-    const int lane = threadIdx.x;
-    const int k = blockIdx.x * 256 + lane * 4;
+__global__ __launch_bounds__(LG_WAVES * 64) void lora_grad_kernel(const T* __restrict__ x, int ldx,
+                                                                   const float* __restrict__ v, int M, int K, int r,
+                                                                   float* __restrict__ part, int rs, int j0) {
+    constexpr int CE = Elem<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);     // [2 waves][CE*RP][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = (blockIdx.x * 64 + lane) * CE;
     const int split = blockIdx.y;
-    const int m0 = split * LG_ROWS;
-    const int m1 = (m0 + LG_ROWS) < M ? (m0 + LG_ROWS) : M;
     const bool active = k < K;
-    float acc[4][RP];
+    const int m0 = split * LG_ROWS + wave * LG_RPW;
+    const int m1 = (m0 + LG_RPW) < M ? (m0 + LG_RPW) : M;
+
+    float acc[CE][RP];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < CE; ++e)
 #pragma unroll
         for (int j = 0; j < RP; ++j) acc[e][j] = 0.f;
 
     const T* xc = x + (active ? k : 0);
     for (int m = m0; m < m1; m += 8) {
-        f32x4 xv[8];
+        typename Elem<T>::chunk_t xv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int mm = (m + u) < m1 ? (m + u) : (m1 - 1);
-            xv[u] = Vec4<T>::load(xc + (size_t)mm * ldx);
+            xv[u] = *reinterpret_cast<const typename Elem<T>::chunk_t*>(xc + (size_t)mm * ldx);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (m + u < m1) {
-                const float* vr = v + (size_t)(m + u) * r;   // wave-uniform address
+                const float* vr = v + (size_t)(m + u) * rs + j0;   // wave-uniform address -> scalar loads
+                float vj[RP];
 #pragma unroll
-                for (int j = 0; j < RP; ++j) {
-                    const float vj = (j < r) ? vr[j] : 0.f;
+                for (int j = 0; j < RP; ++j) vj[j] = (j < r) ? vr[j] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e][j] += xv[u][e] * vj;
+                for (int e = 0; e < CE; ++e) {
+                    const float xe = Elem<T>::to_f(xv[u][e]);
+#pragma unroll
+                    for (int j = 0; j < RP; ++j) acc[e][j] += xe * vj[j];
                 }
             }
         }
     }
-    if (active) {
-        float* dst = part + ((size_t)split * K + k) * r;
+    // tree over the 4 waves: {2,3} -> LDS -> {0,1} add; {1} -> LDS -> {0} adds
+    if (wave >= 2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            for (int j = 0; j < r; ++j) dst[e * r + j] = acc[e][j];
+        for (int e = 0; e < CE; ++e)
+#pragma unroll
+            for (int j = 0; j < RP; ++j) red[((wave - 2) * CE * RP + e * RP + j) * 64 + lane] = acc[e][j];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
+#pragma unroll
+            for (int j = 0; j < RP; ++j) acc[e][j] += red[(wave * CE * RP + e * RP + j) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
+#pragma unroll
+            for (int j = 0; j < RP; ++j) red[(e * RP + j) * 64 + lane] = acc[e][j];
+    }
+    __syncthreads();
+    if (wave == 0 && active) {
+        float* dst = part + ((size_t)split * K + k) * rs + j0;
+#pragma unroll
+        for (int e = 0; e < CE; ++e)
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                if (j < r) dst[e * rs + j] = acc[e][j] + red[(e * RP + j) * 64 + lane];
     }
 }
 
 template <typename T, int RP>
-int launch_grad(const void* x, int ldx, const float* v, int M, int K, int r, float* part, hipStream_t s) {
-    dim3 grid((K + 255) / 256, (M + LG_ROWS - 1) / LG_ROWS);
-    hipLaunchKernelGGL((lora_grad_kernel<T, RP>), grid, dim3(64), 0, s, (const T*)x, ldx, v, M, K, r, part);
+int launch_grad(const void* x, int ldx, const float* v, int M, int K, int r, float* part, int rs, int j0,
+                hipStream_t s) {
+    constexpr int CE = Elem<T>::kPerChunk;
+    dim3 grid((K + 64 * CE - 1) / (64 * CE), (M + LG_ROWS - 1) / LG_ROWS);
+    const int lds = 2 * CE * RP * 64 * 4;
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lora_grad_kernel<T, RP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((lora_grad_kernel<T, RP>), grid, dim3(LG_WAVES * 64), lds, s, (const T*)x, ldx, v, M, K, r,
+                       part, rs, j0);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
 
+// out[o(i)] (+)= sum_s part[s][i]; 4 split-lanes per output, combined by shuffles
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nsplit, int n,
                                                               float* __restrict__ out, int tK, int tr,
                                                               int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (gid >> 2);                     // 4 consecutive lanes share an output
+    const int q = gid & 3;
     float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * n + i];
+    if (i < n)
+        for (int sp = q; sp < nsplit; sp += 4) s += part[(size_t)sp * n + i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (i >= n || q != 0) return;
     int o = i;
-    if (tK > 0) {                       // i = k * r + j  ->  j * K + k
+    if (tK > 0) {                                 // i = k * r + j  ->  j * K + k
         const int k = i / tr, j = i % tr;
         o = j * tK + k;
     }
     out[o] = accumulate ? out[o] + s : s;
 }
 
-#define DISPATCH_RP(FN, T, r, ...)                                  \
-    ((r) <= 4 ? FN<T, 4>(__VA_ARGS__) : (r) <= 8 ? FN<T, 8>(__VA_ARGS__) \
-     : (r) <= 16 ? FN<T, 16>(__VA_ARGS__) : FN<T, 32>(__VA_ARGS__))
+// many small reductions in one launch: blockIdx.y selects the descriptor
+__global__ __launch_bounds__(256) void reduce_multi_kernel(const ffm_reduce_desc* __restrict__ descs) {
+    const ffm_reduce_desc d = descs[blockIdx.y];
+    if ((int)(blockIdx.x * blockDim.x) >= 4 * d.n) return;     // whole block beyond this tensor (uniform)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = gid >> 2, q = gid & 3;
+    float s = 0.f;
+    if (i < d.n)
+        for (int sp = q; sp < d.nsplit; sp += 4) s += d.part[(size_t)sp * d.n + i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (i >= d.n || q != 0) return;
+    int o = i;
+    if (d.transpose_K > 0) {
+        const int k = i / d.transpose_r, j = i % d.transpose_r;
+        o = j * d.transpose_K + k;
+    }
+    d.out[o] = s;
+}
 
 }  // namespace
 
-extern "C" int ffm_lora_down_blocks(int M) { return (M + LD_ROWS - 1) / LD_ROWS; }
+extern "C" int ffm_lora_down_blocks(int M, int K, int r, int dtype) {
+    const int rows = (LD_WAVES / down_kq(K, dtype == FFM_BF16 ? 2 : 4)) * (64 / down_rp(r, dtype));
+    return (M + rows - 1) / rows;
+}
 extern "C" int ffm_lora_grad_splits(int M) { return (M + LG_ROWS - 1) / LG_ROWS; }
 
 extern "C" int ffm_lora_down(const void* x, int ldx, const float* P, int layout_rk, const float* S,
@@ -224,32 +378,52 @@ extern "C" int ffm_lora_down(const void* x, int ldx, const float* P, int layout_
     if (G * r > 256) return FFM_EUNSUP;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
-    if (((size_t)K * es) % 128 || ((size_t)ldx * es) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
+    if (((size_t)K * es) % 16 || ((size_t)ldx * es) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FFM_BF16)
-        return DISPATCH_RP(launch_down, bf16_t, r, x, ldx, P, layout_rk, S, attr, M, K, r, G, rows_per_sample, scaling,
-                           lambda_group, t, ts, t_fwd, ds_part, s);
-    return DISPATCH_RP(launch_down, float, r, x, ldx, P, layout_rk, S, attr, M, K, r, G, rows_per_sample, scaling,
-                       lambda_group, t, ts, t_fwd, ds_part, s);
+#define DOWN(T, RP, RR, J0) launch_down<T, RP>(x, ldx, P, layout_rk, S, attr, M, K, RR, G, rows_per_sample, scaling, \
+                                               lambda_group, t, ts, t_fwd, ds_part, r, J0, s)
+    if (r > 16) {                       // rank 17..32: two passes over the rank (second pass re-reads x)
+        int e = dtype == FFM_BF16 ? DOWN(bf16_t, 16, 16, 0) : DOWN(float, 16, 16, 0);
+        if (e) return e;
+        return dtype == FFM_BF16 ? DOWN(bf16_t, 16, r - 16, 16) : DOWN(float, 16, r - 16, 16);
+    }
+    if (dtype == FFM_BF16) return r <= 8 ? DOWN(bf16_t, 8, r, 0) : DOWN(bf16_t, 16, r, 0);
+    return r <= 4 ? DOWN(float, 4, r, 0) : r <= 8 ? DOWN(float, 8, r, 0) : DOWN(float, 16, r, 0);
+#undef DOWN
 }
 
 extern "C" int ffm_lora_grad_partial(const void* x, int ldx, const float* v, int M, int K, int r, float* part,
                                      int dtype, void* stream) {
-    if (!x || !v || !part || M <= 0 || K <= 0 || (K & 3) || r <= 0 || r > FFM_MAX_RANK) return FFM_EINVAL;
+    if (!x || !v || !part || M <= 0 || K <= 0 || r <= 0 || r > FFM_MAX_RANK) return FFM_EINVAL;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
-    if (((size_t)ldx * es) % 8 || ((uintptr_t)x & 15)) return FFM_EINVAL;
+    if (((size_t)K * es) % 16 || ((size_t)ldx * es) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FFM_BF16) return DISPATCH_RP(launch_grad, bf16_t, r, x, ldx, v, M, K, r, part, s);
-    return DISPATCH_RP(launch_grad, float, r, x, ldx, v, M, K, r, part, s);
+#define GRAD(T, RP, RR, J0) launch_grad<T, RP>(x, ldx, v, M, K, RR, part, r, J0, s)
+    if (r > 16) {
+        int e = dtype == FFM_BF16 ? GRAD(bf16_t, 16, 16, 0) : GRAD(float, 16, 16, 0);
+        if (e) return e;
+        return dtype == FFM_BF16 ? GRAD(bf16_t, 16, r - 16, 16) : GRAD(float, 16, r - 16, 16);
+    }
+    if (dtype == FFM_BF16) return r <= 4 ? GRAD(bf16_t, 4, r, 0) : r <= 8 ? GRAD(bf16_t, 8, r, 0) : GRAD(bf16_t, 16, r, 0);
+    return r <= 4 ? GRAD(float, 4, r, 0) : r <= 8 ? GRAD(float, 8, r, 0) : GRAD(float, 16, r, 0);
+#undef GRAD
+}
+
+extern "C" int ffm_reduce_partials_multi(const ffm_reduce_desc* descs_dev, int ndesc, int max_n, void* stream) {
+    if (!descs_dev || ndesc <= 0 || max_n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((4 * max_n + 255) / 256, ndesc), dim3(256), 0, (hipStream_t)stream,
+                       descs_dev);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
 }
 
 extern "C" int ffm_reduce_partials(const float* part, int nsplit, int n, float* out, int transpose_K,
                                    int transpose_r, int accumulate, void* stream) {
     if (!part || !out || nsplit <= 0 || n <= 0) return FFM_EINVAL;
     if (transpose_K > 0 && (transpose_r <= 0 || transpose_K * transpose_r != n)) return FFM_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nsplit,
-                       n, out, transpose_K, transpose_r, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+                       nsplit, n, out, transpose_K, transpose_r, accumulate);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

@@ -5,7 +5,15 @@
 
 namespace {
 
-constexpr int MAXC = 8;   // width <= 4 * 64 * MAXC = 2048
+constexpr int MAXC = 4;   // width <= 8 * 64 * MAXC = 2048
+
+// 8 consecutive fp32 parameters
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -16,16 +24,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int nchunk = width >> 2;
+    const int nchunk = width >> 3;
     const T* xr = x + (size_t)row * width;
-    f32x4 v[MAXC];
+    float v[MAXC][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            v[i] = Vec4<T>::load(xr + c * 4);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            Vec8<T>::load(xr + c * 8, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
         }
     }
     const float mean = wave_sum(s) / (float)width;
@@ -35,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int c = lane + 64 * i;
         if (c < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     }
     const float var = wave_sum(q) / (float)width;
@@ -45,12 +54,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
-            f32x4 o;
+            float g[8], b[8], o[8];
+            load8f(gamma + c * 8, g);
+            load8f(beta + c * 8, b);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            Vec4<T>::store(yr + c * 4, o);
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            Vec8<T>::store(yr + c * 8, o);
         }
     }
     if (lane == 0) {
@@ -70,20 +79,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const int nchunk = width >> 2;
+    const int nchunk = width >> 3;
     const float mean = mean_in[row], rstd = rstd_in[row];
     const size_t base = (size_t)row * width;
-    f32x4 gy[MAXC], xh[MAXC];
+    float gy[MAXC][8], xh[MAXC][8], rr[MAXC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const f32x4 d = Vec4<T>::load(dy + base + c * 4);
-            const f32x4 xv = Vec4<T>::load(x + base + c * 4);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            float d[8], xv[8], g[8];
+            Vec8<T>::load(dy + base + c * 8, d);
+            Vec8<T>::load(x + base + c * 8, xv);
+            if (res) Vec8<T>::load(res + base + c * 8, rr[i]);
+            load8f(gamma + c * 8, g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 gy[i][e] = d[e] * g[e];
                 xh[i][e] = (xv[e] - mean) * rstd;
                 s1 += gy[i][e];
@@ -97,15 +108,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            f32x4 o;
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rstd * (gy[i][e] - m1 - xh[i][e] * m2);
-            if (res) {
-                const f32x4 r = Vec4<T>::load(res + base + c * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += r[e];
+            for (int e = 0; e < 8; ++e) {
+                o[e] = rstd * (gy[i][e] - m1 - xh[i][e] * m2);
+                if (res) o[e] += rr[i][e];
             }
-            Vec4<T>::store(out + base + c * 4, o);
+            Vec8<T>::store(out + base + c * 8, o);
         }
     }
 }
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
     const int nchunk = width >> 2;
     const T* src = (l == 0) ? cls : patch + ((size_t)b * (L - 1) + (l - 1)) * width;
     const T* pr = pos + (size_t)l * width;
+    constexpr int MAXC = 8;              // 4-wide chunks here: width <= 4 * 64 * 8
     f32x4 v[MAXC];
     float s = 0.f;
 #pragma unroll
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
     }
 }
 
-inline bool bad_width(int width) { return width <= 0 || (width & 3) || width > 4 * 64 * MAXC; }
+inline bool bad_width(int width) { return width <= 0 || (width & 7) || width > 8 * 64 * MAXC; }
 
 }  // namespace
 

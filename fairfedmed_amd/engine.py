@@ -135,8 +135,14 @@ class _Stack:
         if rank:
             self.u = f(T, rank)
             self.us = f(T, rank)
-            self.part = f(ops.lora_grad_splits(T) * 4 * w * rank)
-            self.ds_part = f(ops.lora_down_blocks(T) * 8 * rank)
+            # per-layer partial sums of the LoRA gradients; all of them are reduced by ONE launch
+            # (ffm_reduce_partials_multi) at the end of the backward pass
+            ns = ops.lora_grad_splits(T)
+            nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype))
+            self.part = [{"fc_A": f(ns * w * rank), "fc_B": f(ns * 4 * w * rank),
+                          "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),
+                          "fc_S": f(nb * 8 * rank), "proj_S": f(nb * 8 * rank)} for _ in range(layers)]
+            self.plans = {}
 
 
 class FairLoRAEngine:
@@ -179,6 +185,13 @@ class FairLoRAEngine:
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.eot_rows = torch.tensor([i * t.context_length + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
                                      device=dev, dtype=torch.int64)
+        # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
+        # logits head, so it runs on its own HIP stream beside it (forward and backward).
+        self.side = torch.cuda.Stream(device=self.device)
+        self.ev_text_fwd = torch.cuda.Event()
+        self.ev_head_bwd = torch.cuda.Event()
+        self.ev_text_bwd = torch.cuda.Event()
+        self.ev_start = torch.cuda.Event()
 
     # ------------------------------------------------------------ weights --
     def _w(self, x: Tensor) -> Tensor:
@@ -281,26 +294,19 @@ class FairLoRAEngine:
             last = (i == 0) and not need_input_grad
             if r:
                 u, us = st.u[:rows], st.us[:rows]
-                nsp, nbl = ops.lora_grad_splits(rows), ops.lora_down_blocks(rows)
-                gv = lambda role: self.params.view(blk.lora[role], "grad")
+                pt = st.part[i]
                 # ---- c_proj:  g = dL/dy [rows, w]
                 ops.lora_down(g, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t2[i][:rows], st.ds_part)
-                ops.reduce_partials(st.ds_part, nbl, G * r, gv("proj_S"))
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t2[i][:rows], pt["proj_S"])
                 ops.gemm_nt(g, blk.w_proj_t, dpre, ts=us, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                             dgelu_aux=pre)
-                ops.lora_grad_partial(g, st.ts2[i][:rows], r, st.part)
-                ops.reduce_partials(st.part, nsp, w * r, gv("proj_B"), transpose_K=w, transpose_r=r)
-                ops.lora_grad_partial(act, us, r, st.part)
-                ops.reduce_partials(st.part, nsp, 4 * w * r, gv("proj_A"))
+                ops.lora_grad_partial(g, st.ts2[i][:rows], r, pt["proj_B"])
+                ops.lora_grad_partial(act, us, r, pt["proj_A"])
                 # ---- c_fc:  dpre = dL/d(pre) [rows, 4w]
                 ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t1[i][:rows], st.ds_part)
-                ops.reduce_partials(st.ds_part, nbl, G * r, gv("fc_S"))
-                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, st.part)
-                ops.reduce_partials(st.part, nsp, 4 * w * r, gv("fc_B"), transpose_K=4 * w, transpose_r=r)
-                ops.lora_grad_partial(h2, us, r, st.part)
-                ops.reduce_partials(st.part, nsp, w * r, gv("fc_A"))
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t1[i][:rows], pt["fc_S"])
+                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
+                ops.lora_grad_partial(h2, us, r, pt["fc_A"])
                 if last:
                     break
                 ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True)
@@ -313,7 +319,25 @@ class FairLoRAEngine:
                               images, st.L, st.heads, st.causal)
             ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows])
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, g)
+        if r:
+            self._reduce_plan(st, rows).run()
         return g
+
+    def _reduce_plan(self, st: _Stack, rows: int):
+        """Descriptor table (built once per row count) that sums every layer's partials into params.grad."""
+        if rows not in st.plans:
+            r, G, w = st.rank, self.cfg.lora.num_groups, st.width
+            nsp = ops.lora_grad_splits(rows)
+            nb_p = ops.lora_down_blocks(rows, w, r, self.dtype)        # u2 = g B_proj^T sweeps K = w
+            nb_f = ops.lora_down_blocks(rows, 4 * w, r, self.dtype)    # u1 = dpre B_fc^T sweeps K = 4w
+            ent = []
+            for blk, pt in zip(st.blocks, st.part):
+                gv = lambda role: self.params.view(blk.lora[role], "grad")
+                ent += [(pt["proj_S"], nb_p, G * r, gv("proj_S"), 0, 0), (pt["fc_S"], nb_f, G * r, gv("fc_S"), 0, 0),
+                        (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),
+                        (pt["fc_B"], nsp, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
+            st.plans[rows] = ops.ReducePlan(ent, self.device)
+        return st.plans[rows]
 
     # --------------------------------------------------------------- text --
     def _text_features(self, with_grad: bool):
@@ -361,7 +385,7 @@ class FairLoRAEngine:
             raise ValueError(f"batch {b} exceeds the engine's max_images={self.max_images}")
         return b, 1
 
-    def _vision_forward(self, image: Tensor, attr: Optional[Tensor], tbar: Tensor) -> Tensor:
+    def _vision_forward(self, image: Tensor, attr: Optional[Tensor], tbar: Tensor, wait=None) -> Tensor:
         cfg, v = self.cfg, self.cfg.vision
         b, S = self._check_batch(image)
         images = b * S
@@ -379,6 +403,8 @@ class FairLoRAEngine:
         ops.layernorm_fwd(out, self.hpost[:rows], self.lnpost[0], self.lnpost[1], self.post_stats[0],
                           self.post_stats[1])
         ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows])
+        if wait is not None:
+            torch.cuda.current_stream(self.device).wait_event(wait)     # text features ready
         ops.head_fwd(self.feat[:rows], tbar, self.logit_scale, self.fbar, self.rnorm, self.logits_img, images, L,
                      cfg.n_cls)
         self._last = (b, S, images, rows, a32)
@@ -397,22 +423,34 @@ class FairLoRAEngine:
         """Forward, CE loss, backward; gradients of every trainable tensor land in params.grad.
         Returns device tensors (no host sync): loss [1], logits [B,n_cls], prob [B,n_cls], finite [1]."""
         cfg, v = self.cfg, self.cfg.vision
-        with torch.enable_grad():
-            tbar, xe = self._text_features(True)
-        tb = tbar.detach().contiguous()
+        main = torch.cuda.current_stream(self.device)
+        self.ev_start.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_start)          # parameters of the previous step are final
+            with torch.enable_grad():
+                tbar, xe = self._text_features(True)
+            tb = tbar.detach().contiguous()
+            tb.record_stream(main)
+            self.ev_text_fwd.record(self.side)
         with torch.no_grad():
-            self._vision_forward(image, attr, tb)
+            self._vision_forward(image, attr, tb, wait=self.ev_text_fwd)
             b, S, images, rows, a32 = self._last
             L = v.tokens
             ops.ce_loss(self.logits_img, label, self.logits, self.prob, self.loss, self.dlogits_img, self.finite, b,
                         S, cfg.n_cls)
             ops.head_bwd(self.feat[:rows], tb, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
                          self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
+            self.ev_head_bwd.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_head_bwd)
+            self._text_backward(tbar, xe, self.dtbar)
+            self.ev_text_bwd.record(self.side)
+        with torch.no_grad():
             ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
             ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
                               self.post_stats[1], None, self.vis.g[:rows])
             self._stack_backward(self.vis, rows, images, a32, L * S, False)
-        self._text_backward(tbar, xe, self.dtbar)
+        main.wait_event(self.ev_text_bwd)
         return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
 
     @torch.no_grad()

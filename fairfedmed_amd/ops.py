@@ -131,8 +131,30 @@ def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, delta: Te
     return dqkv
 
 
-def lora_down_blocks(M: int) -> int:
-    return L.load().ffm_lora_down_blocks(M)
+def lora_down_blocks(M: int, K: int, r: int, dtype: torch.dtype) -> int:
+    return L.load().ffm_lora_down_blocks(M, K, r, L.dtype_code(dtype))
+
+
+class ReducePlan:
+    """Device-resident descriptor table for ffm_reduce_partials_multi."""
+
+    def __init__(self, entries, device):
+        # entries: (part tensor, nsplit, n, out tensor, transpose_K, transpose_r)
+        import ctypes as C
+        arr = (L.ReduceDesc * len(entries))()
+        self.keep = entries
+        self.max_n = 0
+        for i, (part, nsplit, n, out, tK, tr) in enumerate(entries):
+            _dev(part, out)
+            arr[i] = L.ReduceDesc(part.data_ptr(), out.data_ptr(), nsplit, n, tK, tr)
+            self.max_n = max(self.max_n, n)
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.n = len(entries)
+
+    def run(self) -> None:
+        L.check(L.load().ffm_reduce_partials_multi(self.table.data_ptr(), self.n, self.max_n, L.stream_ptr()),
+                "ffm_reduce_partials_multi")
 
 
 def lora_grad_splits(M: int) -> int:

@@ -103,6 +103,7 @@ int ffm_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
  */
 int ffm_patchify(const float* img, void* cols, int B, int H, int W, int patch,
                  const float* mean3, const float* std3, int prenormalised, int dtype, void* stream);
+/* (mean3 / std3 are HOST pointers to 3 floats each; they are passed to the kernel by value) */
 
 /*
  * Token assembly + ln_pre (clip/model.py:432-436): row (b,0) = cls + pos[0],
@@ -139,13 +140,13 @@ int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const 
  * attr: int32 [nsamples] group index, or NULL for the uniform 1/G mix (:462).
  * If t_fwd != NULL also accumulates the dS partials
  *   ds_part[blk][g][j] = sum_{m in blk} pi_{b(m)}[g] * scaling * t_fwd[m][j] * t[m][j]
- * (ds_part has ffm_lora_down_blocks(M) * G * r floats).
+ * (ds_part has ffm_lora_down_blocks(M, K, r, dtype) * G * r floats).
  */
 int ffm_lora_down(const void* x, int ldx, const float* P, int layout_rk, const float* S,
                   const int32_t* attr, int M, int K, int r, int G, int rows_per_sample,
                   float scaling, float lambda_group, float* t, float* ts,
                   const float* t_fwd, float* ds_part, int dtype, void* stream);
-int ffm_lora_down_blocks(int M);
+int ffm_lora_down_blocks(int M, int K, int r, int dtype);   /* blocks (= dS partial rows) the call above uses */
 
 /*
  * Rank-r gradient reduction over the token rows (the dA / dB sums of
@@ -164,6 +165,17 @@ int ffm_lora_grad_splits(int M);
  */
 int ffm_reduce_partials(const float* part, int nsplit, int n, float* out, int transpose_K,
                         int transpose_r, int accumulate, void* stream);
+
+/*
+ * The same reduction for many tensors in ONE launch (all LoRA gradients of a
+ * step): descs_dev is a DEVICE array of ndesc descriptors, max_n = max over n.
+ */
+typedef struct ffm_reduce_desc {
+    const float* part;
+    float* out;
+    int32_t nsplit, n, transpose_K, transpose_r;
+} ffm_reduce_desc;
+int ffm_reduce_partials_multi(const ffm_reduce_desc* descs_dev, int ndesc, int max_n, void* stream);
 
 /*
  * Logits head with OT='None' (trainers/GLP_OT_SVLoRA.py:713-757):

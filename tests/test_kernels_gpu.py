@@ -210,10 +210,11 @@ def test_lora_down(ops, dt, M, K, r, G, rps, rk, use_attr):
     t = torch.empty(M, r, device="cuda")
     ts = torch.empty(M, r, device="cuda")
     t_fwd = rnd(M, r, seed=28)
-    nb = ops.lora_down_blocks(M)
+    nb = ops.lora_down_blocks(M, K, r, dt)
     ds_part = torch.full((nb, G, r), float("nan"), device="cuda")
     ops.lora_down(x, P, rk, S, attr, r, G, rps, 0.25, 0.7, t, ts, t_fwd, ds_part)
-    Pm = P.double().t() if rk else P.double()
+    Pq = P.to(dt).double()                         # the kernel keeps P in the activation dtype in LDS
+    Pm = Pq.t() if rk else Pq
     ref_t = x.double() @ Pm
     pi = mix(attr, G)
     sample = torch.arange(M, device="cuda") // rps
@@ -226,7 +227,7 @@ def test_lora_down(ops, dt, M, K, r, G, rps, rk, use_attr):
 
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
-@pytest.mark.parametrize("M,K,r", [(1000, 768, 8), (197, 3072, 16), (64, 128, 4), (130, 260, 32)])
+@pytest.mark.parametrize("M,K,r", [(1000, 768, 8), (197, 3072, 16), (64, 128, 4), (130, 264, 32)])
 def test_lora_grad(ops, dt, M, K, r):
     x = rnd(M, K, dt=dt, seed=29)
     v = rnd(M, r, seed=30)
@@ -242,6 +243,12 @@ def test_lora_grad(ops, dt, M, K, r):
     check(out_t, ref.t(), 3e-5, "dB-style [r,K]")
     ops.reduce_partials(part, ns, K * r, out, accumulate=True)
     check(out, 2 * ref, 3e-5, "accumulate")
+    # the batched form (one launch for many tensors)
+    o1, o2 = torch.zeros(K, r, device="cuda"), torch.zeros(r, K, device="cuda")
+    plan = ops.ReducePlan([(part, ns, K * r, o1, 0, 0), (part, ns, K * r, o2, K, r)], "cuda")
+    plan.run()
+    check(o1, ref, 3e-5, "multi [K,r]")
+    check(o2, ref.t(), 3e-5, "multi [r,K]")
 
 
 # ------------------------------------------------------------------ head ---
