@@ -1,0 +1,202 @@
+"""Module-level API of the reference's FairLoRA model on top of the HIP engine.
+
+  * ``CustomCLIP`` — same ``state_dict`` keys, shapes and order as the
+    reference's ``CustomCLIP`` after ``apply_lora_to_model``
+    (trainers/GLP_OT_SVLoRA.py:503-613), so that
+    ``federated_main.py`` / ``fed_utils.average_weights*`` see identical
+    dictionaries.  Trainable parameters are views of the engine's flat buffer;
+    ``forward(image, attr)`` runs the HIP engine (GPU only, no fallback).
+  * ``FairLoRALinear`` — the wrapped-linear layer with the reference's
+    constructor/attributes (trainers/GLP_OT_SVLoRA.py:333-482); forward and
+    backward go through the C ABI (ffm_lora_down / ffm_gemm_nt /
+    ffm_lora_grad_partial), the dense dW is never formed.
+  * ``apply_lora_to_model`` — the reference's injection rule for the ViT
+    backbone (every nn.Linear under ``.mlp.``, :516).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import ModelCfg
+from .engine import FairLoRAEngine
+from .synth import lora_s_init, manifest, trainable_keys
+
+Tensor = torch.Tensor
+
+
+class _Node(nn.Module):
+    """Generic container so that parameter paths reproduce the reference's keys."""
+
+
+def _register(root: nn.Module, key: str, tensor: Tensor, trainable: bool, buffer: bool) -> None:
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=trainable))
+
+
+class CustomCLIP(nn.Module):
+    """CLIP image encoder (+FairLoRA) + prompt learner + text encoder + OT='None' head."""
+
+    def __init__(self, cfg: ModelCfg, state_dict: Dict[str, Tensor], dtype=torch.bfloat16, max_images: int = 32,
+                 device: str = "cuda:0"):
+        super().__init__()
+        self.cfg = cfg
+        self.engine = FairLoRAEngine(cfg, state_dict, dtype=dtype, max_images=max_images, device=device)
+        train = set(trainable_keys(cfg))
+        dev = self.engine.device
+        for key, shape in manifest(cfg).items():
+            if key in train:
+                t = self.engine.params.view(key)                   # view of the flat fp32 buffer
+            else:
+                t = state_dict[key].detach().to(dev, torch.float32).reshape(shape).clone()
+            _register(self, key, t, key in train, buffer=key.startswith("prompt_learner.token_"))
+        for key in train:                                          # .grad = view of the flat grad buffer
+            self.get_parameter(key).grad = self.engine.params.view(key, "grad")
+
+    @property
+    def dtype(self):
+        return self.engine.dtype
+
+    def forward(self, image: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        """logits [B, n_cls] (trainers/GLP_OT_SVLoRA.py:677-763, OT='None')."""
+        return self.engine.forward(image, attr)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        res = super().load_state_dict(state_dict, strict=strict, assign=False)
+        train = set(self.engine.params.keys)
+        if any(k not in train for k in state_dict):
+            # frozen tensors may have changed: rebuild their compute-dtype copies (W and W^T)
+            self.engine.load_frozen(self.state_dict())
+        return res
+
+
+# --------------------------------------------------------------------------
+# Stand-alone FairLoRA layer
+# --------------------------------------------------------------------------
+class _FairLoRAFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, W, Wt, bias, A, S, Bm, attr32, rows_per_sample, scaling, lam):
+        M, K = x2d.shape
+        N, r, G = W.shape[0], A.shape[1], S.shape[0]
+        t = torch.empty(M, r, device=x2d.device)
+        ts = torch.empty(M, r, device=x2d.device)
+        ops.lora_down(x2d, A, False, S, attr32, r, G, rows_per_sample, scaling, lam, t, ts)
+        y = torch.empty(M, N, device=x2d.device, dtype=x2d.dtype)
+        ops.gemm_nt(x2d, W, y, bias=bias, ts=ts, lw=Bm)
+        ctx.save_for_backward(x2d, Wt, A, S, Bm, t, ts, attr32 if attr32 is not None else torch.empty(0))
+        ctx.meta = (rows_per_sample, scaling, lam, attr32 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, Wt, A, S, Bm, t, ts, attr32 = ctx.saved_tensors
+        rps, scaling, lam, has_attr = ctx.meta
+        attr32 = attr32 if has_attr else None
+        g = g.contiguous()
+        M, K = x2d.shape
+        N, r, G = g.shape[1], A.shape[1], S.shape[0]
+        dev = g.device
+        u, us = torch.empty(M, r, device=dev), torch.empty(M, r, device=dev)
+        nb = ops.lora_down_blocks(M, N, r, g.dtype)
+        ds_part = torch.empty(nb, G, r, device=dev)
+        ops.lora_down(g, Bm, True, S, attr32, r, G, rps, scaling, lam, u, us, t, ds_part)
+        dx = torch.empty(M, K, device=dev, dtype=g.dtype)
+        ops.gemm_nt(g, Wt, dx, ts=us, lw=A, lw_is_kr=True)
+        ns = ops.lora_grad_splits(M)
+        part = torch.empty(ns * max(K, N) * r, device=dev)
+        dA, dB, dS = torch.empty_like(A), torch.empty_like(Bm), torch.empty_like(S)
+        ops.lora_grad_partial(x2d, us, r, part)
+        ops.reduce_partials(part, ns, K * r, dA)
+        ops.lora_grad_partial(g, ts, r, part)
+        ops.reduce_partials(part, ns, N * r, dB, transpose_K=N, transpose_r=r)
+        ops.reduce_partials(ds_part, nb, G * r, dS)
+        return dx, None, None, None, dA, dS, dB, None, None, None, None
+
+
+class _Emb(nn.Module):
+    """nn.Embedding-shaped holder (the reference stores LoRA matrices as Embedding.weight)."""
+
+    def __init__(self, rows: int, cols: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(rows, cols))
+
+
+class FairLoRALinear(nn.Module):
+    def __init__(self, original_linear: nn.Linear, rank: int = 4, alpha: float = 0.4, global_s: bool = False,
+                 num_attrs: int = 1):
+        super().__init__()
+        assert num_attrs > 0, "Number of attributes must be provided!"
+        if global_s:
+            raise NotImplementedError("GLOBAL_S is False in every FairLoRA script; not built")
+        if original_linear.weight.dim() != 2:
+            raise NotImplementedError("1x1-conv FairLoRA (RN50, BASELINE configs[4]) is not built yet")
+        self.original_linear = original_linear
+        self.rank, self.alpha, self.scaling = rank, alpha, alpha / rank
+        self.global_s, self.num_attrs, self.is_1x1_conv = global_s, num_attrs, False
+        fin, fout = original_linear.in_features, original_linear.out_features
+        self.lora_A, self.lora_S, self.lora_B = _Emb(fin, rank), _Emb(num_attrs, rank), _Emb(rank, fout)
+        dev = original_linear.weight.device
+        self.to(dev)
+        for p in self.original_linear.parameters():
+            p.requires_grad = False
+        self.reset_parameters()
+        self._cache = None
+
+    def reset_parameters(self):
+        """A = 0, B ~ N(0,1), S 'same+cycle' (trainers/GLP_OT_SVLoRA.py:380-423)."""
+        nn.init.zeros_(self.lora_A.weight)
+        self.lora_S.weight.data.copy_(lora_s_init(self.rank, self.num_attrs))
+        nn.init.normal_(self.lora_B.weight)
+
+    def bias(self):
+        return self.original_linear.bias
+
+    def _frozen(self, dtype):
+        w = self.original_linear.weight
+        if self._cache is None or self._cache[0] != (w.data_ptr(), w._version, dtype):
+            self._cache = ((w.data_ptr(), w._version, dtype), ops.cast_from_f32(w.detach().float(), dtype),
+                           ops.transpose_cast(w.detach().float(), dtype))
+        return self._cache[1], self._cache[2]
+
+    def forward(self, x: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        """x: [L, Bn, in] token-major as in the reference (clip/model.py:438); Bn = b*S."""
+        if not x.is_cuda:
+            raise RuntimeError("FairLoRALinear runs on the MI355X HIP kernels only; there is no CPU path")
+        L, Bn, fin = x.shape
+        b = Bn if attr is None else attr.shape[0]
+        S = Bn // b
+        W, Wt = self._frozen(x.dtype)
+        x2d = x.permute(1, 0, 2).reshape(Bn * L, fin).contiguous()          # image-major rows
+        bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
+        a32 = None if attr is None else attr.to(torch.int32).contiguous()
+        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight, self.lora_B.weight, a32,
+                              L * S, self.scaling, 0.7)
+        return y.reshape(Bn, L, -1).permute(1, 0, 2)
+
+
+def apply_lora_to_model(model: nn.Module, unfreeze_image_encoder: bool, rank: int = 4, alpha: float = 0.04,
+                        lora_type: str = "FairLoRA", global_s: bool = False, num_attrs: int = 1) -> None:
+    """ViT rule of the reference (trainers/GLP_OT_SVLoRA.py:512-540): wrap every nn.Linear whose
+    qualified name starts with 'image_encoder.' and contains '.mlp.'."""
+    if lora_type != "FairLoRA":
+        raise NotImplementedError(lora_type)
+    for name, module in dict(model.named_modules()).items():
+        if unfreeze_image_encoder and name.startswith("image_encoder.") and isinstance(module, nn.Linear) \
+                and ".mlp." in name:
+            parent = model
+            parts = name.split(".")
+            for p in parts[:-1]:
+                parent = getattr(parent, p)
+            setattr(parent, parts[-1], FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s,
+                                                      num_attrs=num_attrs))

@@ -1,0 +1,292 @@
+"""``GLP_OT_SVLoRA`` trainer: the reference's trainer API (the methods
+``federated_main.py`` calls) driving the HIP engine.
+
+Reference: trainers/GLP_OT_SVLoRA.py:767-1053 (trainer), Dassl/dassl/engine/
+trainer.py:108-342,345-589,682-741 (TrainerBase / SimpleTrainer / TrainerX).
+
+``cfg`` is any attribute tree with the reference's yacs field names (a yacs
+CfgNode or types.SimpleNamespace); only the fields the hot path reads are used.
+Data loading is out of scope: the trainer takes
+per-client loaders of batch dicts {"img","label","attrs"} through ``data``
+(see ``SyntheticFedData``).
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import OrderedDict
+from types import SimpleNamespace as NS
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import config as C
+from . import synth
+from .metrics import auc_macro_ovr, macro_f1
+from .model import CustomCLIP
+from .registry import TRAINER_REGISTRY
+
+ATTRIBUTE_GROUPS = {   # trainers/GLP_OT_SVLoRA.py:775-790
+    "FairFedMed": {"race": ["Asian", "Black", "White"], "language": ["English", "Spanish", "Others"],
+                   "ethnicity": ["Non-hispanic", "Hispanic"], "gender": ["Male", "Female"]},
+    "FedChexMimic": {"race": ["White", "Asian", "Black"], "gender": ["Male", "Female"], "age": ["0-60", "60+"]},
+}
+
+# EOT positions of the tokenised prompts "X X X X <classname>." (SURVEY.md §8(c) (iii)); the BPE
+# tokenizer itself is init-time only and out of scope.
+KNOWN_EOT = {"NOT Glaucoma": 9, "Glaucoma": 8, "NOT Pleural Effusion": 11, "Pleural Effusion": 10}
+
+
+class _ListDataset:
+    def __init__(self, batches: List[dict], attributes: Sequence[str], num_groups: Dict[str, int]):
+        self.batches, self.attributes, self.num_groups = batches, list(attributes), num_groups
+
+    def __len__(self):
+        return sum(int(b["label"].shape[0]) for b in self.batches)
+
+    def count_by_attribute(self, attr: str) -> List[int]:
+        """Samples per demographic group (Dassl/dassl/data/data_manager.py:435-473)."""
+        col = self.attributes.index(attr)
+        cnt = np.zeros(self.num_groups[attr], dtype=np.int64)
+        for b in self.batches:
+            v, c = np.unique(b["attrs"][:, col].cpu().numpy(), return_counts=True)
+            cnt[v] += c
+        return cnt.tolist()
+
+
+class _Loader:
+    def __init__(self, dataset: _ListDataset):
+        self.dataset = dataset
+
+    def __iter__(self):
+        return iter(self.dataset.batches)
+
+    def __len__(self):
+        return len(self.dataset.batches)
+
+
+class SyntheticFedData:
+    """Per-client train/test loaders of synthetic batches (what the reference's DataManager
+    exposes as fed_{train,test}_loader_x_dict, Dassl/dassl/data/data_manager.py:104-133)."""
+
+    def __init__(self, mcfg: C.ModelCfg, num_clients: int, train_batches: int, test_batches: int, batch_size: int,
+                 attribute: str = "race", classnames=("NOT Glaucoma", "Glaucoma"), seed: int = 1234,
+                 signal: float = 0.25, device: str = "cpu"):
+        ng = {attribute: mcfg.lora.num_groups}
+        mk = lambda s: {k: v.to(device) for k, v in synth.make_batch(mcfg, batch_size, seed=s, signal=signal).items()}
+        self.fed_train_loader_x_dict, self.fed_test_loader_x_dict = {}, {}
+        for c in range(num_clients):
+            tr = [mk(seed + 1000 * c + i) for i in range(train_batches)]
+            te = [mk(seed + 1000 * c + 500 + i) for i in range(test_batches)]
+            self.fed_train_loader_x_dict[c] = _Loader(_ListDataset(tr, [attribute], ng))
+            self.fed_test_loader_x_dict[c] = _Loader(_ListDataset(te, [attribute], ng))
+        self.dataset = NS(classnames=list(classnames))
+        self.num_classes = len(classnames)
+        self.lab2cname = {i: n for i, n in enumerate(classnames)}
+        self.classnames = list(classnames)
+
+
+@TRAINER_REGISTRY.register()
+class GLP_OT_SVLoRA:
+    """FairLoRA trainer.  Construct with ``GLP_OT_SVLoRA(cfg, data=..., state_dict=...)`` or through
+    ``build_trainer(cfg)`` with ``cfg.DATA`` / ``cfg.MODEL.STATE_DICT`` set."""
+
+    def __init__(self, cfg, data=None, state_dict=None):
+        self._models, self._optims, self._scheds = OrderedDict(), OrderedDict(), OrderedDict()
+        self.check_cfg(cfg)
+        if not torch.cuda.is_available():
+            raise RuntimeError("GLP_OT_SVLoRA runs on an MI355X through the HIP engine; no GPU is visible")
+        self.device = torch.device(getattr(cfg, "DEVICE", "cuda:0"))
+        self.cfg = cfg
+        self.start_epoch = self.epoch = 0
+        self.max_epoch = cfg.OPTIM.MAX_EPOCH
+        self.output_dir = getattr(cfg, "OUTPUT_DIR", "")
+        self.dm = data if data is not None else getattr(cfg, "DATA", None)
+        if self.dm is None:
+            raise ValueError("no data: pass data=SyntheticFedData(...) (dataset I/O is out of scope)")
+        self.fed_train_loader_x_dict = self.dm.fed_train_loader_x_dict
+        self.fed_test_loader_x_dict = self.dm.fed_test_loader_x_dict
+        self.num_classes, self.lab2cname, self.classnames = self.dm.num_classes, self.dm.lab2cname, self.dm.classnames
+        self._state_dict = state_dict if state_dict is not None else getattr(cfg.MODEL, "STATE_DICT", None)
+        self.build_model()
+        self.best_result = -np.inf
+        self.time_start = self.total_time_start = time.time()
+
+    # ------------------------------------------------------------ config --
+    def check_cfg(self, cfg):
+        assert cfg.TRAINER.GLP_OT.PREC in ["fp16", "fp32", "amp", "bf16"]
+
+    def retrieval_attributes(self, attr_name: str):
+        try:
+            return ATTRIBUTE_GROUPS[self.cfg.DATASET.NAME][attr_name]
+        except KeyError:
+            raise NotImplementedError(self.cfg.DATASET.NAME)
+
+    def model_cfg(self) -> C.ModelCfg:
+        cfg = self.cfg
+        lora = cfg.TRAINER.GLP_OT_LORA
+        if lora.TYPE != "FairLoRA":
+            raise NotImplementedError(lora.TYPE)
+        disable = getattr(lora, "DISABLE_ATTR", False)
+        G = 1 if disable else len(self.retrieval_attributes(cfg.DATASET.ATTRIBUTE_TYPE))
+        names = list(self.dm.dataset.classnames)
+        try:
+            eot = tuple(KNOWN_EOT[n.replace("_", " ")] for n in names)
+        except KeyError as e:
+            raise NotImplementedError(f"EOT position of class prompt {e} is not pinned (tokenizer is out of scope)")
+        base = C.vit_b16() if cfg.MODEL.BACKBONE.NAME in ("ViT-B/16", "vit_b16") else getattr(cfg.MODEL, "GEOMETRY")
+        return C.ModelCfg(vision=base.vision, text=base.text,
+                          lora=C.LoraCfg(rank=lora.RANK, alpha=lora.ALPHA, num_groups=G),
+                          n_prompts=cfg.TRAINER.GLP_OT.N, n_ctx=cfg.TRAINER.GLP_OT.N_CTX, n_cls=len(names), eot=eot,
+                          pixel_mean=tuple(cfg.INPUT.PIXEL_MEAN), pixel_std=tuple(cfg.INPUT.PIXEL_STD))
+
+    # ------------------------------------------------------------- model --
+    def build_model(self):
+        cfg = self.cfg
+        mcfg = self.model_cfg()
+        prec = cfg.TRAINER.GLP_OT.PREC
+        dtype = torch.float32 if prec in ("fp32", "amp") else torch.bfloat16     # fp16 of the reference -> bf16
+        sd = self._state_dict
+        if sd is None:
+            # pretrained CLIP cannot be downloaded here (trainers/GLP_OT_SVLoRA.py:23-43 needs network)
+            sd = synth.make_state_dict(mcfg, seed=getattr(cfg, "SEED", 1), lora_init="reference")
+        bs = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.TEST.BATCH_SIZE)
+        self.model = CustomCLIP(mcfg, sd, dtype=dtype, max_images=bs, device=str(self.device))
+        self.engine = self.model.engine
+        o = cfg.OPTIM
+        self.optim = NS(lr0=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY,
+                        param_groups=[{"lr": o.LR}])
+        stepsize = o.STEPSIZE[-1] if isinstance(o.STEPSIZE, (list, tuple)) else o.STEPSIZE
+        self.sched = NS(step_size=stepsize if stepsize > 0 else o.MAX_EPOCH, gamma=o.GAMMA, last_epoch=0)
+        self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
+        self.register_model("image_encoder", self.model.image_encoder, self.optim, self.sched)
+
+    def register_model(self, name="model", model=None, optim=None, sched=None):
+        assert name not in self._models, "Found duplicate model names"
+        self._models[name], self._optims[name], self._scheds[name] = model, optim, sched
+
+    def get_model_names(self, names=None):
+        return list(self._models.keys()) if names is None else list(names)
+
+    def set_model_mode(self, mode="train", names=None):
+        for n in self.get_model_names(names):
+            self._models[n].train(mode == "train")
+
+    def get_current_lr(self, names=None):
+        return self.optim.param_groups[0]["lr"]
+
+    def update_lr(self, names=None):
+        """StepLR.step() (Dassl/dassl/optim/lr_scheduler.py:100-115), once per local epoch."""
+        s = self.sched
+        s.last_epoch += 1
+        self.optim.param_groups[0]["lr"] = self.optim.lr0 * s.gamma ** (s.last_epoch // s.step_size)
+
+    # ------------------------------------------------------------- batch --
+    def _parse(self, batch):
+        cfg = self.cfg
+        image = batch["img"].to(self.device, non_blocking=True)
+        label = batch["label"].to(self.device, non_blocking=True)
+        attrs = batch["attrs"].to(self.device, non_blocking=True).t()
+        idx = list(cfg.DATASET.ATTRIBUTES).index(cfg.DATASET.ATTRIBUTE_TYPE)
+        tgt = None if getattr(cfg.TRAINER.GLP_OT_LORA, "DISABLE_ATTR", False) else attrs[idx]
+        return image, label, attrs, tgt
+
+    parse_batch_train = _parse
+    parse_batch_test = _parse
+
+    def model_inference(self, input, attr=None):
+        return self.model(input, attr)
+
+    # -------------------------------------------------------------- step --
+    def forward_backward(self, batch, is_last_client=False):
+        """One SGD step; returns {"loss","acc","auc"} like the reference (:959-970).
+        Set cfg.TRAIN.METRICS_EVERY = N > 1 to pay the host sync for the metrics only every N steps
+        (the reference syncs three times per step; default 1 reproduces that)."""
+        image, label, _, attr = self.parse_batch_train(batch)
+        out = self.engine.forward_backward(image, attr, label)
+        self.engine.sgd_step(self.get_current_lr(), self.optim.momentum, self.optim.weight_decay)
+        every = getattr(getattr(self.cfg, "TRAIN", NS()), "METRICS_EVERY", 1)
+        summary = {}
+        if every <= 1 or (self.batch_idx + 1) % every == 0 or (self.batch_idx + 1) == self.num_batches:
+            if int(out["finite"]) != 1:
+                raise FloatingPointError("Loss is infinite or NaN!")      # Dassl/dassl/engine/trainer.py:260-262
+            logits, prob = out["logits"], out["prob"]
+            lam = getattr(self.cfg.TRAINER, "LAMBDA_FAIRNESS", 0.0)
+            loss = float(out["loss"])
+            if lam != 0.0 and attr is not None:                         # detached fairness term (:930-948)
+                correct = prob[torch.arange(len(label)), label]
+                vals = torch.stack([1 - correct[attr == g].mean() for g in torch.unique(attr)])
+                loss += lam * float(torch.mean(torch.abs(vals - vals.mean())))
+            summary = {"loss": loss, "acc": float((logits.argmax(-1) == label).float().mean() * 100.0),
+                       "auc": auc_macro_ovr(prob.cpu().numpy(), label.cpu().numpy())}
+        if (self.batch_idx + 1) == self.num_batches:
+            self.update_lr()
+        return summary
+
+    def run_epoch(self, idx=-1, global_epoch=-1, is_last_client=False, **_):
+        self.set_model_mode("train")
+        loader = self.fed_train_loader_x_dict[idx]
+        self.num_batches = len(loader)
+        last = {}
+        for self.batch_idx, batch in enumerate(loader):
+            s = self.forward_backward(batch, is_last_client=is_last_client)
+            if s:
+                last = s
+        return last
+
+    def train(self, idx=-1, global_epoch=0, is_fed=False, is_last_client=False, **_):
+        self.time_start = time.time()
+        for self.epoch in range(self.start_epoch, self.max_epoch):
+            self.run_epoch(idx, global_epoch, is_last_client=is_last_client)
+            self.after_epoch(idx, global_epoch)
+        self.after_train(idx, global_epoch, is_fed)
+
+    def after_epoch(self, idx=-1, global_epoch=-1):
+        freq = getattr(getattr(self.cfg, "TRAIN", NS()), "CHECKPOINT_FREQ", 0)
+        last_epoch = (self.epoch + 1) == self.max_epoch
+        if self.output_dir and ((freq > 0 and (self.epoch + 1) % freq == 0) or last_epoch):
+            name = f"epoch{global_epoch}.pth" if idx == -1 else f"epoch{global_epoch}_client{idx}.pth"
+            self.save_model_with_grad(os.path.join(self.output_dir, name))
+
+    def after_train(self, idx=-1, epoch=0, is_fed=False):
+        if not getattr(self.cfg.TEST, "NO_TEST", False):
+            self.test(idx=idx, current_epoch=epoch)
+
+    def save_model_with_grad(self, filename):
+        """Trainable parameters + all buffers (Dassl/dassl/engine/trainer.py:177-185)."""
+        sd = {n: p.detach().cpu() for n, p in self.model.named_parameters() if p.requires_grad}
+        sd.update({n: b.detach().cpu() for n, b in self.model.named_buffers()})
+        os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
+        torch.save(sd, filename)
+
+    def load_model(self, directory, epoch=None):
+        if not directory:
+            print("Note that load_model() is skipped as no pretrained model is given")
+            return
+        raise FileNotFoundError(f'Model not found at "{directory}"')
+
+    def fed_before_train(self, is_global=False):
+        self.start_epoch = 0
+        self.total_time_start = time.time()
+
+    def fed_after_train(self):
+        print(f"Total time Elapsed: {round(time.time() - self.total_time_start)}s")
+
+    # -------------------------------------------------------------- test --
+    @torch.no_grad()
+    def test(self, split=None, is_global=False, current_epoch=0, idx=-1, global_test=False):
+        """[acc, err, macro_f1, auc] over the client's test loader (SimpleTrainer.test,
+        Dassl/dassl/engine/trainer.py:523-569; federated_main.py:685-690 indexes [0..3])."""
+        self.set_model_mode("eval")
+        probs, labels = [], []
+        for batch in self.fed_test_loader_x_dict[idx]:
+            image, label, _, attr = self.parse_batch_test(batch)
+            logits = self.model_inference(image, attr)
+            probs.append(torch.softmax(logits, -1))
+            labels.append(label)
+        prob = torch.cat(probs).cpu().numpy()
+        y = torch.cat(labels).cpu().numpy()
+        pred = prob.argmax(-1)
+        acc = 100.0 * float((pred == y).mean())
+        return [acc, 100.0 - acc, 100.0 * macro_f1(pred, y, prob.shape[1]), auc_macro_ovr(prob, y)]

@@ -1,0 +1,90 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+include/ffm_hip.h declares, the registry keeps the reference's error behaviour,
+host metrics match the reference's golden values, the product never routes
+through the oracle, and the GPU-only entry points fail loudly without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fairfedmed_amd import _lib, config as C, metrics, synth
+from fairfedmed_amd.registry import Registry, TRAINER_REGISTRY, build_trainer, check_availability
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ffm_hip.h")).read()
+    declared = set(re.findall(r"\bint\s+(ffm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in ffm_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert _lib.load().ffm_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load()
+    args = _lib.GemmArgs()                          # null pointers
+    assert lib.ffm_gemm_nt(ctypes.byref(args), _lib.BF16, None) == -1
+    assert lib.ffm_layernorm_fwd(None, None, None, None, None, None, 4, 768, _lib.BF16, None) == -1
+    assert lib.ffm_lora_grad_splits(6304) > 0 and lib.ffm_lora_down_blocks(6304, 768, 8, _lib.BF16) > 0
+
+
+def test_registry_semantics():
+    r = Registry("T")
+
+    @r.register()
+    class A:
+        pass
+    assert r.get("A") is A and r.registered_names() == ["A"]
+    with pytest.raises(KeyError):
+        r.register(A)
+    with pytest.raises(KeyError):
+        r.get("B")
+    with pytest.raises(ValueError, match="GLP_OT_SVLoRA"):
+        check_availability("GLP_OT_SVLora", ["GLP_OT_SVLoRA"])
+    import fairfedmed_amd.trainer  # noqa: F401  (registers the trainer)
+    assert "GLP_OT_SVLoRA" in TRAINER_REGISTRY.registered_names()
+
+
+def test_metrics_match_reference_goldens(golden_dir):
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    for name in ("n32", "n200"):
+        got = metrics.auc_macro_ovr(unit[f"auc.{name}.prob"], unit[f"auc.{name}.y"])
+        assert abs(got - meta["auc"][name]) < 1e-12
+    assert metrics.auc_macro_ovr(np.array([[.4, .6], [.3, .7]]), np.array([1, 1])) == 1.0
+    assert abs(metrics.macro_f1(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0]), 2) - (0.8 + 2 / 3) / 2) < 1e-12
+
+
+def test_manifest_counts_match_reference(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    m = synth.manifest(C.vit_b16(rank=8))
+    keys = synth.trainable_keys(C.vit_b16(rank=8))
+    assert len(keys) == meta["vitb_r8.trainable_tensors"] == 73
+    assert sum(int(np.prod(m[k])) for k in keys) == meta["vitb_r8.trainable_elems"] == 741952
+    assert sum(int(np.prod(s)) for k, s in m.items() if "token_" not in k) == meta["vitb_r8.total_params"]
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "fairfedmed_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    from fairfedmed_amd.engine import FairLoRAEngine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FairLoRAEngine(C.vit_tiny(), {}, max_images=1)
+    from fairfedmed_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(torch.zeros(4, 128), torch.zeros(4, 128), torch.ones(128), torch.zeros(128))

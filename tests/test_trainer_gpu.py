@@ -1,0 +1,140 @@
+"""Trainer-level boundary on the GPU: state_dict contract, the FairLoRALinear
+layer against the reference's golden layer vectors, and the GLP_OT_SVLoRA
+trainer API that federated_main.py drives."""
+import json
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from fairfedmed_amd import config as C
+from fairfedmed_amd import synth
+from tests.golden.make_golden import LAYER_CASES, layer_inputs, sub
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def test_state_dict_keys_shapes_and_sharing():
+    from fairfedmed_amd.model import CustomCLIP
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    model = CustomCLIP(mcfg, sd, dtype=torch.float32, max_images=4)
+    got = model.state_dict()
+    man = synth.manifest(mcfg)
+    assert list(got.keys()) == list(man.keys())                 # same keys, same order as the reference
+    for k, shp in man.items():
+        assert tuple(got[k].shape) == tuple(shp) and got[k].dtype == torch.float32, k
+        assert torch.equal(got[k].cpu(), sd[k]), k
+    train = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert train == set(synth.trainable_keys(mcfg))
+    # trainable parameters alias the engine's flat buffer; load_state_dict(strict=False) updates it in place
+    k = "image_encoder.transformer.resblocks.0.mlp.c_fc.lora_S.weight"
+    new = {k: torch.full_like(sd[k], 0.25), "prompt_learner.ctx": torch.zeros_like(sd["prompt_learner.ctx"])}
+    model.load_state_dict(new, strict=False)
+    assert float(model.engine.params.view(k).mean()) == 0.25
+    assert float(model.engine.params.view("prompt_learner.ctx").abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [c for c in LAYER_CASES if c[8] is None], ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fairlora_linear_vs_reference_golden(golden_dir, case, dtype):
+    """FairLoRALinear.forward/backward (HIP) vs the imported reference layer."""
+    from fairfedmed_amd.model import FairLoRALinear
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    name, L, Bn, fin, fout, r, G, S, hw = case
+    x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+    lin = torch.nn.Linear(fin, fout)
+    lin.weight.data, lin.bias.data = W.clone(), bias.clone()
+    layer = FairLoRALinear(lin.cuda(), rank=r, alpha=2.0, num_attrs=G)
+    layer.lora_A.weight.data.copy_(A)
+    layer.lora_S.weight.data.copy_(Sm)
+    layer.lora_B.weight.data.copy_(Bm)
+    xin = x.cuda().to(dtype).requires_grad_(True)
+    y = layer(xin, attr.cuda())
+    y.backward(g.cuda().to(dtype))
+    f32 = dtype == torch.float32
+    t1, t2 = (3e-5, 1e-4) if f32 else (1.5e-2, 4e-2)
+    pick = lambda t: t.float().cpu().numpy() if t.numel() <= 65536 else sub(t.float().cpu())
+    assert rel(pick(y.detach()), unit[f"layer.{name}.y"]) < t1
+    assert rel(pick(xin.grad), unit[f"layer.{name}.dx"]) < t1
+    assert rel(layer.lora_A.weight.grad, unit[f"layer.{name}.dA"]) < t2
+    assert rel(layer.lora_S.weight.grad, unit[f"layer.{name}.dS"]) < t2
+    assert rel(layer.lora_B.weight.grad, unit[f"layer.{name}.dB"]) < t2
+
+
+def make_cfg(prec="fp32", rank=4, bs=8):
+    return NS(
+        SEED=1, OUTPUT_DIR="", VERBOSE=False,
+        INPUT=NS(PIXEL_MEAN=list(C.CLIP_PIXEL_MEAN), PIXEL_STD=list(C.CLIP_PIXEL_STD), SIZE=(64, 64)),
+        DATASET=NS(NAME="FairFedMed", ATTRIBUTES=["race"], ATTRIBUTE_TYPE="race"),
+        MODEL=NS(BACKBONE=NS(NAME="tiny"), GEOMETRY=C.vit_tiny(), STATE_DICT=None),
+        TRAINER=NS(NAME="GLP_OT_SVLoRA", LAMBDA_FAIRNESS=0.0,
+                   GLP_OT=NS(N=2, N_CTX=4, PREC=prec, OT="None"),
+                   GLP_OT_LORA=NS(RANK=rank, ALPHA=2.0, TYPE="FairLoRA", GLOBAL_S=False, DISABLE_ATTR=False,
+                                  UNFREEZE_IMAGE_ENCODER=True)),
+        OPTIM=NS(NAME="sgd", LR=1e-3, MOMENTUM=0.9, WEIGHT_DECAY=5e-4, LR_SCHEDULER="single_step", STEPSIZE=2,
+                 GAMMA=0.1, MAX_EPOCH=1),
+        DATALOADER=NS(TRAIN_X=NS(BATCH_SIZE=bs)), TEST=NS(BATCH_SIZE=bs, NO_TEST=True),
+        TRAIN=NS(METRICS_EVERY=1, CHECKPOINT_FREQ=0),
+    )
+
+
+def test_trainer_reproduces_reference_trajectory(golden_dir):
+    """forward_backward through the registry-built trainer == the reference's forward_backward trajectory."""
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData, _ListDataset, _Loader
+    import fairfedmed_amd.trainer  # noqa: F401
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    mcfg = C.vit_tiny(rank=4)
+    cfg = make_cfg()
+    data = SyntheticFedData(mcfg, 1, 1, 1, 8)
+    batch = synth.make_batch(mcfg, 8, seed=1234)                      # the golden batch
+    data.fed_train_loader_x_dict[0] = _Loader(_ListDataset([batch], ["race"], {"race": 3}))
+    cfg.DATA = data
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    tr = build_trainer(cfg)
+    assert type(tr).__name__ == "GLP_OT_SVLoRA"
+    tr.num_batches = 10 ** 9
+    for i, ref in enumerate(meta["tiny_r4.traj"]):
+        tr.batch_idx = i
+        s = tr.forward_backward(batch)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"])
+        assert abs(s["acc"] - ref["acc"]) < 1e-3 and abs(s["auc"] - ref["auc"]) < 1e-9
+    assert tr.fed_train_loader_x_dict[0].dataset.count_by_attribute("race") == \
+        np.bincount(batch["attrs"][:, 0].numpy(), minlength=3).tolist()
+
+
+def test_trainer_round_api_and_lr_schedule(tmp_path):
+    """train()/test()/state_dict round trip as federated_main.py uses them; StepLR once per local epoch."""
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4)
+    cfg = make_cfg(prec="bf16")
+    cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.TEST.NO_TEST = False
+    data = SyntheticFedData(mcfg, num_clients=2, train_batches=3, test_batches=2, batch_size=8, signal=0.4)
+    tr = GLP_OT_SVLoRA(cfg, data=data)
+    tr.fed_before_train()
+    global_weights = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    assert len(tr.fed_train_loader_x_dict[0].dataset) == 24
+    lrs = []
+    for rnd in range(3):
+        for idx in (0, 1):
+            tr.model.load_state_dict(global_weights, strict=False)
+            tr.train(idx=idx, global_epoch=rnd, is_fed=True)
+            lrs.append(tr.get_current_lr())
+    assert lrs[0] == 1e-3 and abs(lrs[1] - 1e-4) < 1e-12 and abs(lrs[-1] - 1e-6) < 1e-15   # gamma .1 every 2 epochs
+    res = tr.test(idx=0, current_epoch=0)
+    assert len(res) == 4 and 0 <= res[3] <= 1 and abs(res[0] + res[1] - 100) < 1e-9
+    assert os.path.exists(os.path.join(str(tmp_path), "epoch2_client1.pth"))
+    saved = torch.load(os.path.join(str(tmp_path), "epoch2_client1.pth"))
+    assert "prompt_learner.ctx" in saved and "prompt_learner.token_prefix" in saved
+    assert not any("original_linear" in k for k in saved)
+    tr.fed_after_train()
