@@ -134,7 +134,12 @@ class _Stack:
         self.delta = f(max_images * heads * tokens)
         if rank:
             self.u = f(T, rank)
-            self.us = f(T, rank)
+            # The LoRA-gradient reductions trail the dX chain on a side stream, so everything they
+            # read is kept per layer: gradient of the block output, dL/d(pre), and both us tensors.
+            self.g_l = [e(T, w) for _ in range(layers)]
+            self.dpre_l = [e(T, 4 * w) for _ in range(layers)]
+            self.us2 = [f(T, rank) for _ in range(layers)]
+            self.us1 = [f(T, rank) for _ in range(layers)]
             # per-layer partial sums of the LoRA gradients; all of them are reduced by ONE launch
             # (ffm_reduce_partials_multi) at the end of the backward pass
             ns = ops.lora_grad_splits(T)
@@ -188,6 +193,9 @@ class FairLoRAEngine:
         # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
         # logits head, so it runs on its own HIP stream beside it (forward and backward).
         self.side = torch.cuda.Stream(device=self.device)
+        self.grad_stream = torch.cuda.Stream(device=self.device)
+        self.ev_layer = [torch.cuda.Event() for _ in range(v.layers)]
+        self.ev_grads = torch.cuda.Event()
         self.ev_text_fwd = torch.cuda.Event()
         self.ev_head_bwd = torch.cuda.Event()
         self.ev_text_bwd = torch.cuda.Event()
@@ -286,41 +294,53 @@ class FairLoRAEngine:
         lo = self.cfg.lora
         r, G, w = st.rank, lo.num_groups, st.width
         g, g1 = st.g[:rows], st.g1[:rows]
+        main = torch.cuda.current_stream(self.device)
         for i in range(st.layers - 1, -1, -1):
             blk = st.blocks[i]
             x, xm = st.x[i][:rows], st.xm[i][:rows]
             pre, act, h2 = st.pre[i][:rows], st.act[i][:rows], st.h2[i][:rows]
-            dpre = st.dpre[:rows]
             last = (i == 0) and not need_input_grad
             if r:
-                u, us = st.u[:rows], st.us[:rows]
+                # gradient w.r.t. this block's output lives in its own buffer (read later by the side stream)
+                gi, dpre = st.g_l[i][:rows], st.dpre_l[i][:rows]
+                if i == st.layers - 1:
+                    gi.copy_(g)
+                u, us2, us1 = st.u[:rows], st.us2[i][:rows], st.us1[i][:rows]
                 pt = st.part[i]
-                # ---- c_proj:  g = dL/dy [rows, w]
-                ops.lora_down(g, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t2[i][:rows], pt["proj_S"])
-                ops.gemm_nt(g, blk.w_proj_t, dpre, ts=us, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
+                # ---- critical path: u = g B^T, dX with the LoRA dx term in the epilogue
+                ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
+                ops.gemm_nt(gi, blk.w_proj_t, dpre, ts=us2, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                             dgelu_aux=pre)
-                ops.lora_grad_partial(g, st.ts2[i][:rows], r, pt["proj_B"])
-                ops.lora_grad_partial(act, us, r, pt["proj_A"])
-                # ---- c_fc:  dpre = dL/d(pre) [rows, 4w]
                 ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us, st.t1[i][:rows], pt["fc_S"])
-                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
-                ops.lora_grad_partial(h2, us, r, pt["fc_A"])
+                              rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
+                # ---- off the critical path: the four rank-r gradient reductions of this block
+                self.ev_layer[i].record(main)
+                with torch.cuda.stream(self.grad_stream):
+                    self.grad_stream.wait_event(self.ev_layer[i])
+                    ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
+                    ops.lora_grad_partial(act, us2, r, pt["proj_A"])
+                    ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
+                    ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
                 if last:
                     break
-                ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True)
+                ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us1, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True)
+                gout = st.g_l[i - 1][:rows] if i > 0 else g
             else:
-                ops.gemm_nt(g, blk.w_proj_t, dpre, dgelu_aux=pre)
+                gi, dpre, gout = g, st.dpre[:rows], g
+                ops.gemm_nt(gi, blk.w_proj_t, dpre, dgelu_aux=pre)
                 ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows])
-            ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], g, g1)
+            ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], gi, g1)
             ops.gemm_nt(g1, blk.w_out_t, st.do[:rows])
             ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
                               images, st.L, st.heads, st.causal)
             ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows])
-            ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, g)
+            ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
         if r:
-            self._reduce_plan(st, rows).run()
+            with torch.cuda.stream(self.grad_stream):
+                self._reduce_plan(st, rows).run()
+                self.ev_grads.record(self.grad_stream)
+            main.wait_event(self.ev_grads)
         return g
 
     def _reduce_plan(self, st: _Stack, rows: int):
