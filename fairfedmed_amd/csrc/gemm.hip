@@ -15,12 +15,21 @@ namespace {
 
 constexpr int BM = 128, BN = 128, KT_BYTES = 128;
 constexpr int TILE_BYTES = BM * KT_BYTES;            // 16 KiB per operand per buffer
-constexpr int MAIN_LDS = 4 * TILE_BYTES;             // A0 B0 A1 B1
+constexpr int RK_ROWS = 16;                          // rows of the packed rank operand (rank padded to 16)
+constexpr int RK_BYTES = RK_ROWS * KT_BYTES;         // 2 KiB per buffer
 constexpr int CS_LD = 132;                           // padded f32 row of the C stage
 constexpr int CS_ROWS = 64;                          // epilogue runs in two 64-row halves
 
-__host__ __device__ constexpr int epi_lds_bytes(int r) {
-    return CS_ROWS * CS_LD * 4 + r * BN * 4 + CS_ROWS * r * 4;
+// FFM_EPI_RANKOP: the rank-r down projection of FairLoRA, t = A_rows . rk^T (x A in the forward pass,
+// g B^T in the backward pass), is computed INSIDE this GEMM: the packed operand rk [16, K] rides through
+// the same LDS ring as 16 extra B rows and costs 2 extra MFMAs per wave per k-step (+6 %), instead of a
+// separate kernel that re-reads the whole activation matrix from HBM.  ts = scaling * t * s_b is formed
+// in the epilogue and used by the rank-r update of the same tile; the blocks of the first column of tiles
+// also store t / ts and the dS partial sums.
+template <bool RK> __host__ __device__ constexpr int buf_bytes() { return 2 * TILE_BYTES + (RK ? RK_BYTES : 0); }
+
+__host__ __device__ constexpr int epi_lds_bytes(int r, bool rk) {
+    return CS_ROWS * CS_LD * 4 + r * BN * 4 + CS_ROWS * r * 4 + (rk ? BM * RK_ROWS * 4 + 256 * 4 + BM * 4 : 0);
 }
 
 template <typename T>
@@ -44,9 +53,10 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
     }
 }
 
-template <typename T>
+template <typename T, bool RK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     typedef typename Mma16<T>::frag_t frag_t;
+    constexpr int BUF = buf_bytes<RK>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,20 +79,36 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    f32x4 tacc[2];
+    tacc[0] = tacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the packed rank operand: 16 rows x 128 B per K-tile = 2 wave-instructions (waves 0 and 1)
+    auto stage_rank = [&](int kbyte0, char* dst) {
+        if (RK && wave < 2) {
+            const int rsub = lane >> 3, slot = lane & 7;
+            const int row = wave * 8 + rsub;
+            const char* src = reinterpret_cast<const char*>(p.rk) + (size_t)row * (size_t)p.K * sizeof(T) + kbyte0 +
+                              ((slot ^ rsub) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
+        }
+    };
+
     // prologue: tile 0 -> buffer 0
     stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
     stage_tile<T>(B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_rank(0, smem + 2 * TILE_BYTES);
     __syncthreads();
 
     const int frow = lane & 15, fgrp = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        char* As = smem + cur * 2 * TILE_BYTES;
+        char* As = smem + cur * BUF;
         char* Bs = As + TILE_BYTES;
         if (kt + 1 < nk) {
-            char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            char* An = smem + (cur ^ 1) * BUF;
             stage_tile<T>(A, p.lda, m0, p.M, (kt + 1) * KT_BYTES, An, wave, lane);
             stage_tile<T>(B, p.ldb, n0, p.N, (kt + 1) * KT_BYTES, An + TILE_BYTES, wave, lane);
+            stage_rank((kt + 1) * KT_BYTES, An + 2 * TILE_BYTES);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -99,6 +125,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], af[i], bf[j]);
+            if constexpr (RK) {
+                // t tile: wave (wm, wn) owns row fragments 2*wn, 2*wn+1 of its 64 rows
+                const frag_t kf = *reinterpret_cast<const frag_t*>(As + 2 * TILE_BYTES + frow * KT_BYTES +
+                                                                   ((chunk ^ (frow & 7)) << 4));
+                if (wn == 0) { Mma16<T>::mma(tacc[0], af[0], kf); Mma16<T>::mma(tacc[1], af[1], kf); }
+                else         { Mma16<T>::mma(tacc[0], af[2], kf); Mma16<T>::mma(tacc[1], af[3], kf); }
+            }
         }
         __syncthreads();   // next tile landed (compiler drains vmcnt before the barrier); cur is free
     }
@@ -109,7 +142,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     const int r = has_lora ? p.rank : 0;
     float* Ls = Cs + CS_ROWS * CS_LD;                 // LoRA matrix tile [r][BN]
     float* Ts = Ls + r * BN;                          // ts rows [64][r]
+    float* Tt = Ts + CS_ROWS * r;                     // RANKOP: t tile [128][16]
     T* C = reinterpret_cast<T*>(p.c);
+    if constexpr (RK) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Tt[(wm * 64 + (2 * wn + ii) * 16 + fgrp * 4 + e) * RK_ROWS + frow] = tacc[ii][e];
+    }
 
     if (has_lora) {
         // LoRA matrix tile: Ls[j][n] for n0..n0+127
@@ -119,6 +160,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
             if (n0 + n < p.N)
                 v = (p.flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
             Ls[idx] = v;
+        }
+    }
+
+    float* Sg = Tt + BM * RK_ROWS;                    // RANKOP: lora_S [G][r]
+    int* Ga = reinterpret_cast<int*>(Sg + 256);       // RANKOP: group index of each of the 128 rows (-1: uniform)
+    auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
+        const int a = Ga[row];
+        return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
+    };
+    if constexpr (RK) {
+        if (tid < p.G * r) Sg[tid] = p.S[tid];
+        if (tid < BM) {
+            const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+            Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
+        }
+        const bool do_ds = (tn == 0) && p.t_fwd && p.ds_part;
+        if (do_ds) {
+            // Wv[row][j] = scaling * t_fwd * t, staged in the (still free) C-stage region
+            __syncthreads();                          // Tt complete
+            for (int idx = tid; idx < BM * r; idx += 256) {
+                const int row = idx / r, j = idx % r;
+                const int gm = m0 + row;
+                Cs[idx] = gm < p.M ? p.scaling * p.t_fwd[(size_t)gm * r + j] * Tt[row * RK_ROWS + j] : 0.f;
+            }
+        }
+        __syncthreads();                              // Tt, Sg, Ga (and Wv) visible
+        if (do_ds) {
+            if (tid < p.G * r) {
+                // dS partial of this row tile: sum_rows pi_b[g] * scaling * t_fwd * t
+                const int g = tid / r, j = tid % r;
+                float sacc = 0.f;
+                for (int row = 0; row < BM; ++row) sacc += mixw(row, g) * Cs[row * r + j];
+                p.ds_part[((size_t)tm * p.G + g) * r + j] = sacc;
+            }
+            __syncthreads();                          // Cs is reused by the halves below
         }
     }
 
@@ -139,7 +215,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
             for (int idx = tid; idx < CS_ROWS * r; idx += 256) {
                 const int row = idx / r, j = idx % r;
                 const int gm = m0 + half * 64 + row;
-                Ts[idx] = gm < p.M ? p.ts[(size_t)gm * r + j] : 0.f;
+                if constexpr (RK) {
+                    float tsv = 0.f;
+                    if (gm < p.M) {
+                        const float tv = Tt[(half * 64 + row) * RK_ROWS + j];
+                        float sb = 0.f;
+                        for (int g = 0; g < p.G; ++g) sb += mixw(half * 64 + row, g) * Sg[g * r + j];
+                        tsv = p.scaling * tv * sb;
+                        if (tn == 0) {
+                            if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
+                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv;
+                        }
+                    }
+                    Ts[idx] = tsv;
+                } else {
+                    Ts[idx] = gm < p.M ? p.ts[(size_t)gm * r + j] : 0.f;
+                }
             }
         }
         __syncthreads();
@@ -214,15 +305,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     }
 }
 
-template <typename T>
+template <typename T, bool RK>
 int launch_gemm(const ffm_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int r = (a.flags & FFM_EPI_LORA) ? a.rank : 0;
-    int lds = epi_lds_bytes(r);
-    if (lds < MAIN_LDS) lds = MAIN_LDS;
-    hipLaunchKernelGGL((gemm_nt_kernel<T>), dim3(tiles), dim3(256), lds, s, a);
+    int lds = epi_lds_bytes(r, RK);
+    if (lds < 2 * buf_bytes<RK>()) lds = 2 * buf_bytes<RK>();
+    if (lds > 65536) {
+        static bool done = false;                     // one per instantiation
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK>), dim3(tiles), dim3(256), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
+}
+
+// packed rank operands: dst[j][k] (dtype, 16 rows, rows >= r zero) from lora_A [K, r] or lora_B [r, K]
+template <typename T>
+__global__ __launch_bounds__(256) void lora_pack_kernel(const ffm_pack_desc* __restrict__ descs) {
+    const ffm_pack_desc d = descs[blockIdx.y];
+    const int total = RK_ROWS * d.K;
+    T* dst = reinterpret_cast<T*>(d.dst);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i / d.K, k = i % d.K;
+        float v = 0.f;
+        if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
+        dst[i] = Elem<T>::from_f(v);
+    }
 }
 
 }  // namespace
@@ -237,11 +351,33 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if (((size_t)a.lda * es) % 16 || ((size_t)a.ldb * es) % 16 || ((size_t)a.ldc * es) % 16) return FFM_EINVAL;
     if (((uintptr_t)a.a | (uintptr_t)a.b | (uintptr_t)a.c) & 15) return FFM_EINVAL;
     if (a.lda < a.K || a.ldb < a.K || a.ldc < a.N) return FFM_EINVAL;
-    if ((a.flags & FFM_EPI_LORA) && (a.rank <= 0 || a.rank > FFM_MAX_RANK || !a.ts || !a.lw)) return FFM_EINVAL;
+    const bool rk = (a.flags & FFM_EPI_RANKOP) != 0;
+    if ((a.flags & FFM_EPI_LORA) && (a.rank <= 0 || a.rank > FFM_MAX_RANK || !a.lw || (!rk && !a.ts))) return FFM_EINVAL;
+    if (rk) {
+        if (!(a.flags & FFM_EPI_LORA) || a.rank > RK_ROWS || !a.rk || ((uintptr_t)a.rk & 15) || !a.S) return FFM_EINVAL;
+        if (a.G <= 0 || a.G > FFM_MAX_GROUPS || a.rows_per_sample <= 0 || a.G * a.rank > 256) return FFM_EINVAL;
+        if ((a.t_fwd == nullptr) != (a.ds_part == nullptr)) return FFM_EINVAL;
+    }
     if ((a.flags & FFM_EPI_BIAS) && !a.bias) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_RESIDUAL) && (!a.res || ((uintptr_t)a.res & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == FFM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
+    if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true>(a, s) : launch_gemm<float, true>(a, s);
+    return dtype == FFM_BF16 ? launch_gemm<bf16_t, false>(a, s) : launch_gemm<float, false>(a, s);
+}
+
+extern "C" int ffm_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
+
+extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream) {
+    if (!descs_dev || ndesc <= 0 || max_K <= 0) return FFM_EINVAL;
+    dim3 grid((RK_ROWS * max_K + 255) / 256, ndesc);
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((lora_pack_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, descs_dev);
+    else if (dtype == FFM_F32)
+        hipLaunchKernelGGL((lora_pack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, descs_dev);
+    else
+        return FFM_EINVAL;
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
 }

@@ -143,7 +143,8 @@ class _Stack:
             # per-layer partial sums of the LoRA gradients; all of them are reduced by ONE launch
             # (ffm_reduce_partials_multi) at the end of the backward pass
             ns = ops.lora_grad_splits(T)
-            nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype))
+            nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype),
+                     ops.gemm_tiles_m(T))
             self.part = [{"fc_A": f(ns * w * rank), "fc_B": f(ns * 4 * w * rank),
                           "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),
                           "fc_S": f(nb * 8 * rank), "proj_S": f(nb * 8 * rank)} for _ in range(layers)]
@@ -171,6 +172,21 @@ class FairLoRAEngine:
         self.txt = _Stack(t.width, t.heads, t.layers, t.context_length, self.n_text, True, 0, dtype, self.device)
         self.load_frozen(state_dict)
         dev, f32 = self.device, torch.float32
+        # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
+        self.fused_rank = 0 < cfg.lora.rank <= 16
+        if self.fused_rank:
+            w = v.width
+            ent = []
+            self.rk = []
+            for blk in self.vis.blocks:
+                pk = {"fc_A": torch.zeros(16, w, device=dev, dtype=dtype),
+                      "proj_A": torch.zeros(16, 4 * w, device=dev, dtype=dtype),
+                      "fc_B": torch.zeros(16, 4 * w, device=dev, dtype=dtype),
+                      "proj_B": torch.zeros(16, w, device=dev, dtype=dtype)}
+                self.rk.append(pk)
+                for role, buf in pk.items():
+                    ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf))
+            self.pack_plan = ops.PackPlan(ent, dtype, dev)
         P = v.grid * v.grid
         self.cols = torch.zeros(max_images * P, 3 * v.patch * v.patch, device=dev, dtype=dtype)
         self.patch_out = torch.zeros(max_images * P, v.width, device=dev, dtype=dtype)
@@ -273,7 +289,15 @@ class FairLoRAEngine:
             ops.attention_fwd(qkv, o, st.lse[i], images, st.L, st.heads, st.causal)
             ops.gemm_nt(o, blk.w_out, xm, bias=blk.b_out, res=x)
             ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
-            if r:
+            if r and self.fused_rank:
+                ro = ops.RankOp(self.rk[i]["fc_A"], self._lora_view(blk, "fc_S"), attr, rows_per_sample, lo.scaling,
+                                lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i])
+                ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro)
+                ro = ops.RankOp(self.rk[i]["proj_A"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
+                                lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i])
+                ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
+                            res=xm, rankop=ro)
+            elif r:
                 ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._lora_view(blk, "fc_S"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
                 ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, ts=st.ts1[i], lw=self._lora_view(blk, "fc_B"),
@@ -307,13 +331,27 @@ class FairLoRAEngine:
                     gi.copy_(g)
                 u, us2, us1 = st.u[:rows], st.us2[i][:rows], st.us1[i][:rows]
                 pt = st.part[i]
-                # ---- critical path: u = g B^T, dX with the LoRA dx term in the epilogue
-                ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
-                ops.gemm_nt(gi, blk.w_proj_t, dpre, ts=us2, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
-                            dgelu_aux=pre)
-                ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
-                              rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
+                # ---- critical path: u = g B^T and dX (+ LoRA dx term), dS partials
+                fused = self.fused_rank
+                if fused:
+                    ro = ops.RankOp(self.rk[i]["proj_B"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
+                                    lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"])
+                    ops.gemm_nt(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
+                                dgelu_aux=pre, rankop=ro)
+                else:
+                    ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
+                                  rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
+                    ops.gemm_nt(gi, blk.w_proj_t, dpre, ts=us2, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
+                                dgelu_aux=pre)
+                if fused and not last:
+                    # u1 = dpre B_fc^T rides inside the dX GEMM of c_fc
+                    ro = ops.RankOp(self.rk[i]["fc_B"], self._lora_view(blk, "fc_S"), attr, rows_per_sample,
+                                    lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"])
+                    ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
+                                rankop=ro)
+                else:
+                    ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
+                                  rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
                 self.ev_layer[i].record(main)
                 with torch.cuda.stream(self.grad_stream):
@@ -324,7 +362,9 @@ class FairLoRAEngine:
                     ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
                 if last:
                     break
-                ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us1, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True)
+                if not fused:
+                    ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], ts=us1, lw=self._lora_view(blk, "fc_A"),
+                                lw_is_kr=True)
                 gout = st.g_l[i - 1][:rows] if i > 0 else g
             else:
                 gi, dpre, gout = g, st.dpre[:rows], g
@@ -348,11 +388,14 @@ class FairLoRAEngine:
         if rows not in st.plans:
             r, G, w = st.rank, self.cfg.lora.num_groups, st.width
             nsp = ops.lora_grad_splits(rows)
-            nb_p = ops.lora_down_blocks(rows, w, r, self.dtype)        # u2 = g B_proj^T sweeps K = w
-            nb_f = ops.lora_down_blocks(rows, 4 * w, r, self.dtype)    # u1 = dpre B_fc^T sweeps K = 4w
             ent = []
-            for blk, pt in zip(st.blocks, st.part):
+            for li, (blk, pt) in enumerate(zip(st.blocks, st.part)):
                 gv = lambda role: self.params.view(blk.lora[role], "grad")
+                # dS partial rows: GEMM row tiles when the down projection is fused, lora_down blocks otherwise
+                # (block 0's c_fc has no dX GEMM, so it always uses the stand-alone kernel)
+                nb_p = ops.gemm_tiles_m(rows) if self.fused_rank else ops.lora_down_blocks(rows, w, r, self.dtype)
+                nb_f = ops.gemm_tiles_m(rows) if (self.fused_rank and li > 0) \
+                    else ops.lora_down_blocks(rows, 4 * w, r, self.dtype)
                 ent += [(pt["proj_S"], nb_p, G * r, gv("proj_S"), 0, 0), (pt["fc_S"], nb_f, G * r, gv("fc_S"), 0, 0),
                         (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),
                         (pt["fc_B"], nsp, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
@@ -415,6 +458,8 @@ class FairLoRAEngine:
         if attr is not None:
             a32 = self.attr_i32[:b]
             a32.copy_(attr.to(torch.int32))
+        if self.fused_rank:
+            self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
         ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
         ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],

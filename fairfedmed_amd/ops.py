@@ -33,8 +33,23 @@ def _ld(t: Tensor) -> int:
     return t.stride(0)
 
 
+class RankOp:
+    """Arguments of FFM_EPI_RANKOP: the rank-r down projection computed inside the GEMM."""
+
+    def __init__(self, rk: Tensor, S: Tensor, attr: Optional[Tensor], rows_per_sample: int, scaling: float,
+                 lambda_group: float, t_out: Optional[Tensor] = None, ts_out: Optional[Tensor] = None,
+                 t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None):
+        self.rk, self.S, self.attr, self.rps = rk, S, attr, rows_per_sample
+        self.scaling, self.lam = scaling, lambda_group
+        self.t_out, self.ts_out, self.t_fwd, self.ds_part = t_out, ts_out, t_fwd, ds_part
+
+
+def gemm_tiles_m(M: int) -> int:
+    return L.load().ffm_gemm_tiles_m(M)
+
+
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
-            gelu_out=None, dgelu_aux=None) -> Tensor:
+            gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype)."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux)
     assert a.dtype == b.dtype == out.dtype
@@ -45,7 +60,15 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     if bias is not None:
         flags |= L.EPI_BIAS
         _f32(bias)
-    if ts is not None:
+    ro = rankop
+    if ro is not None:
+        _dev(ro.rk, ro.S, ro.attr, ro.t_out, ro.ts_out, ro.t_fwd, ro.ds_part)
+        flags |= L.EPI_LORA | L.EPI_RANKOP | (L.EPI_LORA_KR if lw_is_kr else 0)
+        rank = ro.S.shape[1]
+        assert ro.rk.dtype == a.dtype and tuple(ro.rk.shape) == (16, K) and ro.rk.is_contiguous()
+        assert lw.numel() == rank * N and (ro.attr is None or ro.attr.dtype == torch.int32)
+        _f32(lw), _f32(ro.S), _f32(ro.t_out), _f32(ro.ts_out), _f32(ro.t_fwd), _f32(ro.ds_part)
+    elif ts is not None:
         flags |= L.EPI_LORA | (L.EPI_LORA_KR if lw_is_kr else 0)
         _f32(ts), _f32(lw)
         rank = ts.shape[1]
@@ -59,8 +82,13 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         flags |= L.EPI_GELU
     if dgelu_aux is not None:
         flags |= L.EPI_DGELU
+    if ro is not None:
+        extra = (L.ptr(ro.rk), L.ptr(ro.S), L.ptr(ro.attr), L.ptr(ro.t_out), L.ptr(ro.ts_out), L.ptr(ro.t_fwd),
+                 L.ptr(ro.ds_part), ro.S.shape[0], ro.rps, ro.scaling, ro.lam)
+    else:
+        extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
-                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux))
+                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra)
     L.check(L.load().ffm_gemm_nt(C.byref(args), L.dtype_code(a.dtype), L.stream_ptr()), "ffm_gemm_nt")
     return out
 
@@ -155,6 +183,28 @@ class ReducePlan:
     def run(self) -> None:
         L.check(L.load().ffm_reduce_partials_multi(self.table.data_ptr(), self.n, self.max_n, L.stream_ptr()),
                 "ffm_reduce_partials_multi")
+
+
+class PackPlan:
+    """Device-resident descriptor table for ffm_lora_pack_multi (all adapters in one launch)."""
+
+    def __init__(self, entries, dtype, device):
+        # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype)
+        arr = (L.PackDesc * len(entries))()
+        self.keep, self.max_K, self.dtype = entries, 0, dtype
+        for i, (src, layout_rk, dst) in enumerate(entries):
+            _dev(src, dst)
+            K = dst.shape[1]
+            r = src.shape[0] if layout_rk else src.shape[1]
+            assert dst.dtype == dtype and dst.shape[0] == 16 and dst.is_contiguous() and src.is_contiguous()
+            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0)
+            self.max_K = max(self.max_K, K)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.n = len(entries)
+
+    def run(self) -> None:
+        L.check(L.load().ffm_lora_pack_multi(self.table.data_ptr(), self.n, self.max_K, L.dtype_code(self.dtype),
+                                             L.stream_ptr()), "ffm_lora_pack_multi")
 
 
 def lora_grad_splits(M: int) -> int:

@@ -40,7 +40,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 1
+#define FFM_ABI_VERSION 2
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -50,6 +50,7 @@ int ffm_abi_version(void);
 #define FFM_EPI_RESIDUAL  8   /* + res[m][n]                       (dtype, ld = ldc) */
 #define FFM_EPI_GELU      16  /* also write c2 = quick_gelu(c)                        */
 #define FFM_EPI_DGELU     32  /* c *= quick_gelu'(aux[m][n])       (aux dtype, ldc)  */
+#define FFM_EPI_RANKOP    64  /* with LORA: ts is computed in-kernel from the packed rank operand rk  */
 
 typedef struct ffm_gemm_args {
     const void* a;      /* [M, K] dtype, row stride lda (elements) */
@@ -65,6 +66,17 @@ typedef struct ffm_gemm_args {
     const void*  res;   /* residual [M, N] dtype, stride ldc */
     void*        c2;    /* GELU: activated output [M, N] dtype, stride ldc */
     const void*  aux;   /* DGELU: pre-activation [M, N] dtype, stride ldc */
+    /* FFM_EPI_RANKOP (rank <= 16): t = A . rk^T is accumulated by the GEMM itself (x A forward, g B^T
+     * backward), ts = scaling * t * s_b feeds the rank-r update above, `ts` is ignored. */
+    const void*  rk;    /* [16, K] dtype, row stride K: packed lora_A^T or lora_B (rows >= r zero), see ffm_lora_pack_multi */
+    const float* S;     /* lora_S [G, r] */
+    const int32_t* attr;/* [nsamples] group index or NULL (uniform mix) */
+    float*       t_out; /* optional [M, r]: t  */
+    float*       ts_out;/* optional [M, r]: ts */
+    const float* t_fwd; /* optional [M, r]: with ds_part, dS partials = sum_rows pi_b scaling t_fwd t */
+    float*       ds_part;/* [ffm_gemm_tiles_m(M), G, r] */
+    int32_t G, rows_per_sample;
+    float scaling, lambda_group;
 } ffm_gemm_args;
 
 /*
@@ -77,6 +89,19 @@ typedef struct ffm_gemm_args {
  * Requires K*sizeof(dtype) % 128 == 0, N % 8 == 0, 16-byte aligned rows.
  */
 int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
+int ffm_gemm_tiles_m(int M);     /* row tiles (= dS partial rows written under FFM_EPI_RANKOP) */
+
+/*
+ * Pack LoRA matrices into the GEMM's rank-operand form: dst [16, K] dtype with dst[j][k] = lora_A[k][j]
+ * (layout_rk = 0, src [K, r]) or lora_B[j][k] (layout_rk = 1, src [r, K]); rows >= r are zero.
+ * descs_dev is a DEVICE array; one launch packs every adapter of the model.
+ */
+typedef struct ffm_pack_desc {
+    const float* src;
+    void* dst;
+    int32_t K, r, layout_rk, pad_;
+} ffm_pack_desc;
+int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream);
 
 /*
  * LayerNorm over the last dimension, fp32 statistics, eps 1e-5

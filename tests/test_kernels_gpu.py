@@ -81,6 +81,39 @@ def test_gemm_fused_epilogue(ops, dt, r, kr):
 
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("r,G,kr,use_attr", [(8, 3, False, True), (16, 3, True, True), (4, 2, False, False), (12, 3, True, True)])
+def test_gemm_rankop_fused_lora(ops, dt, r, G, kr, use_attr):
+    """FFM_EPI_RANKOP: t = a . P (inside the GEMM), ts = scaling t s_b, out = a b^T + bias + ts lw, dS partials."""
+    M, N, K, rps = 700, 384, 256, 197
+    a, b = rnd(M, K, dt=dt, seed=50), rnd(N, K, dt=dt, scale=K ** -0.5, seed=51)
+    bias = rnd(N, seed=52)
+    P = rnd(K, r, scale=0.1, seed=53)                                  # e.g. lora_A [K, r]
+    S = rnd(G, r, seed=54)
+    lw = rnd(N, r, seed=55) if kr else rnd(r, N, seed=55)
+    nsamp = (M + rps - 1) // rps
+    attr = torch.randint(0, G, (nsamp,), device="cuda", dtype=torch.int32) if use_attr else None
+    t_fwd = rnd(M, r, seed=56)
+    rk = torch.zeros(16, K, device="cuda", dtype=dt)
+    ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+    assert torch.equal(rk[:r].float(), P.t().to(dt).float()) and float(rk[r:].abs().sum()) == 0.0
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    t, ts = torch.empty(M, r, device="cuda"), torch.empty(M, r, device="cuda")
+    dsp = torch.full((ops.gemm_tiles_m(M), G, r), float("nan"), device="cuda")
+    ro = ops.RankOp(rk, S, attr, rps, 0.25, 0.7, t_out=t, ts_out=ts, t_fwd=t_fwd, ds_part=dsp)
+    ops.gemm_nt(a, b, out, bias=bias, lw=lw, lw_is_kr=kr, rankop=ro)
+    ref_t = a.double() @ P.to(dt).double()
+    pi = mix(attr, G)
+    rows = torch.arange(M, device="cuda") // rps
+    pi_rows = pi[rows] if attr is not None else pi.expand(M, G)
+    ref_ts = 0.25 * ref_t * (pi_rows @ S.double())
+    lwm = lw.double().t() if kr else lw.double()
+    check(t, ref_t, 2e-5, "t")
+    check(ts, ref_ts, 2e-5, "ts")
+    check(out, a.double() @ b.double().t() + bias.double() + ref_ts @ lwm, tol(dt), "fused out")
+    check(dsp.double().sum(0), pi_rows.t() @ (0.25 * t_fwd.double() * ref_t), 5e-5, "dS")
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
 def test_gemm_gelu_and_dgelu(ops, dt):
     M, N, K = 260, 256, 128
     a, b = rnd(M, K, dt=dt, seed=9), rnd(N, K, dt=dt, scale=K ** -0.5 * 2, seed=10)
