@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--rank", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--launch", default="replay", choices=["replay", "eager", "graph"],
+                    help="replay: recorded launch plan (default); eager: Python per launch; graph: one hipGraph per step")
     return ap.parse_args()
 
 
@@ -151,9 +153,18 @@ def main():
     n_client = [1024] * world
     by_attr = [[400, 300, 324]] * world
 
-    def step():
+    def eager_step():
         eng.forward_backward(img, attr, label)
         eng.sgd_step(opt.lr, opt.momentum, opt.weight_decay)
+
+    eng.use_replay = args.launch == "replay"
+    graphed = eng.capture_train_step(BATCH, opt.lr, opt.momentum, opt.weight_decay) if args.launch == "graph" else None
+
+    def step():
+        if graphed is None:
+            eager_step()
+        else:
+            graphed.run(img, attr, label)          # copies the (resident) batch into the graph's inputs, replays
 
     def round_boundary():
         if agg is not None:
@@ -170,6 +181,7 @@ def main():
     for _ in range(args.steps):
         step()
     round_boundary()
+    t_enqueue = time.perf_counter() - t0            # host time to enqueue the K steps (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,9 +196,10 @@ def main():
 
     roof = None
     if not args.no_roofline and rank == 0:
+        eng.use_replay = False                         # per-launch events need eager launches
         with GemmTimer(ops) as gt:
             for _ in range(args.steps):
-                step()
+                eager_step()
             n, ms, fl = gt.summary()
         peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
         ach = fl / (ms * 1e-3) / 1e12
@@ -212,7 +225,9 @@ def main():
                                    "fwd+bwd+SGD per step%s" % (args.rank, "" if world == 1 else
                                                                "; one client per GPU, FedAvg all-reduce at the round end"),
                        "global_batch": BATCH * world, "clients": world,
-                       "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite},
+                       "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite,
+                       "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
+                       "launch": args.launch},
         }
         if roof:
             res["roofline"] = roof

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ffm_ce_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_sgd_momentum": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
+    "ffm_sgd_momentum_dev": [_vp, _vp, _vp, _i64, _vp, _vp],
     "ffm_scale_by": [_vp, _vp, _vp, _i64, _vp],
     "ffm_fedavg_finish": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "ffm_cast_f32_to": [_vp, _vp, _i64, _i32, _vp],

@@ -17,6 +17,21 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// same update with the hyper-parameters read from device memory (hp = {lr, momentum, weight_decay}),
+// so that a captured hipGraph keeps working when the LR scheduler changes lr.  With a zero-initialised
+// momentum buffer the general formula equals torch's first-step rule (mu*0 + d == d exactly).
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ buf, int64_t n,
+                                                      const float* __restrict__ hp) {
+    const float lr = hp[0], mu = hp[1], wd = hp[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float b = mu * buf[i] + (g[i] + wd * pi);
+        buf[i] = b;
+        p[i] = pi - lr * b;
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                        float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -90,6 +105,13 @@ extern "C" int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n,
     if (!p || !g || !buf || n <= 0) return FFM_EINVAL;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
                        weight_decay, first_step);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_sgd_momentum_dev(float* p, const float* g, float* buf, int64_t n, const float* hp, void* stream) {
+    if (!p || !g || !buf || !hp || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, hp);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

@@ -204,6 +204,10 @@ class FairLoRAEngine:
         self.finite = torch.ones(1, device=dev, dtype=torch.int32)
         self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
+        self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
+        self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.step_plans: Dict[tuple, list] = {}
+        self.use_replay = True                        # replay recorded launch plans (host-side "graph")
         self.eot_rows = torch.tensor([i * t.context_length + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
                                      device=dev, dtype=torch.int64)
         # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
@@ -228,6 +232,7 @@ class FairLoRAEngine:
         return x.to(self.device, torch.float32).contiguous().clone()
 
     def _load_stack(self, stack: _Stack, sd, prefix: str, lora: bool) -> None:
+        old = stack.blocks if stack.blocks else None
         stack.blocks = []
         for i in range(stack.layers):
             p = f"{prefix}transformer.resblocks.{i}."
@@ -247,6 +252,12 @@ class FairLoRAEngine:
             )
             if lora:
                 blk.lora = {f"{n}_{m}": f"{p}mlp.c_{n}.lora_{m}.weight" for n in ("fc", "proj") for m in "ASB"}
+            if old is not None:
+                # keep the device addresses stable (recorded launch plans hold raw pointers): refresh in place
+                for name, val in vars(blk).items():
+                    if isinstance(val, torch.Tensor):
+                        getattr(old[i], name).copy_(val)
+                blk = old[i]
             stack.blocks.append(blk)
 
     def load_frozen(self, sd: Dict[str, Tensor]) -> None:
@@ -255,20 +266,30 @@ class FairLoRAEngine:
         ie, te = "image_encoder.", "text_encoder."
         self._load_stack(self.vis, sd, ie, True)
         self._load_stack(self.txt, sd, te, False)
-        self.conv_w = self._w(sd[ie + "conv1.weight"].reshape(v.width, -1))
-        self.cls = self._w(sd[ie + "class_embedding"])
-        self.pos = self._w(sd[ie + "positional_embedding"])
-        self.lnpre = (self._f(sd[ie + "ln_pre.weight"]), self._f(sd[ie + "ln_pre.bias"]))
-        self.lnpost = (self._f(sd[ie + "ln_post.weight"]), self._f(sd[ie + "ln_post.bias"]))
-        self.proj = self._w(sd[ie + "proj"])                      # [width, out]: B operand of dh = df proj^T
-        self.proj_t = self._wt(sd[ie + "proj"])                   # [out, width]: B operand of f = h proj
-        self.logit_scale = self._f(sd["logit_scale"].reshape(1))
+        def put(name, val):                                       # stable addresses across reloads
+            cur = getattr(self, name, None)
+            if cur is None:
+                setattr(self, name, val)
+            elif isinstance(val, tuple):
+                for c, n in zip(cur, val):
+                    c.copy_(n)
+            else:
+                cur.copy_(val)
+
+        put("conv_w", self._w(sd[ie + "conv1.weight"].reshape(v.width, -1)))
+        put("cls", self._w(sd[ie + "class_embedding"]))
+        put("pos", self._w(sd[ie + "positional_embedding"]))
+        put("lnpre", (self._f(sd[ie + "ln_pre.weight"]), self._f(sd[ie + "ln_pre.bias"])))
+        put("lnpost", (self._f(sd[ie + "ln_post.weight"]), self._f(sd[ie + "ln_post.bias"])))
+        put("proj", self._w(sd[ie + "proj"]))                     # [width, out]: B operand of dh = df proj^T
+        put("proj_t", self._wt(sd[ie + "proj"]))                  # [out, width]: B operand of f = h proj
+        put("logit_scale", self._f(sd["logit_scale"].reshape(1)))
         # text side constants stay fp32 (tiny): prompt pieces, ln_final, projection
-        self.tok_prefix = self._f(sd["prompt_learner.token_prefix"])
-        self.tok_suffix = self._f(sd["prompt_learner.token_suffix"])
-        self.txt_pos = self._f(sd[te + "positional_embedding"])
-        self.lnfinal = (self._f(sd[te + "ln_final.weight"]), self._f(sd[te + "ln_final.bias"]))
-        self.text_proj = self._f(sd[te + "text_projection"])
+        put("tok_prefix", self._f(sd["prompt_learner.token_prefix"]))
+        put("tok_suffix", self._f(sd["prompt_learner.token_suffix"]))
+        put("txt_pos", self._f(sd[te + "positional_embedding"]))
+        put("lnfinal", (self._f(sd[te + "ln_final.weight"]), self._f(sd[te + "ln_final.bias"])))
+        put("text_proj", self._f(sd[te + "text_projection"]))
 
     # -------------------------------------------------------------- tower --
     def _lora_view(self, blk: _Block, role: str) -> Tensor:
@@ -328,7 +349,7 @@ class FairLoRAEngine:
                 # gradient w.r.t. this block's output lives in its own buffer (read later by the side stream)
                 gi, dpre = st.g_l[i][:rows], st.dpre_l[i][:rows]
                 if i == st.layers - 1:
-                    gi.copy_(g)
+                    self._glue(lambda gi=gi, g=g: gi.copy_(g))
                 u, us2, us1 = st.u[:rows], st.us2[i][:rows], st.us1[i][:rows]
                 pt = st.part[i]
                 # ---- critical path: u = g B^T and dX (+ LoRA dx term), dS partials
@@ -353,9 +374,9 @@ class FairLoRAEngine:
                     ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
-                self.ev_layer[i].record(main)
-                with torch.cuda.stream(self.grad_stream):
-                    self.grad_stream.wait_event(self.ev_layer[i])
+                self._ev_record(self.ev_layer[i], main)
+                self._ev_wait(self.grad_stream, self.ev_layer[i])
+                with self._on(self.grad_stream):
                     ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
                     ops.lora_grad_partial(act, us2, r, pt["proj_A"])
                     ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
@@ -377,10 +398,10 @@ class FairLoRAEngine:
             ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows])
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
         if r:
-            with torch.cuda.stream(self.grad_stream):
+            with self._on(self.grad_stream):
                 self._reduce_plan(st, rows).run()
-                self.ev_grads.record(self.grad_stream)
-            main.wait_event(self.ev_grads)
+            self._ev_record(self.ev_grads, self.grad_stream)
+            self._ev_wait(main, self.ev_grads)
         return g
 
     def _reduce_plan(self, st: _Stack, rows: int):
@@ -402,37 +423,95 @@ class FairLoRAEngine:
             st.plans[rows] = ops.ReducePlan(ent, self.device)
         return st.plans[rows]
 
+    # ------------------------------------------------------------ replay --
+    # A training step is a fixed sequence of C launches over static buffers plus a few host-side
+    # actions (event record/wait, the PyTorch glue at the ends of the text tower).  The helpers below
+    # execute an action and, while a recording is active, also append it to the replay plan.
+    def _ev_record(self, ev, stream) -> None:
+        ev.record(stream)
+        ops.record_callable(lambda: ev.record(stream))
+
+    def _ev_wait(self, stream, ev) -> None:
+        stream.wait_event(ev)
+        ops.record_callable(lambda: stream.wait_event(ev))
+
+    def _glue(self, fn, stream=None) -> None:
+        def run():
+            if stream is None:
+                fn()
+            else:
+                with torch.cuda.stream(stream):
+                    fn()
+        run()
+        ops.record_callable(run)
+
+    class _on:
+        """Make `stream` current for the C launches issued inside (their stream pointer is baked into the
+        recorded launch, so nothing is recorded for the context itself)."""
+
+        def __init__(self, stream):
+            self.ctx = torch.cuda.stream(stream)
+
+        def __enter__(self):
+            return self.ctx.__enter__()
+
+        def __exit__(self, *a):
+            return self.ctx.__exit__(*a)
+
     # --------------------------------------------------------------- text --
-    def _text_features(self, with_grad: bool):
-        """tbar [n_cls, D] = mean_n normalize(text_encoder(prompts))  (trainers/GLP_OT_SVLoRA.py:55-66,
-        131-152, 709-715).  The 12 transformer blocks run on the HIP kernels; only the tiny ends
-        (prompt concat, EOT gather, ln_final on n_text rows, projection, normalise) are PyTorch glue."""
+    def _text_glue_in(self) -> None:
+        """prompts = [prefix, ctx, suffix] + pos -> text tower input (trainers/GLP_OT_SVLoRA.py:131-152,57)."""
         cfg, t = self.cfg, self.cfg.text
         ctx = self.params.view("prompt_learner.ctx")
-        n_ctx = cfg.n_ctx
-        ctx_rows = ctx.unsqueeze(1).expand(cfg.n_prompts, cfg.n_cls, n_ctx, t.width).reshape(self.n_text, n_ctx, t.width)
+        ctx_rows = ctx.unsqueeze(1).expand(cfg.n_prompts, cfg.n_cls, cfg.n_ctx, t.width).reshape(
+            self.n_text, cfg.n_ctx, t.width)
         prompts = torch.cat([self.tok_prefix, ctx_rows, self.tok_suffix], dim=1) + self.txt_pos
         rows = self.n_text * t.context_length
         self.txt.x[0][:rows].copy_(prompts.reshape(rows, t.width))
-        out = self._stack_forward(self.txt, rows, self.n_text, None, t.context_length)
-        xe = out[self.eot_rows].float()
-        if with_grad:
-            xe.requires_grad_(True)
-        y = torch.nn.functional.layer_norm(xe, (t.width,), self.lnfinal[0], self.lnfinal[1], 1e-5)
-        tf = (y @ self.text_proj).view(cfg.n_prompts, cfg.n_cls, -1)
-        tbar = torch.nn.functional.normalize(tf, dim=2).mean(0)
-        return tbar, xe
 
-    def _text_backward(self, tbar: Tensor, xe: Tensor, dtbar: Tensor) -> None:
+    def _text_glue_out(self, with_grad: bool) -> None:
+        """EOT gather, ln_final, projection, normalise, mean over prompts -> tbar_buf [n_cls, D]
+        (trainers/GLP_OT_SVLoRA.py:62-64, 709-715).  4 rows: PyTorch glue, with autograd for the way back."""
         cfg, t = self.cfg, self.cfg.text
         rows = self.n_text * t.context_length
-        tbar.backward(dtbar)
+        xe = self.txt.x[self.txt.layers][:rows][self.eot_rows].float()
+        with torch.set_grad_enabled(with_grad):
+            if with_grad:
+                xe.requires_grad_(True)
+            y = torch.nn.functional.layer_norm(xe, (t.width,), self.lnfinal[0], self.lnfinal[1], 1e-5)
+            tf = (y @ self.text_proj).view(cfg.n_prompts, cfg.n_cls, -1)
+            tbar = torch.nn.functional.normalize(tf, dim=2).mean(0)
+        self._tbar, self._xe = tbar, xe
+        self.tbar_buf.copy_(tbar.detach())
+
+    def _text_glue_back_in(self) -> None:
+        t = self.cfg.text
+        rows = self.n_text * t.context_length
+        self._tbar.backward(self.dtbar)
         g = self.txt.g[:rows]
         g.zero_()
-        g[self.eot_rows] = xe.grad.to(self.dtype)
-        g0 = self._stack_backward(self.txt, rows, self.n_text, None, t.context_length, True)
-        d = g0.float().view(cfg.n_prompts, cfg.n_cls, t.context_length, t.width)[:, :, 1:1 + cfg.n_ctx, :].sum(1)
-        self.params.view("prompt_learner.ctx", "grad").copy_(d)
+        g[self.eot_rows] = self._xe.grad.to(self.dtype)
+        self._tbar = self._xe = None
+
+    def _text_glue_back_out(self) -> None:
+        cfg, t = self.cfg, self.cfg.text
+        rows = self.n_text * t.context_length
+        d = self.txt.g[:rows].float().view(cfg.n_prompts, cfg.n_cls, t.context_length, t.width)
+        self.params.view("prompt_learner.ctx", "grad").copy_(d[:, :, 1:1 + cfg.n_ctx, :].sum(1))
+
+    def _text_forward(self, with_grad: bool, stream=None) -> None:
+        t = self.cfg.text
+        rows = self.n_text * t.context_length
+        self._glue(self._text_glue_in, stream)
+        self._stack_forward(self.txt, rows, self.n_text, None, t.context_length)
+        self._glue(lambda: self._text_glue_out(with_grad), stream)
+
+    def _text_backward(self, stream=None) -> None:
+        t = self.cfg.text
+        rows = self.n_text * t.context_length
+        self._glue(self._text_glue_back_in, stream)
+        self._stack_backward(self.txt, rows, self.n_text, None, t.context_length, True)
+        self._glue(self._text_glue_back_out, stream)
 
     # ------------------------------------------------------------- vision --
     def _check_batch(self, image: Tensor) -> Tuple[int, int]:
@@ -448,19 +527,27 @@ class FairLoRAEngine:
             raise ValueError(f"batch {b} exceeds the engine's max_images={self.max_images}")
         return b, 1
 
-    def _vision_forward(self, image: Tensor, attr: Optional[Tensor], tbar: Tensor, wait=None) -> Tensor:
+    def _load_inputs(self, image: Tensor, attr: Optional[Tensor], label: Optional[Tensor]):
+        """Per-step inputs -> static buffers (these three launches are the only ones not replayed)."""
         cfg, v = self.cfg, self.cfg.vision
         b, S = self._check_batch(image)
         images = b * S
+        P = v.grid * v.grid
+        ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
+        if attr is not None:
+            self.attr_i32[:b].copy_(attr)
+        if label is not None:
+            self.label_buf[:b].copy_(label)
+        return b, S
+
+    def _vision_forward(self, b: int, S: int, has_attr: bool, wait=None) -> None:
+        cfg, v = self.cfg, self.cfg.vision
+        images = b * S
         P, L = v.grid * v.grid, v.tokens
         rows = images * L
-        a32 = None
-        if attr is not None:
-            a32 = self.attr_i32[:b]
-            a32.copy_(attr.to(torch.int32))
+        a32 = self.attr_i32[:b] if has_attr else None
         if self.fused_rank:
             self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
-        ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
         ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
                         self.vis.x[0][:rows], images, L)
@@ -469,53 +556,64 @@ class FairLoRAEngine:
                           self.post_stats[1])
         ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows])
         if wait is not None:
-            torch.cuda.current_stream(self.device).wait_event(wait)     # text features ready
-        ops.head_fwd(self.feat[:rows], tbar, self.logit_scale, self.fbar, self.rnorm, self.logits_img, images, L,
-                     cfg.n_cls)
-        self._last = (b, S, images, rows, a32)
-        return self.logits_img[:images]
+            self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
+        ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
+                     images, L, cfg.n_cls)
 
     # ---------------------------------------------------------------- API --
     @torch.no_grad()
     def forward(self, image: Tensor, attr: Optional[Tensor] = None) -> Tensor:
         """CustomCLIP.forward(image, attr) -> logits [B, n_cls] (inference)."""
-        tbar, _ = self._text_features(False)
-        li = self._vision_forward(image, attr, tbar.contiguous())
-        b, S = self._last[0], self._last[1]
-        return li.view(b, S, -1).mean(1)
+        b, S = self._load_inputs(image, attr, None)
+        self._text_forward(False)
+        self._vision_forward(b, S, attr is not None)
+        return self.logits_img[:b * S].view(b, S, -1).mean(1)
+
+    def _step_body(self, b: int, S: int, has_attr: bool) -> None:
+        cfg, v = self.cfg, self.cfg.vision
+        main = torch.cuda.current_stream(self.device)
+        images, L = b * S, v.tokens
+        rows = images * L
+        a32 = self.attr_i32[:b] if has_attr else None
+        self._ev_record(self.ev_start, main)
+        self._ev_wait(self.side, self.ev_start)           # parameters of the previous step are final
+        with self._on(self.side):
+            self._text_forward(True, self.side)
+        self._ev_record(self.ev_text_fwd, self.side)
+        self._vision_forward(b, S, has_attr, wait=self.ev_text_fwd)
+        ops.ce_loss(self.logits_img, self.label_buf, self.logits, self.prob, self.loss, self.dlogits_img,
+                    self.finite, b, S, cfg.n_cls)
+        ops.head_bwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
+                     self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
+        self._ev_record(self.ev_head_bwd, main)
+        self._ev_wait(self.side, self.ev_head_bwd)
+        with self._on(self.side):
+            self._text_backward(self.side)
+        self._ev_record(self.ev_text_bwd, self.side)
+        ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
+        ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
+                          self.post_stats[1], None, self.vis.g[:rows])
+        self._stack_backward(self.vis, rows, images, a32, L * S, False)
+        self._ev_wait(main, self.ev_text_bwd)
 
     def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:
         """Forward, CE loss, backward; gradients of every trainable tensor land in params.grad.
-        Returns device tensors (no host sync): loss [1], logits [B,n_cls], prob [B,n_cls], finite [1]."""
-        cfg, v = self.cfg, self.cfg.vision
-        main = torch.cuda.current_stream(self.device)
-        self.ev_start.record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_start)          # parameters of the previous step are final
-            with torch.enable_grad():
-                tbar, xe = self._text_features(True)
-            tb = tbar.detach().contiguous()
-            tb.record_stream(main)
-            self.ev_text_fwd.record(self.side)
+        Returns device tensors (no host sync): loss [1], logits [B,n_cls], prob [B,n_cls], finite [1].
+        The first call for a batch shape records the step's launch plan; later calls replay it."""
         with torch.no_grad():
-            self._vision_forward(image, attr, tb, wait=self.ev_text_fwd)
-            b, S, images, rows, a32 = self._last
-            L = v.tokens
-            ops.ce_loss(self.logits_img, label, self.logits, self.prob, self.loss, self.dlogits_img, self.finite, b,
-                        S, cfg.n_cls)
-            ops.head_bwd(self.feat[:rows], tb, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
-                         self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
-            self.ev_head_bwd.record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev_head_bwd)
-            self._text_backward(tbar, xe, self.dtbar)
-            self.ev_text_bwd.record(self.side)
-        with torch.no_grad():
-            ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
-            ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
-                              self.post_stats[1], None, self.vis.g[:rows])
-            self._stack_backward(self.vis, rows, images, a32, L * S, False)
-        main.wait_event(self.ev_text_bwd)
+            b, S = self._load_inputs(image, attr, label)
+            key = (b, S, attr is not None, torch.cuda.current_stream(self.device).cuda_stream)
+            plan = self.step_plans.get(key) if self.use_replay else None
+            if plan is not None:
+                for f in plan:
+                    f()
+            elif self.use_replay:
+                plan = []
+                with ops.record(plan):
+                    self._step_body(b, S, attr is not None)
+                self.step_plans[key] = plan
+            else:
+                self._step_body(b, S, attr is not None)
         return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
 
     @torch.no_grad()
@@ -524,5 +622,64 @@ class FairLoRAEngine:
         ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0)
         p.steps += 1
 
+    # ------------------------------------------------------------- graph --
+    def capture_train_step(self, batch_size: int, lr: float, momentum: float, weight_decay: float) -> "GraphedStep":
+        """Capture forward + backward + SGD (all three streams) into one hipGraph.  A step then costs the
+        host one graph launch instead of ~450 Python->C calls (the eager loop is host-bound at ~7 ms)."""
+        return GraphedStep(self, batch_size, lr, momentum, weight_decay)
+
     def trainable_state(self) -> Dict[str, Tensor]:
         return {k: self.params.view(k) for k in self.params.keys}
+
+
+class GraphedStep:
+    """One captured training step.  ``run(image, attr, label)`` copies the batch into the static input
+    buffers and replays the graph; results are the engine's usual device tensors (loss, logits, prob, finite)."""
+
+    def __init__(self, eng: FairLoRAEngine, batch_size: int, lr: float, momentum: float, weight_decay: float):
+        self.eng = eng
+        eng.use_replay = False                        # the hipGraph replaces the recorded launch plan
+        v, dev = eng.cfg.vision, eng.device
+        self.image = torch.zeros(batch_size, 3, v.image_size, v.image_size, device=dev)
+        self.attr = torch.zeros(batch_size, device=dev, dtype=torch.int64)
+        self.label = torch.zeros(batch_size, device=dev, dtype=torch.int64)
+        self.hp = torch.tensor([lr, momentum, weight_decay], device=dev, dtype=torch.float32)
+        p = eng.params
+        if p.steps == 0:
+            p.momentum.zero_()
+        keep = (p.flat.clone(), p.momentum.clone(), p.grad.clone())
+        # warm-up off the default stream (sets kernel attributes, sizes the allocator), then restore the state
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        p.flat.copy_(keep[0]); p.momentum.copy_(keep[1]); p.grad.copy_(keep[2])
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+        p.flat.copy_(keep[0]); p.momentum.copy_(keep[1]); p.grad.copy_(keep[2])
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        out = self.eng.forward_backward(self.image, self.attr, self.label)
+        with torch.no_grad():
+            p = self.eng.params
+            ops.sgd_momentum_dev(p.flat, p.grad, p.momentum, self.hp)
+        return out
+
+    def set_lr(self, lr: float) -> None:
+        self.hp[0:1].fill_(lr)
+
+    def run(self, image: Optional[Tensor] = None, attr: Optional[Tensor] = None, label: Optional[Tensor] = None):
+        if image is not None:
+            self.image.copy_(image, non_blocking=True)
+        if attr is not None:
+            self.attr.copy_(attr, non_blocking=True)
+        if label is not None:
+            self.label.copy_(label, non_blocking=True)
+        self.graph.replay()
+        self.eng.params.steps += 1
+        return self.out

@@ -15,6 +15,59 @@ from . import _lib as L
 
 Tensor = torch.Tensor
 
+# ---------------------------------------------------------------------------
+# Launch recording.  Every buffer of the engine is static, so the ctypes arguments of a whole
+# training step can be built once: while a recorder list is active, each C call is executed AND
+# appended as a zero-argument callable; replaying the list costs ~1.5 us per launch on the host
+# instead of ~16 us of Python (the eager loop is host-bound at ~7 ms/step for ~450 launches).
+# ---------------------------------------------------------------------------
+_REC = None
+
+
+class record:
+    def __init__(self, plan: list):
+        self.plan = plan
+
+    def __enter__(self):
+        global _REC
+        self.prev, _REC = _REC, self.plan
+        return self.plan
+
+    def __exit__(self, *a):
+        global _REC
+        _REC = self.prev
+
+
+def recording() -> bool:
+    return _REC is not None
+
+
+def record_callable(fn) -> None:
+    """Append a host-side step (event record/wait, PyTorch glue) to the active recording."""
+    if _REC is not None:
+        _REC.append(fn)
+
+
+class _Launch:
+    __slots__ = ("fn", "args", "name")
+
+    def __init__(self, fn, args, name):
+        self.fn, self.args, self.name = fn, args, name
+
+    def __call__(self):
+        rc = self.fn(*self.args)
+        if rc:
+            L.check(rc, self.name)
+
+
+def _call(name: str, *args) -> None:
+    fn = getattr(L.load(), name)
+    if _REC is not None:
+        _REC.append(_Launch(fn, args, name))
+    rc = fn(*args)
+    if rc:
+        L.check(rc, name)
+
 
 def _dev(*ts):
     for t in ts:
@@ -89,7 +142,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra)
-    L.check(L.load().ffm_gemm_nt(C.byref(args), L.dtype_code(a.dtype), L.stream_ptr()), "ffm_gemm_nt")
+    _call("ffm_gemm_nt", C.byref(args), L.dtype_code(a.dtype), L.stream_ptr())
     return out
 
 
@@ -98,9 +151,8 @@ def layernorm_fwd(x: Tensor, y: Tensor, gamma: Tensor, beta: Tensor, mean: Optio
     _dev(x, y, gamma, beta, mean, rstd)
     rows, width = x.shape
     assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype
-    L.check(L.load().ffm_layernorm_fwd(L.ptr(x), L.ptr(y), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(_f32(mean)),
-                                       L.ptr(_f32(rstd)), rows, width, L.dtype_code(x.dtype), L.stream_ptr()),
-            "ffm_layernorm_fwd")
+    _call("ffm_layernorm_fwd", L.ptr(x), L.ptr(y), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(_f32(mean)),
+                                       L.ptr(_f32(rstd)), rows, width, L.dtype_code(x.dtype), L.stream_ptr())
     return y
 
 
@@ -110,9 +162,8 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     rows, width = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and out.is_contiguous()
     assert dy.dtype == x.dtype == out.dtype and (res is None or (res.dtype == x.dtype and res.is_contiguous()))
-    L.check(L.load().ffm_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
-                                       L.ptr(res), L.ptr(out), rows, width, L.dtype_code(x.dtype), L.stream_ptr()),
-            "ffm_layernorm_bwd")
+    _call("ffm_layernorm_bwd", L.ptr(dy), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
+                                       L.ptr(res), L.ptr(out), rows, width, L.dtype_code(x.dtype), L.stream_ptr())
     return out
 
 
@@ -122,8 +173,8 @@ def patchify(img: Tensor, cols: Tensor, patch: int, mean3, std3, prenormalised: 
     assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and cols.is_contiguous()
     m = (C.c_float * 3)(*[float(v) for v in mean3])
     s = (C.c_float * 3)(*[float(v) for v in std3])
-    L.check(L.load().ffm_patchify(L.ptr(img), L.ptr(cols), B, H, W, patch, m, s, int(prenormalised),
-                                  L.dtype_code(cols.dtype), L.stream_ptr()), "ffm_patchify")
+    _call("ffm_patchify", L.ptr(img), L.ptr(cols), B, H, W, patch, m, s, int(prenormalised),
+                                  L.dtype_code(cols.dtype), L.stream_ptr())
     return cols
 
 
@@ -132,9 +183,8 @@ def embed_lnpre(patch: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Te
     _dev(patch, cls, pos, gamma, beta, x)
     width = x.shape[1]
     assert patch.dtype == cls.dtype == pos.dtype == x.dtype
-    L.check(L.load().ffm_embed_lnpre(L.ptr(patch), L.ptr(cls), L.ptr(pos), L.ptr(_f32(gamma)), L.ptr(_f32(beta)),
-                                     L.ptr(x), B, Ltok, width, L.dtype_code(x.dtype), L.stream_ptr()),
-            "ffm_embed_lnpre")
+    _call("ffm_embed_lnpre", L.ptr(patch), L.ptr(cls), L.ptr(pos), L.ptr(_f32(gamma)), L.ptr(_f32(beta)),
+                                     L.ptr(x), B, Ltok, width, L.dtype_code(x.dtype), L.stream_ptr())
     return x
 
 
@@ -143,8 +193,8 @@ def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok:
     _dev(qkv, out, lse)
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.dtype == out.dtype
     assert qkv.shape[1] == 3 * heads * 64 and out.shape[1] == heads * 64
-    L.check(L.load().ffm_attention_fwd(L.ptr(qkv), L.ptr(out), L.ptr(_f32(lse)), B, Ltok, heads, int(causal),
-                                       L.dtype_code(qkv.dtype), L.stream_ptr()), "ffm_attention_fwd")
+    _call("ffm_attention_fwd", L.ptr(qkv), L.ptr(out), L.ptr(_f32(lse)), B, Ltok, heads, int(causal),
+                                       L.dtype_code(qkv.dtype), L.stream_ptr())
     return out
 
 
@@ -153,9 +203,9 @@ def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, delta: Te
     _dev(qkv, out, dout, lse, delta, dqkv)
     for t in (qkv, out, dout, dqkv):
         assert t.is_contiguous() and t.dtype == qkv.dtype
-    L.check(L.load().ffm_attention_bwd(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(_f32(lse)), L.ptr(_f32(delta)),
+    _call("ffm_attention_bwd", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(_f32(lse)), L.ptr(_f32(delta)),
                                        L.ptr(dqkv), B, Ltok, heads, int(causal), L.dtype_code(qkv.dtype),
-                                       L.stream_ptr()), "ffm_attention_bwd")
+                                       L.stream_ptr())
     return dqkv
 
 
@@ -181,8 +231,7 @@ class ReducePlan:
         self.n = len(entries)
 
     def run(self) -> None:
-        L.check(L.load().ffm_reduce_partials_multi(self.table.data_ptr(), self.n, self.max_n, L.stream_ptr()),
-                "ffm_reduce_partials_multi")
+        _call("ffm_reduce_partials_multi", self.table.data_ptr(), self.n, self.max_n, L.stream_ptr())
 
 
 class PackPlan:
@@ -203,8 +252,8 @@ class PackPlan:
         self.n = len(entries)
 
     def run(self) -> None:
-        L.check(L.load().ffm_lora_pack_multi(self.table.data_ptr(), self.n, self.max_K, L.dtype_code(self.dtype),
-                                             L.stream_ptr()), "ffm_lora_pack_multi")
+        _call("ffm_lora_pack_multi", self.table.data_ptr(), self.n, self.max_K, L.dtype_code(self.dtype),
+                                             L.stream_ptr())
 
 
 def lora_grad_splits(M: int) -> int:
@@ -218,24 +267,23 @@ def lora_down(x: Tensor, P: Tensor, layout_rk: bool, S: Tensor, attr: Optional[T
     M, K = x.shape
     if attr is not None:
         assert attr.dtype == torch.int32
-    L.check(L.load().ffm_lora_down(L.ptr(x), _ld(x), L.ptr(_f32(P)), int(layout_rk), L.ptr(_f32(S)), L.ptr(attr), M,
+    _call("ffm_lora_down", L.ptr(x), _ld(x), L.ptr(_f32(P)), int(layout_rk), L.ptr(_f32(S)), L.ptr(attr), M,
                                    K, r, G, rows_per_sample, scaling, lambda_group, L.ptr(_f32(t)), L.ptr(_f32(ts)),
-                                   L.ptr(_f32(t_fwd)), L.ptr(_f32(ds_part)), L.dtype_code(x.dtype), L.stream_ptr()),
-            "ffm_lora_down")
+                                   L.ptr(_f32(t_fwd)), L.ptr(_f32(ds_part)), L.dtype_code(x.dtype), L.stream_ptr())
 
 
 def lora_grad_partial(x: Tensor, v: Tensor, r: int, part: Tensor) -> None:
     _dev(x, v, part)
     M, K = x.shape
-    L.check(L.load().ffm_lora_grad_partial(L.ptr(x), _ld(x), L.ptr(_f32(v)), M, K, r, L.ptr(_f32(part)),
-                                           L.dtype_code(x.dtype), L.stream_ptr()), "ffm_lora_grad_partial")
+    _call("ffm_lora_grad_partial", L.ptr(x), _ld(x), L.ptr(_f32(v)), M, K, r, L.ptr(_f32(part)),
+                                           L.dtype_code(x.dtype), L.stream_ptr())
 
 
 def reduce_partials(part: Tensor, nsplit: int, n: int, out: Tensor, transpose_K: int = 0, transpose_r: int = 0,
                     accumulate: bool = False) -> None:
     _dev(part, out)
-    L.check(L.load().ffm_reduce_partials(L.ptr(_f32(part)), nsplit, n, L.ptr(out), transpose_K, transpose_r,
-                                         int(accumulate), L.stream_ptr()), "ffm_reduce_partials")
+    _call("ffm_reduce_partials", L.ptr(_f32(part)), nsplit, n, L.ptr(out), transpose_K, transpose_r,
+                                         int(accumulate), L.stream_ptr())
 
 
 def head_fwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: Tensor, logits_img: Tensor, B: int,
@@ -243,18 +291,18 @@ def head_fwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: 
     _dev(f, tbar, logit_scale, fbar, rnorm, logits_img)
     D = f.shape[1]
     assert f.is_contiguous()
-    L.check(L.load().ffm_head_fwd(L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
+    _call("ffm_head_fwd", L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
                                   L.ptr(_f32(rnorm)), L.ptr(_f32(logits_img)), B, Ltok, D, n_cls,
-                                  L.dtype_code(f.dtype), L.stream_ptr()), "ffm_head_fwd")
+                                  L.dtype_code(f.dtype), L.stream_ptr())
 
 
 def ce_loss(logits_img: Tensor, label: Tensor, logits: Tensor, prob: Tensor, loss: Tensor, dlogits_img: Tensor,
             finite: Optional[Tensor], nb: int, S: int, n_cls: int) -> None:
     _dev(logits_img, label, logits, prob, loss, dlogits_img, finite)
     assert label.dtype == torch.int64 and (finite is None or finite.dtype == torch.int32)
-    L.check(L.load().ffm_ce_loss(L.ptr(_f32(logits_img)), L.ptr(label), L.ptr(_f32(logits)), L.ptr(_f32(prob)),
+    _call("ffm_ce_loss", L.ptr(_f32(logits_img)), L.ptr(label), L.ptr(_f32(logits)), L.ptr(_f32(prob)),
                                  L.ptr(_f32(loss)), L.ptr(_f32(dlogits_img)), L.ptr(finite), nb, S, n_cls,
-                                 L.stream_ptr()), "ffm_ce_loss")
+                                 L.stream_ptr())
 
 
 def head_bwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: Tensor, dlogits_img: Tensor,
@@ -262,22 +310,27 @@ def head_bwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: 
     _dev(f, tbar, logit_scale, fbar, rnorm, dlogits_img, df, dtbar)
     D = f.shape[1]
     assert f.dtype == df.dtype and df.is_contiguous()
-    L.check(L.load().ffm_head_bwd(L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
+    _call("ffm_head_bwd", L.ptr(f), L.ptr(_f32(tbar)), L.ptr(_f32(logit_scale)), L.ptr(_f32(fbar)),
                                   L.ptr(_f32(rnorm)), L.ptr(_f32(dlogits_img)), L.ptr(df), L.ptr(_f32(dtbar)), B,
-                                  Ltok, D, n_cls, L.dtype_code(f.dtype), L.stream_ptr()), "ffm_head_bwd")
+                                  Ltok, D, n_cls, L.dtype_code(f.dtype), L.stream_ptr())
 
 
 def sgd_momentum(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, weight_decay: float,
                  first_step: bool) -> None:
     _dev(p, g, buf)
-    L.check(L.load().ffm_sgd_momentum(L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
-                                      weight_decay, int(first_step), L.stream_ptr()), "ffm_sgd_momentum")
+    _call("ffm_sgd_momentum", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
+                                      weight_decay, int(first_step), L.stream_ptr())
+
+
+def sgd_momentum_dev(p: Tensor, g: Tensor, buf: Tensor, hp: Tensor) -> None:
+    _dev(p, g, buf, hp)
+    _call("ffm_sgd_momentum_dev", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), L.ptr(_f32(hp)),
+                                          L.stream_ptr())
 
 
 def scale_by(p: Tensor, w: Tensor, out: Tensor) -> None:
     _dev(p, w, out)
-    L.check(L.load().ffm_scale_by(L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(out)), p.numel(), L.stream_ptr()),
-            "ffm_scale_by")
+    _call("ffm_scale_by", L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(out)), p.numel(), L.stream_ptr())
 
 
 def fedavg_finish(avg: Tensor, prev: Tensor, out: Tensor, s_offsets: Optional[Tensor], G: int, r: int,
@@ -286,24 +339,23 @@ def fedavg_finish(avg: Tensor, prev: Tensor, out: Tensor, s_offsets: Optional[Te
     n_s = 0 if s_offsets is None else s_offsets.numel()
     if s_offsets is not None:
         assert s_offsets.dtype == torch.int64
-    L.check(L.load().ffm_fedavg_finish(L.ptr(_f32(avg)), L.ptr(_f32(prev)), L.ptr(_f32(out)), avg.numel(),
-                                       L.ptr(s_offsets), n_s, G, r, int(shared_half_s), beta, L.stream_ptr()),
-            "ffm_fedavg_finish")
+    _call("ffm_fedavg_finish", L.ptr(_f32(avg)), L.ptr(_f32(prev)), L.ptr(_f32(out)), avg.numel(),
+                                       L.ptr(s_offsets), n_s, G, r, int(shared_half_s), beta, L.stream_ptr())
 
 
 def cast_from_f32(src: Tensor, dtype: torch.dtype) -> Tensor:
     _dev(src)
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
-    L.check(L.load().ffm_cast_f32_to(L.ptr(_f32(src.contiguous())), L.ptr(dst), src.numel(), L.dtype_code(dtype),
-                                     L.stream_ptr()), "ffm_cast_f32_to")
+    _call("ffm_cast_f32_to", L.ptr(_f32(src.contiguous())), L.ptr(dst), src.numel(), L.dtype_code(dtype),
+                                     L.stream_ptr())
     return dst
 
 
 def cast_to_f32(src: Tensor) -> Tensor:
     _dev(src)
     dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
-    L.check(L.load().ffm_cast_to_f32(L.ptr(src.contiguous()), L.ptr(dst), src.numel(), L.dtype_code(src.dtype),
-                                     L.stream_ptr()), "ffm_cast_to_f32")
+    _call("ffm_cast_to_f32", L.ptr(src.contiguous()), L.ptr(dst), src.numel(), L.dtype_code(src.dtype),
+                                     L.stream_ptr())
     return dst
 
 
@@ -312,6 +364,6 @@ def transpose_cast(src: Tensor, dtype: torch.dtype) -> Tensor:
     _dev(src)
     rows, cols = src.shape
     dst = torch.empty((cols, rows), dtype=dtype, device=src.device)
-    L.check(L.load().ffm_transpose_cast(L.ptr(_f32(src.contiguous())), L.ptr(dst), rows, cols, L.dtype_code(dtype),
-                                        L.stream_ptr()), "ffm_transpose_cast")
+    _call("ffm_transpose_cast", L.ptr(_f32(src.contiguous())), L.ptr(dst), rows, cols, L.dtype_code(dtype),
+                                        L.stream_ptr())
     return dst

@@ -240,6 +240,10 @@ int ffm_head_bwd(const void* f, const float* tbar, const float* logit_scale, con
 int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                      float weight_decay, int first_step, void* stream);
 
+/* The same update with {lr, momentum, weight_decay} read from DEVICE memory (hp[3]) and a momentum buffer
+ * that starts at zero: safe to capture in a hipGraph while the LR schedule changes lr between replays. */
+int ffm_sgd_momentum_dev(float* p, const float* g, float* buf, int64_t n, const float* hp, void* stream);
+
 /*
  * Round boundary helpers (utils/fed_utils.py:42-100) on the flat trainable
  * buffer: out[i] = p[i] * w[i] (per-element FedAvg weights: n_k/N, or
