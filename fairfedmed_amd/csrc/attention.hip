@@ -162,14 +162,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 
         f32x4 s[NFP];
         float mx = -INFINITY;
+        frag_t kcur[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks)
+            kcur[ks] = *reinterpret_cast<const frag_t*>(Ks + rm_off<T>(col, ks * 4 + g));
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
+            frag_t knxt[AT<T>::ND];                   // fragments of f+1 are in flight while f multiplies
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks)
+                knxt[ks] = *reinterpret_cast<const frag_t*>(Ks + rm_off<T>((f + 1 < NFP ? f + 1 : f) * 16 + col, ks * 4 + g));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                const frag_t kf = *reinterpret_cast<const frag_t*>(Ks + rm_off<T>(f * 16 + col, ks * 4 + g));
-                Mma16<T>::mma(acc, kf, qf[ks]);
-            }
+            for (int ks = 0; ks < AT<T>::ND; ++ks) Mma16<T>::mma(acc, kcur[ks], qf[ks]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = f * 16 + g * 4 + e;
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
                 mx = fmaxf(mx, v);
             }
             s[f] = acc;
-            __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads from being hoisted across f (VGPR pressure)
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) kcur[ks] = knxt[ks];
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment loads from being hoisted further (VGPR pressure)
         }
         mx = group4_max(mx);
         float sum = 0.f;
@@ -196,14 +203,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         f32x4 o[4];
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int NST = NFP / AT<T>::FPK;
+        frag_t vcur[4];
 #pragma unroll
-        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+        for (int fd = 0; fd < 4; ++fd) vcur[fd] = AT<T>::tfrag(Vt, ts, fd * 16 + col, 0, g);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            frag_t vnxt[4];
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) vnxt[fd] = AT<T>::tfrag(Vt, ts, fd * 16 + col, st + 1 < NST ? st + 1 : st, g);
             const frag_t pf = AT<T>::pack(s, st);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                const frag_t vf = AT<T>::tfrag(Vt, ts, fd * 16 + col, st, g);
-                Mma16<T>::mma(o[fd], vf, pf);
-            }
+            for (int fd = 0; fd < 4; ++fd) Mma16<T>::mma(o[fd], vcur[fd], pf);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) vcur[fd] = vnxt[fd];
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < L) {
@@ -227,14 +240,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
                                                          float* __restrict__ delta, int B, int L, int heads) {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);          // (b, l, h)
-    if (idx >= B * L * heads) return;
-    const int h = idx % heads, row = idx / heads;                 // row = b*L + l
-    const size_t off = (size_t)row * heads * HD + h * HD + lane;
-    float v = Elem<T>::to_f(o[off]) * Elem<T>::to_f(d_o[off]);
-    v = wave_sum(v);
-    if (lane == 0) {
+    // 8 lanes per (row, head): each loads 8 consecutive d (16 B bf16 / 2 x 16 B f32), 3 shuffles combine them
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pair = gid >> 3, sub = gid & 7;                     // pair = row * heads + h
+    const bool ok = pair < B * L * heads;
+    const int h = ok ? pair % heads : 0, row = ok ? pair / heads : 0;
+    const size_t off = (size_t)row * heads * HD + h * HD + sub * 8;
+    float a[8], g[8];
+    Vec8<T>::load(o + off, a);
+    Vec8<T>::load(d_o + off, g);
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v += a[e] * g[e];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (ok && sub == 0) {
         const int b = row / L, l = row % L;
         delta[((size_t)b * heads + h) * L + l] = v;
     }
@@ -299,15 +320,26 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __rest
         const float dl = delta[((size_t)b * heads + h) * L + qc];
 
         f32x4 ds[NFP];
+        frag_t kcur[AT<T>::ND], vcur[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks) {
+            kcur[ks] = opfrag<T, STAGED>(Ks, base + E, ld, col, L, ks, g);
+            vcur[ks] = opfrag<T, STAGED>(Vs, base + 2 * E, ld, col, L, ks, g);
+        }
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
+            frag_t knxt[AT<T>::ND], vnxt[AT<T>::ND];      // f+1 in flight while f multiplies
+            const int fn = (f + 1 < NFP) ? f + 1 : f;
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                knxt[ks] = opfrag<T, STAGED>(Ks, base + E, ld, fn * 16 + col, L, ks, g);
+                vnxt[ks] = opfrag<T, STAGED>(Vs, base + 2 * E, ld, fn * 16 + col, L, ks, g);
+            }
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                const frag_t kf = opfrag<T, STAGED>(Ks, base + E, ld, f * 16 + col, L, ks, g);
-                const frag_t vf = opfrag<T, STAGED>(Vs, base + 2 * E, ld, f * 16 + col, L, ks, g);
-                Mma16<T>::mma(sa, kf, qf[ks]);
-                Mma16<T>::mma(pa, vf, dof[ks]);
+                Mma16<T>::mma(sa, kcur[ks], qf[ks]);
+                Mma16<T>::mma(pa, vcur[ks], dof[ks]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -320,19 +352,27 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __rest
                 sa[e] = v;
             }
             ds[f] = sa;
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) { kcur[ks] = knxt[ks]; vcur[ks] = vnxt[ks]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 o[4];
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int NST = NFP / AT<T>::FPK;
+        frag_t tcur[4];
 #pragma unroll
-        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+        for (int fd = 0; fd < 4; ++fd) tcur[fd] = AT<T>::tfrag(Kt, ts, fd * 16 + col, 0, g);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            frag_t tnxt[4];
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) tnxt[fd] = AT<T>::tfrag(Kt, ts, fd * 16 + col, st + 1 < NST ? st + 1 : st, g);
             const frag_t pf = AT<T>::pack(ds, st);
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                const frag_t kf = AT<T>::tfrag(Kt, ts, fd * 16 + col, st, g);
-                Mma16<T>::mma(o[fd], kf, pf);
-            }
+            for (int fd = 0; fd < 4; ++fd) Mma16<T>::mma(o[fd], tcur[fd], pf);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) tcur[fd] = tnxt[fd];
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < L) {
@@ -393,15 +433,26 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
             vf[ks] = gfrag<T>(base + 2 * E, ld, key, L, ks, g);
         }
         f32x4 pp[NFP], ds[NFP];
+        frag_t qcur[AT<T>::ND], dcur[AT<T>::ND];
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::ND; ++ks) {
+            qcur[ks] = opfrag<T, STAGED>(Qs, base, ld, col, L, ks, g);
+            dcur[ks] = opfrag<T, STAGED>(dOs, dob, E, col, L, ks, g);
+        }
 #pragma unroll
         for (int f = 0; f < NFP; ++f) {
+            frag_t qnxt[AT<T>::ND], dnxt[AT<T>::ND];
+            const int fn = (f + 1 < NFP) ? f + 1 : f;
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                qnxt[ks] = opfrag<T, STAGED>(Qs, base, ld, fn * 16 + col, L, ks, g);
+                dnxt[ks] = opfrag<T, STAGED>(dOs, dob, E, fn * 16 + col, L, ks, g);
+            }
             f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                const frag_t qf = opfrag<T, STAGED>(Qs, base, ld, f * 16 + col, L, ks, g);
-                const frag_t dof = opfrag<T, STAGED>(dOs, dob, E, f * 16 + col, L, ks, g);
-                Mma16<T>::mma(sa, qf, kf[ks]);
-                Mma16<T>::mma(pa, dof, vf[ks]);
+                Mma16<T>::mma(sa, qcur[ks], kf[ks]);
+                Mma16<T>::mma(pa, dcur[ks], vf[ks]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -416,22 +467,38 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
             }
             pp[f] = sa;
             ds[f] = pa;
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::ND; ++ks) { qcur[ks] = qnxt[ks]; dcur[ks] = dnxt[ks]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) { dv[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        constexpr int NST = NFP / AT<T>::FPK;
+        frag_t a1c[4], a2c[4];
 #pragma unroll
-        for (int st = 0; st < NFP / AT<T>::FPK; ++st) {
+        for (int fd = 0; fd < 4; ++fd) {
+            a1c[fd] = AT<T>::tfrag(dOt, ts, fd * 16 + col, 0, g);
+            a2c[fd] = AT<T>::tfrag(Qt, ts, fd * 16 + col, 0, g);
+        }
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            frag_t a1n[4], a2n[4];
+            const int sn = st + 1 < NST ? st + 1 : st;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                a1n[fd] = AT<T>::tfrag(dOt, ts, fd * 16 + col, sn, g);
+                a2n[fd] = AT<T>::tfrag(Qt, ts, fd * 16 + col, sn, g);
+            }
             const frag_t pf = AT<T>::pack(pp, st);
             const frag_t df = AT<T>::pack(ds, st);
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
-                const frag_t a1 = AT<T>::tfrag(dOt, ts, fd * 16 + col, st, g);
-                const frag_t a2 = AT<T>::tfrag(Qt, ts, fd * 16 + col, st, g);
-                Mma16<T>::mma(dv[fd], a1, pf);
-                Mma16<T>::mma(dk[fd], a2, df);
+                Mma16<T>::mma(dv[fd], a1c[fd], pf);
+                Mma16<T>::mma(dk[fd], a2c[fd], df);
             }
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) { a1c[fd] = a1n[fd]; a2c[fd] = a2n[fd]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (key < L) {
@@ -486,7 +553,7 @@ int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int
 template <typename T, int NFP>
 int run_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
             int L, int heads, int causal, hipStream_t s) {
-    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((B * L * heads + 3) / 4), dim3(256), 0, s, (const T*)out,
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((B * L * heads * 8 + 255) / 256), dim3(256), 0, s, (const T*)out,
                        (const T*)dout, delta, B, L, heads);
     FFM_CHECK_LAUNCH();
     int lds = lds_dq<T>(NFP);

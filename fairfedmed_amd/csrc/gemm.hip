@@ -28,8 +28,15 @@ constexpr int CS_ROWS = 64;                          // epilogue runs in two 64-
 // also store t / ts and the dS partial sums.
 template <bool RK> __host__ __device__ constexpr int buf_bytes() { return 2 * TILE_BYTES + (RK ? RK_BYTES : 0); }
 
+// LDS = [ring: 2 buffers, reused by the epilogue for the C stage / Ts / t tile]
+//       [persistent: LoRA matrix tile Ls[r][128], bias[128], ts rows [128][r] (non-RANKOP), lora_S [256] and the
+//        128 rows' group ids (RANKOP)] -- filled at kernel start so that their global-load latency hides behind
+//        the main loop instead of sitting in front of the epilogue.
 __host__ __device__ constexpr int epi_lds_bytes(int r, bool rk) {
-    return CS_ROWS * CS_LD * 4 + r * BN * 4 + CS_ROWS * r * 4 + (rk ? BM * RK_ROWS * 4 + 256 * 4 + BM * 4 : 0);
+    return CS_ROWS * CS_LD * 4 + CS_ROWS * ((r + 7) & ~7) * 4 + (rk ? BM * RK_ROWS * 4 : 0);
+}
+__host__ __device__ constexpr int persist_bytes(int r, bool rk) {
+    return r * BN * 4 + BN * 4 + (rk ? 256 * 4 + BM * 4 : BM * r * 4);
 }
 
 template <typename T>
@@ -53,10 +60,13 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
     }
 }
 
-template <typename T, bool RK>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
+// FL >= 0: the epilogue flags are a compile-time constant (the combinations the engine uses are
+// instantiated below, so the epilogue is straight-line code); FL < 0: generic, flags read at run time.
+template <typename T, bool RK, int FL>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
     typedef typename Mma16<T>::frag_t frag_t;
     constexpr int BUF = buf_bytes<RK>();
+    const int flags = FL >= 0 ? FL : p.flags;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,6 +88,37 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- persistent epilogue operands (their loads overlap the main loop)
+    const bool has_lora = (flags & FFM_EPI_LORA) != 0;
+    const int r = has_lora ? p.rank : 0;
+    float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);     // LoRA matrix tile [r][BN]
+    float* Bias = Ls + r * BN;                                // [BN]
+    float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
+    float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
+    int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
+    if (tid < BN) Bias[tid] = ((flags & FFM_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    if (has_lora) {
+        for (int idx = tid; idx < r * BN; idx += 256) {
+            const int j = idx / BN, n = idx % BN;
+            float v = 0.f;
+            if (n0 + n < p.N)
+                v = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
+            Ls[idx] = v;
+        }
+        if constexpr (RK) {
+            if (tid < p.G * r) Sg[tid] = p.S[tid];
+            if (tid < BM) {
+                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+                Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
+            }
+        } else {
+            for (int idx = tid; idx < BM * r; idx += 256) {
+                const int gm = m0 + idx / r;
+                TsAll[idx] = gm < p.M ? p.ts[(size_t)gm * r + idx % r] : 0.f;
+            }
+        }
+    }
 
     f32x4 tacc[2];
     tacc[0] = tacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -138,43 +179,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
 
     // ---------------- epilogue: two halves of 64 rows through LDS ----------
     float* Cs = reinterpret_cast<float*>(smem);
-    const bool has_lora = (p.flags & FFM_EPI_LORA) != 0;
-    const int r = has_lora ? p.rank : 0;
-    float* Ls = Cs + CS_ROWS * CS_LD;                 // LoRA matrix tile [r][BN]
-    float* Ts = Ls + r * BN;                          // ts rows [64][r]
-    float* Tt = Ts + CS_ROWS * r;                     // RANKOP: t tile [128][16]
+    const int rp8 = (r + 7) & ~7;                     // Ts row stride: rank padded to 8 with zeros (branch-free update)
+    float* Ts = Cs + CS_ROWS * CS_LD;                 // ts rows of the current half [64][rp8]
+    float* Tt = Ts + CS_ROWS * rp8;                   // RANKOP: t tile [128][16]
     T* C = reinterpret_cast<T*>(p.c);
+    auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
+        const int a = Ga[row];
+        return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
+    };
     if constexpr (RK) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 Tt[(wm * 64 + (2 * wn + ii) * 16 + fgrp * 4 + e) * RK_ROWS + frow] = tacc[ii][e];
-    }
-
-    if (has_lora) {
-        // LoRA matrix tile: Ls[j][n] for n0..n0+127
-        for (int idx = tid; idx < r * BN; idx += 256) {
-            const int j = idx / BN, n = idx % BN;
-            float v = 0.f;
-            if (n0 + n < p.N)
-                v = (p.flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
-            Ls[idx] = v;
-        }
-    }
-
-    float* Sg = Tt + BM * RK_ROWS;                    // RANKOP: lora_S [G][r]
-    int* Ga = reinterpret_cast<int*>(Sg + 256);       // RANKOP: group index of each of the 128 rows (-1: uniform)
-    auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
-        const int a = Ga[row];
-        return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
-    };
-    if constexpr (RK) {
-        if (tid < p.G * r) Sg[tid] = p.S[tid];
-        if (tid < BM) {
-            const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
-            Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
-        }
         const bool do_ds = (tn == 0) && p.t_fwd && p.ds_part;
         if (do_ds) {
             // Wv[row][j] = scaling * t_fwd * t, staged in the (still free) C-stage region
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
                 Cs[idx] = gm < p.M ? p.scaling * p.t_fwd[(size_t)gm * r + j] * Tt[row * RK_ROWS + j] : 0.f;
             }
         }
-        __syncthreads();                              // Tt, Sg, Ga (and Wv) visible
+        __syncthreads();                              // Tt (and Wv) visible
         if (do_ds) {
             if (tid < p.G * r) {
                 // dS partial of this row tile: sum_rows pi_b[g] * scaling * t_fwd * t
@@ -202,6 +220,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     const int erow0 = tid >> 4;                       // rows erow0 + 16*i
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
+        // this half's residual / pre-activation rows: issue the global loads now, consume after the barrier
+        constexpr int NCH = (int)(sizeof(T) * 8 / 16);               // 16-byte chunks per 8 elements (1 bf16, 2 f32)
+        typename Elem<T>::chunk_t rres[4][NCH], raux[4][NCH];
+        const int gn = n0 + ecol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + half * 64 + erow0 + 16 * i;
+            if (gn < p.N && gm < p.M) {
+                const size_t off = (size_t)gm * p.ldc + gn;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (flags & FFM_EPI_RESIDUAL)
+                        rres[i][c] = reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.res) + off)[c];
+                    if (flags & FFM_EPI_DGELU)
+                        raux[i][c] = reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.aux) + off)[c];
+                }
+            }
+        }
         if (wm == half) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -212,9 +248,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
                         Cs[(i * 16 + fgrp * 4 + e) * CS_LD + wn * 64 + j * 16 + frow] = acc[i][j][e];
         }
         if (has_lora) {
-            for (int idx = tid; idx < CS_ROWS * r; idx += 256) {
-                const int row = idx / r, j = idx % r;
+            for (int idx = tid; idx < CS_ROWS * rp8; idx += 256) {
+                const int row = idx / rp8, j = idx % rp8;
                 const int gm = m0 + half * 64 + row;
+                if (j >= r) { Ts[idx] = 0.f; continue; }
                 if constexpr (RK) {
                     float tsv = 0.f;
                     if (gm < p.M) {
@@ -229,25 +266,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
                     }
                     Ts[idx] = tsv;
                 } else {
-                    Ts[idx] = gm < p.M ? p.ts[(size_t)gm * r + j] : 0.f;
+                    Ts[idx] = TsAll[(half * 64 + row) * r + j];
                 }
             }
         }
         __syncthreads();
-        const int gn = n0 + ecol;
         if (gn < p.N) {
             float v[4][8];
             {
-                float bias8[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) bias8[c] = (p.flags & FFM_EPI_BIAS) ? p.bias[gn + c] : 0.f;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[ecol]);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[ecol + 4]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int lrow = erow0 + 16 * i;
                     const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol]);
                     const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cs[lrow * CS_LD + ecol + 4]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { v[i][c] = c0[c] + bias8[c]; v[i][4 + c] = c1[c] + bias8[4 + c]; }
+                    for (int c = 0; c < 4; ++c) { v[i][c] = c0[c] + b0[c]; v[i][4 + c] = c1[c] + b1[c]; }
                 }
             }
             if (has_lora) {
@@ -267,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
                         const int lrow = erow0 + 16 * i;
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) {
-                            const float tj = (j0 + jj) < r ? Ts[lrow * r + j0 + jj] : 0.f;
+                            const float tj = Ts[lrow * rp8 + j0 + jj];
 #pragma unroll
                             for (int c = 0; c < 8; ++c) v[i][c] += tj * lreg[jj][c];
                         }
@@ -280,20 +315,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
                 const int gm = m0 + half * 64 + lrow;
                 if (gm >= p.M) continue;
                 const size_t off = (size_t)gm * p.ldc + gn;
-                if (p.flags & FFM_EPI_RESIDUAL) {
-                    float rr[8];
-                    Vec8<T>::load(reinterpret_cast<const T*>(p.res) + off, rr);
+                constexpr int EPC = Elem<T>::kPerChunk;
+                if (flags & FFM_EPI_RESIDUAL) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[i][c] += rr[c];
+                    for (int c = 0; c < 8; ++c) v[i][c] += Elem<T>::to_f(rres[i][c / EPC][c % EPC]);
                 }
-                if (p.flags & FFM_EPI_DGELU) {
-                    float pre[8];
-                    Vec8<T>::load(reinterpret_cast<const T*>(p.aux) + off, pre);
+                if (flags & FFM_EPI_DGELU) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(pre[c]);
+                    for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(Elem<T>::to_f(raux[i][c / EPC][c % EPC]));
                 }
                 Vec8<T>::store(C + off, v[i]);
-                if (p.flags & FFM_EPI_GELU) {
+                if (flags & FFM_EPI_GELU) {
                     float a[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) a[c] = Act<T>::gelu(Elem<T>::to_f(Elem<T>::from_f(v[i][c])));
@@ -305,22 +337,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(ffm_gemm_args p) {
     }
 }
 
-template <typename T, bool RK>
+template <typename T, bool RK, int FL>
 int launch_gemm(const ffm_gemm_args& a, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int r = (a.flags & FFM_EPI_LORA) ? a.rank : 0;
     int lds = epi_lds_bytes(r, RK);
     if (lds < 2 * buf_bytes<RK>()) lds = 2 * buf_bytes<RK>();
+    lds += persist_bytes(r, RK);
     if (lds > 65536) {
         static bool done = false;                     // one per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return (int)e;
             done = true;
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, RK>), dim3(tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL>), dim3(tiles), dim3(256), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -363,8 +396,32 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true>(a, s) : launch_gemm<float, true>(a, s);
-    return dtype == FFM_BF16 ? launch_gemm<bf16_t, false>(a, s) : launch_gemm<float, false>(a, s);
+    const int fl = a.flags & ~FFM_EPI_RANKOP;
+#define FFM_GEMM_CASE(RKB, F) \
+    case F: return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
+    if (rk) {
+        switch (fl) {
+            FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU)                        // c_fc forward
+            FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)                    // c_proj forward
+            FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                    // dX of c_proj
+            FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR)                                    // dX of c_fc
+            default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1>(a, s) : launch_gemm<float, true, -1>(a, s);
+        }
+    }
+    switch (fl) {
+        FFM_GEMM_CASE(false, 0)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_RESIDUAL)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_GELU)
+        FFM_GEMM_CASE(false, FFM_EPI_DGELU)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_LORA)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU)
+        FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)
+        FFM_GEMM_CASE(false, FFM_EPI_LORA | FFM_EPI_LORA_KR)
+        FFM_GEMM_CASE(false, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)
+        default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1>(a, s) : launch_gemm<float, false, -1>(a, s);
+    }
+#undef FFM_GEMM_CASE
 }
 
 extern "C" int ffm_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }

@@ -212,8 +212,8 @@ class FairLoRAEngine:
                                      device=dev, dtype=torch.int64)
         # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
         # logits head, so it runs on its own HIP stream beside it (forward and backward).
-        self.side = torch.cuda.Stream(device=self.device)
-        self.grad_stream = torch.cuda.Stream(device=self.device)
+        self.side = self._side0 = torch.cuda.Stream(device=self.device)
+        self.grad_stream = self._grad0 = torch.cuda.Stream(device=self.device)
         self.ev_layer = [torch.cuda.Event() for _ in range(v.layers)]
         self.ev_grads = torch.cuda.Event()
         self.ev_text_fwd = torch.cuda.Event()
@@ -621,6 +621,16 @@ class FairLoRAEngine:
         p = self.params
         ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0)
         p.steps += 1
+
+    def set_overlap(self, on: bool) -> None:
+        """on: text tower and LoRA-gradient reductions run on their own streams beside the vision chain
+        (default).  off: everything on the caller's stream, one kernel at a time (clean per-kernel timings)."""
+        cur = torch.cuda.current_stream(self.device)
+        if on:
+            self.side, self.grad_stream = self._side0, self._grad0
+        else:
+            self.side = self.grad_stream = cur
+        self.step_plans.clear()
 
     # ------------------------------------------------------------- graph --
     def capture_train_step(self, batch_size: int, lr: float, momentum: float, weight_decay: float) -> "GraphedStep":
