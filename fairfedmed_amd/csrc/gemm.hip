@@ -33,10 +33,11 @@ template <bool RK> __host__ __device__ constexpr int buf_bytes() { return 2 * TI
 //        128 rows' group ids (RANKOP)] -- filled at kernel start so that their global-load latency hides behind
 //        the main loop instead of sitting in front of the epilogue.
 __host__ __device__ constexpr int epi_lds_bytes(int r, bool rk) {
-    return CS_ROWS * CS_LD * 4 + CS_ROWS * ((r + 7) & ~7) * 4 + (rk ? BM * RK_ROWS * 4 : 0);
+    return CS_ROWS * CS_LD * 4 + CS_ROWS * ((r + 7) & ~7) * 4 + (rk ? BM * RK_ROWS * 4 : 0) + (r ? BM * 64 : 0);
 }
 __host__ __device__ constexpr int persist_bytes(int r, bool rk) {
-    return r * BN * 4 + BN * 4 + (rk ? 256 * 4 + BM * 4 : BM * r * 4);
+    const int ls = r * BN * 4 > BN * 64 ? r * BN * 4 : (r ? BN * 64 : 0);   // Ls [r][128] f32, or LwB [128][64 B]
+    return ls + BN * 4 + (rk ? 256 * 4 + BM * 4 : BM * r * 4);
 }
 
 template <typename T>
@@ -89,37 +90,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- persistent epilogue operands (their loads overlap the main loop)
-    const bool has_lora = (flags & FFM_EPI_LORA) != 0;
-    const int r = has_lora ? p.rank : 0;
-    float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);     // LoRA matrix tile [r][BN]
-    float* Bias = Ls + r * BN;                                // [BN]
-    float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
-    float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
-    int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
-    if (tid < BN) Bias[tid] = ((flags & FFM_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
-    if (has_lora) {
-        for (int idx = tid; idx < r * BN; idx += 256) {
-            const int j = idx / BN, n = idx % BN;
-            float v = 0.f;
-            if (n0 + n < p.N)
-                v = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
-            Ls[idx] = v;
-        }
-        if constexpr (RK) {
-            if (tid < p.G * r) Sg[tid] = p.S[tid];
-            if (tid < BM) {
-                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
-                Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
-            }
-        } else {
-            for (int idx = tid; idx < BM * r; idx += 256) {
-                const int gm = m0 + idx / r;
-                TsAll[idx] = gm < p.M ? p.ts[(size_t)gm * r + idx % r] : 0.f;
-            }
-        }
-    }
-
     f32x4 tacc[2];
     tacc[0] = tacc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the packed rank operand: 16 rows x 128 B per K-tile = 2 wave-instructions (waves 0 and 1)
@@ -138,6 +108,81 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
     stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
     stage_tile<T>(B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
     stage_rank(0, smem + 2 * TILE_BYTES);
+
+    // ---- persistent epilogue operands (their loads overlap the main loop)
+    const bool has_lora = (flags & FFM_EPI_LORA) != 0;
+    const int r = has_lora ? p.rank : 0;
+    // rank <= 16: the rank-r update acc += ts . lw runs on the MFMA pipe right after the main loop (operands
+    // as 64-byte rows: 32 bf16 / 16 f32 rank slots, zero padded); larger ranks use the VALU update in the epilogue
+    constexpr int KE = 64 / (int)sizeof(T);
+    const bool lora_mma = has_lora && r <= 16;
+    float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);     // LoRA matrix tile [r][BN] (VALU path)
+    T* LwB = reinterpret_cast<T*>(smem + 2 * BUF);            // LoRA matrix tile, transposed [BN][KE] (MFMA path)
+    const int ls_bytes = r * BN * 4 > BN * 64 ? r * BN * 4 : (r ? BN * 64 : 0);
+    float* Bias = reinterpret_cast<float*>(smem + 2 * BUF + ls_bytes);   // [BN]
+    float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
+    float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
+    int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
+    if (tid < BN) Bias[tid] = ((flags & FFM_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    if (has_lora) {
+        // All global loads of a fill are issued before the first LDS store (a load -> store loop pays one
+        // memory round trip per iteration).
+        if (lora_mma) {
+            // thread -> column n = tid & 127 and rank slots j = (tid >> 7) + 2 it: no integer division, and all
+            // loads are in flight before the first LDS store
+            const int fn = tid & 127, fj0 = tid >> 7;
+            float tmp[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int j = fj0 + 2 * it;
+                tmp[it] = 0.f;
+                if (j < r && n0 + fn < p.N)
+                    tmp[it] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+            }
+#pragma unroll
+            for (int it = 0; it < KE / 2; ++it)           // j < 16 carry values (or zeros), the rest is padding
+                LwB[fn * KE + fj0 + 2 * it] = Elem<T>::from_f(it < 8 ? tmp[it < 8 ? it : 0] : 0.f);
+        } else {
+            for (int idx0 = tid; idx0 < r * BN; idx0 += 256 * 8) {
+                float tmp[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = idx0 + 256 * it;
+                    const int j = idx / BN, n = idx % BN;
+                    tmp[it] = 0.f;
+                    if (idx < r * BN && n0 + n < p.N)
+                        tmp[it] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    if (idx0 + 256 * it < r * BN) Ls[idx0 + 256 * it] = tmp[it];
+            }
+        }
+        if constexpr (RK) {
+            if (tid < p.G * r) Sg[tid] = p.S[tid];
+            if (tid < BM) {
+                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+                Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
+            }
+        } else {
+            const int frow_ = tid & 127, fj0 = tid >> 7;
+            const int gm = m0 + frow_;
+            for (int jb = 0; jb < r; jb += 16) {
+                float tmp[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int j = jb + fj0 + 2 * it;
+                    tmp[it] = (j < r && gm < p.M) ? p.ts[(size_t)gm * r + j] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int j = jb + fj0 + 2 * it;
+                    if (j < r) TsAll[frow_ * r + j] = tmp[it];
+                }
+            }
+        }
+    }
+
     __syncthreads();
 
     const int frow = lane & 15, fgrp = lane >> 4;
@@ -197,10 +242,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
         if (do_ds) {
             // Wv[row][j] = scaling * t_fwd * t, staged in the (still free) C-stage region
             __syncthreads();                          // Tt complete
-            for (int idx = tid; idx < BM * r; idx += 256) {
-                const int row = idx / r, j = idx % r;
-                const int gm = m0 + row;
-                Cs[idx] = gm < p.M ? p.scaling * p.t_fwd[(size_t)gm * r + j] * Tt[row * RK_ROWS + j] : 0.f;
+            for (int idx0 = tid; idx0 < BM * r; idx0 += 256 * 8) {
+                float tmp[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = idx0 + 256 * it;
+                    const int gm = m0 + idx / r;
+                    tmp[it] = (idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = idx0 + 256 * it;
+                    if (idx < BM * r) Cs[idx] = p.scaling * tmp[it] * Tt[(idx / r) * RK_ROWS + idx % r];
+                }
             }
         }
         __syncthreads();                              // Tt (and Wv) visible
@@ -213,6 +267,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
                 p.ds_part[((size_t)tm * p.G + g) * r + j] = sacc;
             }
             __syncthreads();                          // Cs is reused by the halves below
+        }
+    }
+    if (lora_mma) {
+        T* TsA = reinterpret_cast<T*>(Tt + (RK ? BM * RK_ROWS : 0));      // ts tile [BM][KE], zero padded
+        {
+            const int row = tid & 127, fj0 = tid >> 7;
+            const int gm = m0 + row;
+#pragma unroll
+            for (int it = 0; it < KE / 2; ++it) {
+                const int j = fj0 + 2 * it;
+                float tsv = 0.f;
+                if (j < r && gm < p.M) {
+                    if constexpr (RK) {
+                        const float tv = Tt[row * RK_ROWS + j];
+                        float sb = 0.f;
+                        for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
+                        tsv = p.scaling * tv * sb;
+                        if (tn == 0) {
+                            if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
+                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv;
+                        }
+                    } else {
+                        tsv = TsAll[row * r + j];
+                    }
+                }
+                TsA[row * KE + j] = Elem<T>::from_f(tsv);
+            }
+        }
+        __syncthreads();
+        const char* ta = reinterpret_cast<const char*>(TsA);
+        const char* lb = reinterpret_cast<const char*>(LwB);
+        frag_t bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(lb + (wn * 64 + j * 16 + frow) * 64 + fgrp * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const frag_t afr = *reinterpret_cast<const frag_t*>(ta + (wm * 64 + i * 16 + frow) * 64 + fgrp * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], afr, bfr[j]);
         }
     }
 
@@ -247,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
                     for (int e = 0; e < 4; ++e)
                         Cs[(i * 16 + fgrp * 4 + e) * CS_LD + wn * 64 + j * 16 + frow] = acc[i][j][e];
         }
-        if (has_lora) {
+        if (has_lora && !lora_mma) {
             for (int idx = tid; idx < CS_ROWS * rp8; idx += 256) {
                 const int row = idx / rp8, j = idx % rp8;
                 const int gm = m0 + half * 64 + row;
@@ -285,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
                     for (int c = 0; c < 4; ++c) { v[i][c] = c0[c] + b0[c]; v[i][4 + c] = c1[c] + b1[c]; }
                 }
             }
-            if (has_lora) {
-                // rank-r update: this thread's 8 columns of the LoRA matrix stay in registers
+            if (has_lora && !lora_mma) {
+                // rank-r update (rank > 16): this thread's 8 columns of the LoRA matrix stay in registers
                 for (int j0 = 0; j0 < r; j0 += 8) {
                     float lreg[8][8];
 #pragma unroll
