@@ -57,6 +57,7 @@ class FedAvgAggregator:
         self.shared_half_s, self.beta, self.group = shared_half_s, beta, group
         self.global_prev = flat.detach().clone()            # w_g: the global weights before round 0
         self.buf = torch.empty_like(flat)
+        self._wcache = {}
         self.s_offsets = torch.tensor(
             [off for k, (off, shp) in offsets.items() if "lora_S" in k and shp[0] == num_groups],
             dtype=torch.int64, device=flat.device)
@@ -66,8 +67,13 @@ class FedAvgAggregator:
                   n_client_by_attr: Optional[Sequence[Sequence[int]]], epoch: int, max_epoch: int) -> Tensor:
         """All ranks call this at the round boundary; afterwards `flat` holds the new global
         weights on every rank (utils/fed_utils.py:98 semantic: w = (1-b)*avg + b*w_g)."""
-        w = element_weights(self.offsets, self.flat.numel(), client, participants, n_client, n_client_by_attr)
-        w = w.to(self.flat.device)
+        key = (client, tuple(participants), tuple(n_client),
+               None if n_client_by_attr is None else tuple(map(tuple, n_client_by_attr)))
+        w = self._wcache.get(key)
+        if w is None:                                       # the counts rarely change between rounds
+            w = element_weights(self.offsets, self.flat.numel(), client, participants, n_client,
+                                n_client_by_attr).to(self.flat.device)
+            self._wcache = {key: w}
         beta_decay = self.beta * (epoch / max(max_epoch, 1))
         use_half = self.shared_half_s and n_client_by_attr is not None
         if self.flat.is_cuda:
