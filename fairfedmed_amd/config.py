@@ -106,3 +106,10 @@ def vit_tiny(rank: int = 4, alpha: float = 2.0, num_groups: int = 3) -> ModelCfg
         lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups),
         eot=(9, 8),
     )
+
+
+def vit_tiny_3d(rank: int = 4, dim_per_3d_slice: int = 4, num_groups: int = 3) -> ModelCfg:
+    """vit_tiny with the 3D OCT front end (DATASET.MODALITY_TYPE 'oct_bscans'): every group of
+    `dim_per_3d_slice` B-scans goes through the trainable 5x5 conv (trainers/GLP_OT_SVLoRA.py:634-639)."""
+    import dataclasses
+    return dataclasses.replace(vit_tiny(rank=rank, num_groups=num_groups), dim_per_3d_slice=dim_per_3d_slice)

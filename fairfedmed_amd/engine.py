@@ -206,6 +206,20 @@ class FairLoRAEngine:
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
         self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.is3d = cfg.dim_per_3d_slice > 0
+        if self.is3d:
+            D, H = cfg.dim_per_3d_slice, v.image_size
+            nblk = ops.slice_blocks(H, H)
+            self.conv_out = torch.zeros(max_images, 3, H, H, device=dev, dtype=f32)
+            self.dconv = torch.zeros_like(self.conv_out)
+            self.mm_part = torch.zeros(max_images * nblk * 2, device=dev, dtype=f32)
+            self.mnmx = torch.zeros(max_images, 2, device=dev, dtype=f32)
+            self.mm_cnt = torch.zeros(max_images, 2, device=dev, dtype=torch.int32)
+            self.ab_part = torch.zeros(max_images * ops.slice_bwd_ab_blocks() * 2, device=dev, dtype=f32)
+            self.gmm = torch.zeros(max_images, 2, device=dev, dtype=f32)
+            self.wpart = torch.zeros(max_images * nblk * (3 * D * 25 + 3), device=dev, dtype=f32)
+            self.dcols = torch.zeros_like(self.cols)
+            self.dpatch = torch.zeros_like(self.patch_out)
         self.step_plans: Dict[tuple, list] = {}
         self.use_replay = True                        # replay recorded launch plans (host-side "graph")
         self.eot_rows = torch.tensor([i * t.context_length + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
@@ -277,6 +291,8 @@ class FairLoRAEngine:
                 cur.copy_(val)
 
         put("conv_w", self._w(sd[ie + "conv1.weight"].reshape(v.width, -1)))
+        if cfg.dim_per_3d_slice:
+            put("conv_w_t", self._wt(sd[ie + "conv1.weight"].reshape(v.width, -1)))   # dX of the patch embedding
         put("cls", self._w(sd[ie + "class_embedding"]))
         put("pos", self._w(sd[ie + "positional_embedding"]))
         put("lnpre", (self._f(sd[ie + "ln_pre.weight"]), self._f(sd[ie + "ln_pre.bias"])))
@@ -399,14 +415,15 @@ class FairLoRAEngine:
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
         if r:
             with self._on(self.grad_stream):
-                self._reduce_plan(st, rows).run()
+                self._reduce_plan(st, rows, need_input_grad).run()
             self._ev_record(self.ev_grads, self.grad_stream)
             self._ev_wait(main, self.ev_grads)
         return g
 
-    def _reduce_plan(self, st: _Stack, rows: int):
+    def _reduce_plan(self, st: _Stack, rows: int, full_bwd: bool = False):
         """Descriptor table (built once per row count) that sums every layer's partials into params.grad."""
-        if rows not in st.plans:
+        key = (rows, full_bwd)
+        if key not in st.plans:
             r, G, w = st.rank, self.cfg.lora.num_groups, st.width
             nsp = ops.lora_grad_splits(rows)
             ent = []
@@ -415,13 +432,13 @@ class FairLoRAEngine:
                 # dS partial rows: GEMM row tiles when the down projection is fused, lora_down blocks otherwise
                 # (block 0's c_fc has no dX GEMM, so it always uses the stand-alone kernel)
                 nb_p = ops.gemm_tiles_m(rows) if self.fused_rank else ops.lora_down_blocks(rows, w, r, self.dtype)
-                nb_f = ops.gemm_tiles_m(rows) if (self.fused_rank and li > 0) \
+                nb_f = ops.gemm_tiles_m(rows) if (self.fused_rank and (li > 0 or full_bwd)) \
                     else ops.lora_down_blocks(rows, 4 * w, r, self.dtype)
                 ent += [(pt["proj_S"], nb_p, G * r, gv("proj_S"), 0, 0), (pt["fc_S"], nb_f, G * r, gv("fc_S"), 0, 0),
                         (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),
                         (pt["fc_B"], nsp, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
-            st.plans[rows] = ops.ReducePlan(ent, self.device)
-        return st.plans[rows]
+            st.plans[key] = ops.ReducePlan(ent, self.device)
+        return st.plans[key]
 
     # ------------------------------------------------------------ replay --
     # A training step is a fixed sequence of C launches over static buffers plus a few host-side
@@ -519,13 +536,14 @@ class FairLoRAEngine:
         if not image.is_cuda or image.dtype != torch.float32:
             raise TypeError("image must be a float32 CUDA tensor of raw 0..255 values")
         b, c, h, w = image.shape
-        if cfg.dim_per_3d_slice:
-            raise NotImplementedError("3D OCT slice projection is not built yet (SURVEY.md §8 a4)")
-        if c != 3 or h != v.image_size or w != v.image_size:
-            raise ValueError(f"expected [B,3,{v.image_size},{v.image_size}], got {tuple(image.shape)}")
-        if b > self.max_images:
-            raise ValueError(f"batch {b} exceeds the engine's max_images={self.max_images}")
-        return b, 1
+        D = cfg.dim_per_3d_slice
+        if h != v.image_size or w != v.image_size or (not D and c != 3) or (D and c % D):
+            raise ValueError(f"expected [B,{'S*%d' % D if D else 3},{v.image_size},{v.image_size}], "
+                             f"got {tuple(image.shape)}")
+        S = c // D if D else 1                       # slices per sample: the ViT batch is b*S (:683-684)
+        if b * S > self.max_images:
+            raise ValueError(f"{b * S} ViT images exceed the engine's max_images={self.max_images}")
+        return b, S
 
     def _load_inputs(self, image: Tensor, attr: Optional[Tensor], label: Optional[Tensor]):
         """Per-step inputs -> static buffers (these three launches are the only ones not replayed)."""
@@ -533,7 +551,16 @@ class FairLoRAEngine:
         b, S = self._check_batch(image)
         images = b * S
         P = v.grid * v.grid
-        ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
+        if self.is3d:
+            # trainable 5x5 slice conv + per-image min-max (trainers/GLP_OT_SVLoRA.py:681-690), then the patches
+            self._image = image.contiguous()
+            ops.slice_conv_fwd(self._image, self.params.view("proj_per_3d_slice.weight"),
+                               self.params.view("proj_per_3d_slice.bias"), self.conv_out[:images], self.mm_part,
+                               self.mnmx, self.mm_cnt, cfg.dim_per_3d_slice)
+            ops.patchify_minmax(self.conv_out[:images], self.mnmx, self.mm_cnt, self.cols[:images * P], v.patch,
+                                cfg.pixel_mean, cfg.pixel_std)
+        else:
+            ops.patchify(image.contiguous(), self.cols[:images * P], v.patch, cfg.pixel_mean, cfg.pixel_std)
         if attr is not None:
             self.attr_i32[:b].copy_(attr)
         if label is not None:
@@ -593,7 +620,13 @@ class FairLoRAEngine:
         ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
         ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
                           self.post_stats[1], None, self.vis.g[:rows])
-        self._stack_backward(self.vis, rows, images, a32, L * S, False)
+        self._stack_backward(self.vis, rows, images, a32, L * S, self.is3d)
+        if self.is3d:
+            # dL/d(tokens) -> ln_pre / pos-add backward -> dX of the patch embedding (columns of the patches)
+            P = v.grid * v.grid
+            ops.embed_lnpre_bwd(self.vis.g[:rows], self.patch_out[:images * P], self.pos, self.lnpre[0],
+                                self.dpatch[:images * P], images, L)
+            ops.gemm_nt(self.dpatch[:images * P], self.conv_w_t, self.dcols[:images * P])
         self._ev_wait(main, self.ev_text_bwd)
 
     def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:
@@ -614,6 +647,16 @@ class FairLoRAEngine:
                 self.step_plans[key] = plan
             else:
                 self._step_body(b, S, attr is not None)
+            if self.is3d:
+                images, P, D = b * S, self.cfg.vision.grid ** 2, self.cfg.dim_per_3d_slice
+                ops.slice_bwd(self.dcols[:images * P], self._image, self.conv_out[:images], self.mnmx, self.mm_cnt,
+                              self.dconv[:images], self.ab_part, self.gmm, self.wpart, D, self.cfg.vision.patch,
+                              self.cfg.pixel_std)
+                nw = 3 * D * 25 + 3
+                off = self.params.offsets["proj_per_3d_slice.weight"][0]
+                assert self.params.offsets["proj_per_3d_slice.bias"][0] == off + nw - 3
+                nblk = ops.slice_blocks(self.cfg.vision.image_size, self.cfg.vision.image_size)
+                ops.reduce_partials(self.wpart, images * nblk, nw, self.params.grad[off:off + nw])
         return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
 
     @torch.no_grad()

@@ -188,6 +188,50 @@ def embed_lnpre(patch: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Te
     return x
 
 
+def slice_blocks(H: int, W: int) -> int:
+    return L.load().ffm_slice_blocks(H, W)
+
+
+def slice_bwd_ab_blocks() -> int:
+    return L.load().ffm_slice_bwd_ab_blocks()
+
+
+def slice_conv_fwd(img: Tensor, w: Tensor, bias: Tensor, conv: Tensor, mm_part: Tensor, mnmx: Tensor, cnt: Tensor,
+                   D: int) -> None:
+    """img: fp32 [B, S*D, H, W] raw 0..255, read as [B*S, D, H, W]."""
+    _dev(img, w, bias, conv, mm_part, mnmx, cnt)
+    B, Cc, H, W = img.shape
+    assert img.dtype == torch.float32 and img.is_contiguous() and Cc % D == 0 and cnt.dtype == torch.int32
+    _call("ffm_slice_conv_fwd", L.ptr(img), L.ptr(_f32(w)), L.ptr(_f32(bias)), L.ptr(_f32(conv)), L.ptr(_f32(mm_part)),
+          L.ptr(_f32(mnmx)), L.ptr(cnt), B * Cc // D, D, H, W, L.stream_ptr())
+
+
+def patchify_minmax(conv: Tensor, mnmx: Tensor, cnt: Tensor, cols: Tensor, patch: int, mean3, std3) -> None:
+    _dev(conv, mnmx, cnt, cols)
+    N, _, H, W = conv.shape
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    _call("ffm_patchify_minmax", L.ptr(_f32(conv)), L.ptr(_f32(mnmx)), L.ptr(cnt), L.ptr(cols), N, H, W, patch, m, s,
+          L.dtype_code(cols.dtype), L.stream_ptr())
+
+
+def embed_lnpre_bwd(dx: Tensor, patch: Tensor, pos: Tensor, gamma: Tensor, dpatch: Tensor, B: int, Ltok: int) -> None:
+    _dev(dx, patch, pos, gamma, dpatch)
+    assert dx.dtype == patch.dtype == pos.dtype == dpatch.dtype
+    _call("ffm_embed_lnpre_bwd", L.ptr(dx), L.ptr(patch), L.ptr(pos), L.ptr(_f32(gamma)), L.ptr(dpatch), B, Ltok,
+          dx.shape[1], L.dtype_code(dx.dtype), L.stream_ptr())
+
+
+def slice_bwd(dcols: Tensor, img: Tensor, conv: Tensor, mnmx: Tensor, cnt: Tensor, dconv: Tensor, ab_part: Tensor,
+              gmm: Tensor, wpart: Tensor, D: int, patch: int, std3) -> None:
+    _dev(dcols, img, conv, mnmx, cnt, dconv, ab_part, gmm, wpart)
+    N, _, H, W = conv.shape
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    _call("ffm_slice_bwd", L.ptr(dcols), L.ptr(img), L.ptr(_f32(conv)), L.ptr(_f32(mnmx)), L.ptr(cnt), L.ptr(_f32(dconv)),
+          L.ptr(_f32(ab_part)), L.ptr(_f32(gmm)), L.ptr(_f32(wpart)), N, D, H, W, patch, s, L.dtype_code(dcols.dtype),
+          L.stream_ptr())
+
+
 def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok: int, heads: int,
                   causal: bool = False) -> Tensor:
     _dev(qkv, out, lse)

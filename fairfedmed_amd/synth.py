@@ -178,17 +178,16 @@ def make_state_dict(cfg: ModelCfg, seed: int = 1, lora_init: str = "reference") 
     return sd
 
 
-def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0):
+def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0, slices: int = 2):
     """Synthetic batch in the reference's dict contract:
-    img f32 [B,C,H,W] raw 0..255, label i64 [B], attrs i64 [B,1].
+    img f32 [B,C,H,W] raw 0..255 (C = 3, or slices*dim_per_3d_slice for 3D OCT), label i64 [B], attrs i64 [B,1].
 
     signal > 0 adds a label-dependent mean shift on a fixed patch mask and a
     group-dependent contrast, so AUC can move off 0.5."""
     g = np.random.Generator(np.random.Philox(key=[0xBA7C4, seed & 0xFFFFFFFF]))
     v = cfg.vision
-    c = 3 if not cfg.dim_per_3d_slice else None
-    assert c is not None, "use make_batch_3d for 3D inputs"
-    img = g.random((batch, 3, v.image_size, v.image_size), dtype=np.float32)
+    c = 3 if not cfg.dim_per_3d_slice else slices * cfg.dim_per_3d_slice   # 3D OCT: `slices` groups of B-scans
+    img = g.random((batch, c, v.image_size, v.image_size), dtype=np.float32)
     label = g.integers(0, cfg.n_cls, size=(batch,), dtype=np.int64)
     attr = g.integers(0, cfg.lora.num_groups, size=(batch,), dtype=np.int64)
     if signal > 0:

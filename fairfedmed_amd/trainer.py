@@ -66,6 +66,9 @@ class _Loader:
         return len(self.dataset.batches)
 
 
+MODALITIES_3D = {"oct_bscans", "oct_bscans_3d", "mac_onh", "onh_mac"}
+
+
 class SyntheticFedData:
     """Per-client train/test loaders of synthetic batches (what the reference's DataManager
     exposes as fed_{train,test}_loader_x_dict, Dassl/dassl/data/data_manager.py:104-133)."""
@@ -136,10 +139,13 @@ class GLP_OT_SVLoRA:
         except KeyError as e:
             raise NotImplementedError(f"EOT position of class prompt {e} is not pinned (tokenizer is out of scope)")
         base = C.vit_b16() if cfg.MODEL.BACKBONE.NAME in ("ViT-B/16", "vit_b16") else getattr(cfg.MODEL, "GEOMETRY")
+        # 3D modalities go through the trainable per-slice conv (trainers/GLP_OT_SVLoRA.py:584-586)
+        is_3d = getattr(cfg.DATASET, "MODALITY_TYPE", "slo_fundus") in MODALITIES_3D
         return C.ModelCfg(vision=base.vision, text=base.text,
                           lora=C.LoraCfg(rank=lora.RANK, alpha=lora.ALPHA, num_groups=G),
                           n_prompts=cfg.TRAINER.GLP_OT.N, n_ctx=cfg.TRAINER.GLP_OT.N_CTX, n_cls=len(names), eot=eot,
-                          pixel_mean=tuple(cfg.INPUT.PIXEL_MEAN), pixel_std=tuple(cfg.INPUT.PIXEL_STD))
+                          pixel_mean=tuple(cfg.INPUT.PIXEL_MEAN), pixel_std=tuple(cfg.INPUT.PIXEL_STD),
+                          dim_per_3d_slice=cfg.DATASET.DIM_PER_3D_SLICE if is_3d else 0)
 
     # ------------------------------------------------------------- model --
     def build_model(self):
@@ -152,6 +158,10 @@ class GLP_OT_SVLoRA:
             # pretrained CLIP cannot be downloaded here (trainers/GLP_OT_SVLoRA.py:23-43 needs network)
             sd = synth.make_state_dict(mcfg, seed=getattr(cfg, "SEED", 1), lora_init="reference")
         bs = max(cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.TEST.BATCH_SIZE)
+        if mcfg.dim_per_3d_slice:
+            # every sample becomes C / DIM_PER_3D_SLICE ViT images; the volume depth comes from the data
+            first = next(iter(self.fed_train_loader_x_dict[min(self.fed_train_loader_x_dict)]))
+            bs *= first["img"].shape[1] // mcfg.dim_per_3d_slice
         self.model = CustomCLIP(mcfg, sd, dtype=dtype, max_images=bs, device=str(self.device))
         self.engine = self.model.engine
         o = cfg.OPTIM

@@ -139,6 +139,31 @@ int ffm_embed_lnpre(const void* patch, const void* cls, const void* pos, const f
                     const float* beta, void* x, int B, int L, int width, int dtype, void* stream);
 
 /*
+ * 3D OCT input path (trainers/GLP_OT_SVLoRA.py:585-595, 681-693; BASELINE.json configs[3]).
+ * img: fp32 [N = B*S, D, H, W] raw 0..255 (the reference's reshape(-1, D, h, w) view of [B, S*D, H, W]).
+ *   ffm_slice_conv_fwd   conv = conv5x5(img/255; w [3,D,5,5], bias [3], pad 2) fp32 [N,3,H,W]; per-image
+ *                        mnmx [N,2] = {min, max} over (3,H,W); cnt [N,2] zeroed (tie counters);
+ *                        mm_part: scratch [N * ffm_slice_blocks(H,W) * 2]
+ *   ffm_patchify_minmax  cols = patches of ((conv - min)/(max - min + 1e-5) - mean)/std; counts the tied extrema
+ *   ffm_embed_lnpre_bwd  backward of ffm_embed_lnpre w.r.t. the patch rows (class token / pos are frozen)
+ *   ffm_slice_bwd        dcols [N*P, 3*ps*ps] -> gradient partials of the conv weight and bias:
+ *                        wpart [N * ffm_slice_blocks(H,W)][3*D*25 + 3] (reduce with ffm_reduce_partials);
+ *                        scratch: dconv [N,3,H,W], ab_part [N * ffm_slice_bwd_ab_blocks() * 2], gmm [N,2]
+ * mean3 / std3 are HOST pointers.
+ */
+int ffm_slice_blocks(int H, int W);
+int ffm_slice_bwd_ab_blocks(void);
+int ffm_slice_conv_fwd(const float* img, const float* w, const float* bias, float* conv, float* mm_part,
+                       float* mnmx, int32_t* cnt, int N, int D, int H, int W, void* stream);
+int ffm_patchify_minmax(const float* conv, const float* mnmx, int32_t* cnt, void* cols, int N, int H, int W,
+                        int patch, const float* mean3, const float* std3, int dtype, void* stream);
+int ffm_embed_lnpre_bwd(const void* dx, const void* patch, const void* pos, const float* gamma, void* dpatch,
+                        int B, int L, int width, int dtype, void* stream);
+int ffm_slice_bwd(const void* dcols, const float* img, const float* conv, const float* mnmx, const int32_t* cnt,
+                  float* dconv, float* ab_part, float* gmm, float* wpart, int N, int D, int H, int W, int patch,
+                  const float* std3, int dtype, void* stream);
+
+/*
  * Multi-head self-attention core, softmax(Q K^T / sqrt(64)) V, head_dim 64,
  * optional causal mask (text tower, clip/model.py:562-568); no dropout.
  * qkv: [B*L, 3*heads*64] rows (b,l) with q|k|v concatenated as nn.MultiheadAttention's

@@ -222,6 +222,8 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
     tr.model = model
     tr.device = torch.device("cpu")
     params = list(model.prompt_learner.parameters()) + list(model.image_encoder.parameters())
+    if mcfg.dim_per_3d_slice:
+        params += list(model.proj_per_3d_slice.parameters())      # trainers/GLP_OT_SVLoRA.py:862-863
     tr.optim = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, dampening=0, nesterov=False)
     tr.sched = torch.optim.lr_scheduler.StepLR(tr.optim, step_size=200, gamma=0.1)
     from collections import OrderedDict
@@ -324,6 +326,10 @@ def main():
     golden_model(M, CLIP, C.vit_tiny(rank=8, num_groups=2), "tiny_r8g2", 6, 2, out, meta)
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_refinit", 8, 3, out, meta, lora_init="reference")
     np.savez_compressed(os.path.join(HERE, "tiny.npz"), **out)
+
+    out = {}   # 3D OCT front end: 6 samples x 2 slice groups of 4 B-scans -> 12 ViT images
+    golden_model(M, CLIP, C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), "tiny3d_r4", 6, 3, out, meta)
+    np.savez_compressed(os.path.join(HERE, "tiny3d.npz"), **out)
 
     if args.vitb:
         out = {}

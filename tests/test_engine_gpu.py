@@ -34,6 +34,15 @@ def make_engine(mcfg, sd, dtype, max_images):
     return FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=max_images)
 
 
+def gold_file(mcfg):
+    return "tiny3d.npz" if mcfg.dim_per_3d_slice else "tiny.npz"
+
+
+def vit_images(mcfg, bs, slices=2):
+    """3D OCT: every sample contributes `slices` ViT images (synth.make_batch default)."""
+    return bs * slices if mcfg.dim_per_3d_slice else bs
+
+
 def to_dev(batch):
     return batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda()
 
@@ -42,16 +51,17 @@ def to_dev(batch):
     ("tiny_r4", C.vit_tiny(rank=4), 8, "random"),
     ("tiny_r8g2", C.vit_tiny(rank=8, num_groups=2), 6, "random"),
     ("tiny_refinit", C.vit_tiny(rank=4), 8, "reference"),
+    ("tiny3d_r4", C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random"),   # 3D OCT: 6 samples x 2 slice groups
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
     from oracle import fairlora_oracle as O
-    gold = np.load(os.path.join(golden_dir, "tiny.npz"))
+    gold = np.load(os.path.join(golden_dir, gold_file(mcfg)))
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
     sd = synth.make_state_dict(mcfg, seed=1, lora_init=init)
     batch = synth.make_batch(mcfg, bs, seed=1234)
     keys = synth.trainable_keys(mcfg)
-    eng = make_engine(mcfg, sd, dtype, bs)
+    eng = make_engine(mcfg, sd, dtype, vit_images(mcfg, bs))
     img, attr, label = to_dev(batch)
     out = eng.forward_backward(img, attr, label)
     torch.cuda.synchronize()
@@ -86,14 +96,15 @@ def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
 
 
 @pytest.mark.parametrize("tag,mcfg,bs,init", [("tiny_r4", C.vit_tiny(rank=4), 8, "random"),
-                                              ("tiny_refinit", C.vit_tiny(rank=4), 8, "reference")])
+                                              ("tiny_refinit", C.vit_tiny(rank=4), 8, "reference"),
+                                              ("tiny3d_r4", C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random")])
 def test_tiny_trajectory_fp32(golden_dir, tag, mcfg, bs, init):
     """K SGD steps: loss trajectory and final trainable tensors vs the reference's forward_backward."""
-    gold = np.load(os.path.join(golden_dir, "tiny.npz"))
+    gold = np.load(os.path.join(golden_dir, gold_file(mcfg)))
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
     sd = synth.make_state_dict(mcfg, seed=1, lora_init=init)
     batch = synth.make_batch(mcfg, bs, seed=1234)
-    eng = make_engine(mcfg, sd, torch.float32, bs)
+    eng = make_engine(mcfg, sd, torch.float32, vit_images(mcfg, bs))
     img, attr, label = to_dev(batch)
     for ref in meta[f"{tag}.traj"]:
         out = eng.forward_backward(img, attr, label)

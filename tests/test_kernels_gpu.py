@@ -186,6 +186,72 @@ def test_patchify_and_embed(ops, dt):
     check(xt, ref.reshape(-1, width), tol(dt), "embed+ln_pre")
 
 
+
+# ------------------------------------------------- 3D OCT slice front end ---
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("N,D,H,ps,width", [(4, 4, 64, 16, 128), (3, 8, 96, 16, 256), (2, 2, 224, 16, 768)])
+def test_slice3d_front_end(ops, dt, N, D, H, ps, width):
+    """conv5x5 + per-image min-max + patchify, and their backward down to the conv weight/bias gradient,
+    against torch autograd in fp64 (trainers/GLP_OT_SVLoRA.py:681-693)."""
+    F = torch.nn.functional
+    img = torch.rand(1, N * D, H, H, device="cuda", generator=torch.Generator("cuda").manual_seed(31)) * 255
+    w = rnd(3, D, 5, 5, scale=D ** -0.5, seed=32)
+    b = rnd(3, scale=0.1, seed=33)
+    mean3, std3 = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    P = (H // ps) ** 2
+    nblk = ops.slice_blocks(H, H)
+    conv = torch.empty(N, 3, H, H, device="cuda")
+    mm_part = torch.empty(N * nblk * 2, device="cuda")
+    mnmx = torch.empty(N, 2, device="cuda")
+    cnt = torch.full((N, 2), 77, device="cuda", dtype=torch.int32)
+    cols = torch.empty(N * P, 3 * ps * ps, device="cuda", dtype=dt)
+    ops.slice_conv_fwd(img, w, b, conv, mm_part, mnmx, cnt, D)
+    ops.patchify_minmax(conv, mnmx, cnt, cols, ps, mean3, std3)
+
+    wd, bd = w.double().requires_grad_(), b.double().requires_grad_()
+    x = (img.double() / 255.0).reshape(-1, D, H, H)
+    c = F.conv2d(x, wd, bd, padding=2)
+    mn, mx = c.amin(dim=(1, 2, 3), keepdim=True), c.amax(dim=(1, 2, 3), keepdim=True)
+    y = (c - mn) / (mx - mn + 1e-5)
+    z = (y - torch.tensor(mean3, device="cuda", dtype=torch.float64).view(1, 3, 1, 1)) \
+        / torch.tensor(std3, device="cuda", dtype=torch.float64).view(1, 3, 1, 1)
+    ref_cols = F.unfold(z, kernel_size=ps, stride=ps).transpose(1, 2).reshape(N * P, -1)
+    check(conv, c.detach(), 2e-6, "slice conv")
+    check(mnmx[:, 0], mn.flatten().detach(), 2e-6, "min")
+    check(mnmx[:, 1], mx.flatten().detach(), 2e-6, "max")
+    check(cols, ref_cols.detach(), 2e-5 if dt == torch.float32 else 8e-3, "patchify_minmax")
+    assert cnt.tolist() == [[1, 1]] * N                      # random floats: the extrema are unique
+
+    dcols = rnd(N * P, 3 * ps * ps, dt=dt, seed=34)
+    ref_cols.backward(dcols.double())
+    dconv = torch.empty_like(conv)
+    ab_part = torch.empty(N * ops.slice_bwd_ab_blocks() * 2, device="cuda")
+    gmm = torch.empty(N, 2, device="cuda")
+    nw = 3 * D * 25 + 3
+    wpart = torch.empty(N * nblk * nw, device="cuda")
+    ops.slice_bwd(dcols, img, conv, mnmx, cnt, dconv, ab_part, gmm, wpart, D, ps, std3)
+    got = torch.empty(nw, device="cuda")
+    ops.reduce_partials(wpart, N * nblk, nw, got)
+    check(got[:nw - 3].reshape(3, D, 5, 5), wd.grad, 2e-4, "slice conv dW")
+    check(got[nw - 3:], bd.grad, 2e-4, "slice conv dbias")
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_embed_lnpre_bwd(ops, dt):
+    B, P, width = 3, 16, 128
+    patch = rnd(B * P, width, dt=dt, seed=41)
+    cls, pos = rnd(width, dt=dt, scale=0.1, seed=42), rnd(P + 1, width, dt=dt, scale=0.1, seed=43)
+    gamma, beta = 1 + 0.1 * rnd(width, seed=44), 0.1 * rnd(width, seed=45)
+    dx = rnd(B * (P + 1), width, dt=dt, seed=46)
+    pd = patch.double().requires_grad_()
+    tok = torch.cat([cls.double().expand(B, 1, width), pd.reshape(B, P, width)], 1) + pos.double()
+    y = torch.nn.functional.layer_norm(tok, (width,), gamma.double(), beta.double(), 1e-5)
+    y.backward(dx.double().reshape(B, P + 1, width))
+    dpatch = torch.empty_like(patch)
+    ops.embed_lnpre_bwd(dx, patch, pos, gamma, dpatch, B, P + 1)
+    check(dpatch, pd.grad, tol(dt), "embed+ln_pre backward")
+
+
 # ------------------------------------------------------------- attention ---
 def ref_attention(qkv, B, L, heads, causal):
     E = heads * 64

@@ -109,13 +109,14 @@ TINY = {
     "tiny_r4": (C.vit_tiny(rank=4), 8, "random"),
     "tiny_r8g2": (C.vit_tiny(rank=8, num_groups=2), 6, "random"),
     "tiny_refinit": (C.vit_tiny(rank=4), 8, "reference"),
+    "tiny3d_r4": (C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random"),      # 3D OCT front end (§8 a4)
 }
 
 
 @pytest.mark.parametrize("tag", list(TINY))
 def test_tiny_model_step_and_trajectory(golden_dir, meta, tag):
     mcfg, bs, init = TINY[tag]
-    gold = np.load(os.path.join(golden_dir, "tiny.npz"))
+    gold = np.load(os.path.join(golden_dir, "tiny3d.npz" if mcfg.dim_per_3d_slice else "tiny.npz"))
     sd = synth.make_state_dict(mcfg, seed=1, lora_init=init)
     batch = synth.make_batch(mcfg, bs, seed=1234)
     keys = synth.trainable_keys(mcfg)

@@ -87,6 +87,35 @@ def make_cfg(prec="fp32", rank=4, bs=8):
     )
 
 
+def test_trainer_3d_oct_trajectory(golden_dir):
+    """DATASET.MODALITY_TYPE 'oct_bscans': the trainable per-slice conv trains with the LoRA factors
+    (trainers/GLP_OT_SVLoRA.py:584-595, 862-863); trajectory of the reference's forward_backward."""
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData, _ListDataset, _Loader
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    gold = np.load(os.path.join(golden_dir, "tiny3d.npz"))
+    mcfg = C.vit_tiny_3d(rank=4, dim_per_3d_slice=4)
+    cfg = make_cfg(bs=6)
+    cfg.DATASET.MODALITY_TYPE, cfg.DATASET.DIM_PER_3D_SLICE = "oct_bscans", 4
+    data = SyntheticFedData(mcfg, 1, 1, 1, 6)
+    batch = synth.make_batch(mcfg, 6, seed=1234)
+    data.fed_train_loader_x_dict[0] = _Loader(_ListDataset([batch], ["race"], {"race": 3}))
+    cfg.DATA = data
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    tr = build_trainer(cfg)
+    assert tr.engine.is3d and tr.engine.max_images == 12
+    tr.num_batches = 10 ** 9
+    for i, ref in enumerate(meta["tiny3d_r4.traj"]):
+        tr.batch_idx = i
+        s = tr.forward_backward(batch)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (s, ref)
+        assert abs(s["acc"] - ref["acc"]) < 1e-3 and abs(s["auc"] - ref["auc"]) < 1e-9
+    sd = tr.model.state_dict()
+    for k in ("proj_per_3d_slice.weight", "proj_per_3d_slice.bias"):
+        ref = torch.from_numpy(gold[f"tiny3d_r4.post.{k}"])
+        assert float((sd[k].cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, k
+
+
 def test_trainer_reproduces_reference_trajectory(golden_dir):
     """forward_backward through the registry-built trainer == the reference's forward_backward trajectory."""
     from fairfedmed_amd.registry import build_trainer
