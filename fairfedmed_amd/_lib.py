@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libffm_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("bias", _vp), ("ts", _vp), ("lw", _vp), ("res", _vp), ("c2", _vp), ("aux", _vp),
         ("rk", _vp), ("S", _vp), ("attr", _vp), ("t_out", _vp), ("ts_out", _vp), ("t_fwd", _vp), ("ds_part", _vp),
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
+        ("b_packed", _vp),
     ]
 
 
@@ -46,7 +47,8 @@ class ReduceDesc(C.Structure):
 SIGNATURES = {
     "ffm_abi_version": [],
     "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
-    "ffm_gemm_tiles_m": [_i32],
+    "ffm_gemm_tiles_m": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "ffm_pack_b": [_vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_multi": [_vp, _i32, _i32, _i32, _vp],
     "ffm_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],

@@ -9,7 +9,7 @@
 // global_load_lds writes LDS linearly in lane order, so the swizzle is applied
 // to the per-lane SOURCE address (lane -> row r = l>>3, slot p = l&7 reads
 // global chunk p ^ (r&7)) and again on the ds_read side.
-#include "common.h"
+#include "gemm_panel.h"
 
 namespace {
 
@@ -489,6 +489,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (a.b_packed) {
+        const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);
+        if (cfg >= 0) return ffm_panel_launch(a, cfg, s);
+    }
     const int fl = a.flags & ~FFM_EPI_RANKOP;
 #define FFM_GEMM_CASE(RKB, F) \
     case F: return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
@@ -517,7 +521,11 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
 #undef FFM_GEMM_CASE
 }
 
-extern "C" int ffm_gemm_tiles_m(int M) { return (M + BM - 1) / BM; }
+extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {
+    const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
+    const int bm = cfg >= 0 ? 16 * FFM_PANEL_CFGS[cfg].mf : BM;
+    return (M + bm - 1) / bm;
+}
 
 extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream) {
     if (!descs_dev || ndesc <= 0 || max_K <= 0) return FFM_EINVAL;

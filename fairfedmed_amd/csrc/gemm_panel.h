@@ -1,0 +1,19 @@
+// Internal interface between gemm.hip (dispatcher, 128x128 kernel) and gemm_panel*.hip (panel kernel).
+#pragma once
+#include "common.h"
+
+// Panel-kernel tile configurations: block tile (16*MF) x (64*NF), 4 waves side by side along N, 16*NF columns each.
+struct ffm_panel_cfg {
+    int mf, nf;
+};
+// (MF is chosen so that the A-ring pieces, 2*MF (+2 rank rows under FFM_EPI_RANKOP), split evenly over the 4 waves.)
+struct ffm_panel_cfg_ex {
+    int mf, nf;
+    bool rankop;     // instantiated for FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
+};
+constexpr int FFM_PANEL_NCFG = 4;
+constexpr ffm_panel_cfg_ex FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true}, {16, 4, false}, {10, 2, false}, {11, 2, true}};
+
+// -1: use the 128x128 kernel; otherwise the index into FFM_PANEL_CFGS
+int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);
+int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s);

@@ -318,6 +318,114 @@ int launch_grad(const void* x, int ldx, const float* v, int M, int K, int r, flo
     return FFM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// bf16 fast path of the same reduction on the matrix cores: part[split][k][j] = sum_rows x[row][k] * v[row][j]
+// is the product V^T [16 x rows] . X [rows x K] with the ROW index contracted, i.e. X is needed column-major.
+// One wave per block owns a 128-row x 128-column tile of X: 32 LDS-DMA pieces (4 rows x 256 B each) land it
+// row-major in LDS (coalesced from HBM), ds_read_b64_tr_b16 hands it to the MFMA B operand transposed, and v goes
+// into the A operand as a bf16 hi + lo pair (two MFMAs), so the result keeps fp32-level accuracy in v.
+// 32 KiB of LDS per block -> 5 blocks per CU: the whole 6304 x 3072 operand (24 x 50 = 1200 tiles) is in flight at
+// once and the kernel runs at the HBM rate instead of the load latency of a VALU loop.
+// LDS image: 256-byte rows, 16-byte chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) --
+// conflict-free for the transposed reads (cdna_hip_programming.md T10, image (b)).
+// ---------------------------------------------------------------------------
+constexpr int LGM_ROWS = 128, LGM_COLS = 128;
+
+__device__ __forceinline__ int lgm_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int RP>   // RP unused slots of the 16 rank slots are zero
+__global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                            const float* __restrict__ v, int M, int K, int r,
+                                                            float* __restrict__ part, int rs, int j0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int k0 = blockIdx.x * LGM_COLS, split = blockIdx.y, m0 = split * LGM_ROWS;
+
+    // ---- X tile -> LDS: piece = 4 rows; lane -> row 4*piece + (lane >> 4), LDS slot lane & 15
+#pragma unroll
+    for (int piece = 0; piece < LGM_ROWS / 4; ++piece) {
+        const int row = piece * 4 + (lane >> 4);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;                              // clamped rows meet v = 0 below
+        const int ch = (lane & 15) ^ lgm_swz(row);
+        const bf16_t* src = x + (size_t)gm * ldx + k0 + ch * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, 0, 0);
+    }
+    // ---- v -> A fragments (rank slot j = lane & 15, rows 8*(lane >> 4) .. +7 of each 32-row block), hi + lo
+    const int j = lane & 15, kg = lane >> 4;
+    bf16x8 ahi[4], alo[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        float vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int gm = m0 + rb * 32 + kg * 8 + t;
+            vv[t] = (j < r && gm < M) ? v[(size_t)gm * rs + j0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bf16_t h = (bf16_t)vv[t];
+            ahi[rb][t] = h;
+            alo[rb][t] = (bf16_t)(vv[t] - (float)h);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // single wave: orders the DMA writes before the reads
+
+    // ---- 8 column fragments x 4 row blocks; B fragment = two transposed reads (rows 8kg..8kg+3, 8kg+4..8kg+7)
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    f32x4 acc[LGM_COLS / 16];
+#pragma unroll
+    for (int cf = 0; cf < LGM_COLS / 16; ++cf) acc[cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int R = rb * 32 + kg * 8 + q;
+        const uint32_t base0 = (uint32_t)(uintptr_t)smem + 256 * R + 8 * (pp & 1);
+        const uint32_t base1 = base0 + 256 * 4;
+        const int s0 = lgm_swz(R), s1 = lgm_swz(R + 4);
+        // all 16 transposed reads of the row block are issued before the single wait
+        u32x2 lo2[LGM_COLS / 16], hi2[LGM_COLS / 16];
+#pragma unroll
+        for (int cf = 0; cf < LGM_COLS / 16; ++cf) {
+            const int ch = cf * 2 + (pp >> 1);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo2[cf]) : "v"(base0 + 16 * (ch ^ s0)) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi2[cf]) : "v"(base1 + 16 * (ch ^ s1)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int cf = 0; cf < LGM_COLS / 16; ++cf) {
+            asm volatile("" : "+v"(lo2[cf]), "+v"(hi2[cf]));
+            const u32x4 packed = {lo2[cf][0], lo2[cf][1], hi2[cf][0], hi2[cf][1]};
+            const bf16x8 b = __builtin_bit_cast(bf16x8, packed);
+            acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[rb], b, acc[cf], 0, 0, 0);
+            acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[rb], b, acc[cf], 0, 0, 0);
+        }
+    }
+    // ---- D[jrow = 4*(lane>>4) + e][col = lane & 15] -> part[split][k0 + 16 cf + col][j0 + jrow]
+    (void)RP;
+#pragma unroll
+    for (int cf = 0; cf < LGM_COLS / 16; ++cf) {
+        float* dst = part + ((size_t)split * K + k0 + cf * 16 + (lane & 15)) * rs + j0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int jj = 4 * kg + e;
+            if (jj < r) dst[jj] = acc[cf][e];
+        }
+    }
+}
+
+int launch_grad_mfma(const void* x, int ldx, const float* v, int M, int K, int r, float* part, int rs, int j0,
+                     hipStream_t s) {
+    dim3 grid(K / LGM_COLS, (M + LGM_ROWS - 1) / LGM_ROWS);
+    hipLaunchKernelGGL((lora_grad_mfma_kernel<16>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx, v, M,
+                       K, r, part, rs, j0);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
 // out[o(i)] (+)= sum_s part[s][i]; 4 split-lanes per output, combined by shuffles
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nsplit, int n,
                                                               float* __restrict__ out, int tK, int tr,
@@ -399,6 +507,13 @@ extern "C" int ffm_lora_grad_partial(const void* x, int ldx, const float* v, int
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
     if (((size_t)K * es) % 16 || ((size_t)ldx * es) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16 && K % LGM_COLS == 0) {             // matrix-core path (rank slots 16 at a time)
+        for (int j0 = 0; j0 < r; j0 += 16) {
+            const int e = launch_grad_mfma(x, ldx, v, M, K, (r - j0) < 16 ? (r - j0) : 16, part, r, j0, s);
+            if (e) return e;
+        }
+        return FFM_OK;
+    }
 #define GRAD(T, RP, RR, J0) launch_grad<T, RP>(x, ldx, v, M, K, RR, part, r, J0, s)
     if (r > 16) {
         int e = dtype == FFM_BF16 ? GRAD(bf16_t, 16, 16, 0) : GRAD(float, 16, 16, 0);

@@ -144,7 +144,7 @@ class _Stack:
             # (ffm_reduce_partials_multi) at the end of the backward pass
             ns = ops.lora_grad_splits(T)
             nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype),
-                     ops.gemm_tiles_m(T))
+                     ops.gemm_tiles_m(T))  # TODO-tiles
             self.part = [{"fc_A": f(ns * w * rank), "fc_B": f(ns * 4 * w * rank),
                           "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),
                           "fc_S": f(nb * 8 * rank), "proj_S": f(nb * 8 * rank)} for _ in range(layers)]

@@ -97,14 +97,26 @@ class RankOp:
         self.t_out, self.ts_out, self.t_fwd, self.ds_part = t_out, ts_out, t_fwd, ds_part
 
 
-def gemm_tiles_m(M: int) -> int:
-    return L.load().ffm_gemm_tiles_m(M)
+def gemm_tiles_m(M: int, N: int = 128, K: int = 128, flags: int = 0, rank: int = 0, dtype=torch.float32,
+                 packed: bool = False) -> int:
+    """Row tiles (= dS partial rows) of the kernel ffm_gemm_nt picks for this call."""
+    return L.load().ffm_gemm_tiles_m(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
+
+
+def pack_b(w: Tensor) -> Tensor:
+    """Frozen bf16 weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
+    _dev(w)
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    out = torch.empty(N * K, device=w.device, dtype=w.dtype)
+    _call("ffm_pack_b", L.ptr(w), L.ptr(out), N, K, w.stride(0), L.stream_ptr())
+    return out
 
 
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
-            gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None) -> Tensor:
-    """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype)."""
-    _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux)
+            gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None) -> Tensor:
+    """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional."""
+    _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
     assert a.dtype == b.dtype == out.dtype
     M, K = a.shape
     N = b.shape[0]
@@ -141,7 +153,9 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     else:
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
-                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra)
+                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
+                      L.ptr(b_packed))
+    assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
     _call("ffm_gemm_nt", C.byref(args), L.dtype_code(a.dtype), L.stream_ptr())
     return out
 

@@ -40,7 +40,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 2
+#define FFM_ABI_VERSION 3
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -77,6 +77,10 @@ typedef struct ffm_gemm_args {
     float*       ds_part;/* [ffm_gemm_tiles_m(M), G, r] */
     int32_t G, rows_per_sample;
     float scaling, lambda_group;
+    /* optional (bf16): the same matrix as `b` in MFMA-fragment order, written once by ffm_pack_b for FROZEN
+     * weights.  When present and the shape fills the chip in one round of large tiles, the panel kernel
+     * streams it straight into registers (csrc/gemm_panel.hip); `b` must still be valid. */
+    const void*  b_packed;
 } ffm_gemm_args;
 
 /*
@@ -89,7 +93,13 @@ typedef struct ffm_gemm_args {
  * Requires K*sizeof(dtype) % 128 == 0, N % 8 == 0, 16-byte aligned rows.
  */
 int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
-int ffm_gemm_tiles_m(int M);     /* row tiles (= dS partial rows written under FFM_EPI_RANKOP) */
+/* row tiles (= dS partial rows written under FFM_EPI_RANKOP) of the kernel ffm_gemm_nt picks for this call */
+int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed);
+/*
+ * dst = src [N, K] bf16 (row stride ld) in MFMA-fragment order: [N/16][K/32][64 lanes][8] with lane l holding
+ * row (l & 15), k-group (l >> 4).  N % 16 == 0, K % 32 == 0.  Load-time only (weights are frozen).
+ */
+int ffm_pack_b(const void* src, void* dst, int N, int K, int ld, void* stream);
 
 /*
  * Pack LoRA matrices into the GEMM's rank-operand form: dst [16, K] dtype with dst[j][k] = lora_A[k][j]
