@@ -523,8 +523,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
 
 extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {
     const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
-    const int bm = cfg >= 0 ? 16 * FFM_PANEL_CFGS[cfg].mf : BM;
-    return (M + bm - 1) / bm;
+    return cfg >= 0 ? ffm_panel_ds_rows(M, N, cfg) : (M + BM - 1) / BM;
 }
 
 extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream) {

@@ -3,17 +3,18 @@
 #include "common.h"
 
 // Panel-kernel tile configurations: block tile (16*MF) x (64*NF), 4 waves side by side along N, 16*NF columns each.
+// MF is chosen so that the A-ring pieces, 2*MF (+2 for the rank rows under FFM_EPI_RANKOP), split evenly over the
+// 4 waves (the counted vmcnt waits assume the same number of DMA pieces on every wave).
 struct ffm_panel_cfg {
     int mf, nf;
-};
-// (MF is chosen so that the A-ring pieces, 2*MF (+2 rank rows under FFM_EPI_RANKOP), split evenly over the 4 waves.)
-struct ffm_panel_cfg_ex {
-    int mf, nf;
-    bool rankop;     // instantiated for FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
+    bool rankop;     // instantiated for the FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
 };
 constexpr int FFM_PANEL_NCFG = 4;
-constexpr ffm_panel_cfg_ex FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true}, {16, 4, false}, {10, 2, false}, {11, 2, true}};
+constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true}, {16, 4, false}, {10, 2, false}, {11, 2, true}};
 
 // -1: use the 128x128 kernel; otherwise the index into FFM_PANEL_CFGS
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);
+// rows of dS partials the chosen kernel writes (tiles_m x tiles_n: every block owns a slice of its tile row)
+int ffm_panel_ds_rows(int M, int N, int cfg);
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s);
+int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s);      // gemm_panel_rk.hip

@@ -1,0 +1,513 @@
+// Panel GEMM for the vision tower's big products, C = epilogue(A * B^T), bf16 (instantiated by gemm_panel*.hip).
+//
+// Why a second GEMM kernel: with M = 32 * 197 = 6304 rows the 128x128 kernel (gemm.hip) reloads every operand
+// panel once per 128 output columns through the CU's 64 B/clk texture path, which is as busy as the MFMA pipe at
+// that tile size, and its two-buffer pipeline exposes the L2 latency of every K step.  This kernel
+//   * uses ONE block per CU with a tile of (16*MF) x (64*NF) chosen so that the whole product is a single round
+//     of <= 256 blocks (208 x 384 -> 31 x 8 = 248 blocks for N = 3072): half the operand bytes per flop;
+//   * streams the activation panel A through a 4-stage LDS ring (global_load_lds, 128-byte rows, XOR swizzle)
+//     with counted s_waitcnt vmcnt(N) and ONE raw s_barrier per 64-wide K step: three stages of loads in flight;
+//   * reads the FROZEN weight operand straight from HBM/L2 into VGPRs in MFMA-fragment order (ffm_pack_b writes
+//     that layout once at load time: every fragment is one contiguous, fully coalesced 1 KiB wave load), with a
+//     4-deep register ring, so the weights never pass through LDS;
+//   * runs 4 waves per block, ONE per SIMD, side by side along N (each wave owns 16*NF columns of all 16*MF rows,
+//     up to 13 x 6 accumulator fragments = 312 registers, which only fit at one wave per SIMD: 256 AGPRs + VGPRs):
+//     no two waves load the same weight fragment and the A fragments are the only LDS reads;
+//   * spreads its vector-memory instructions over the MFMA stream, one after each fragment row: a VMEM issue
+//     stalls the wave until the texture path accepts it, and with one wave per SIMD a burst of them would stall
+//     the matrix pipe too (measured: 0.7 us per K step before, 0.1 us after).
+// Measured on MI355X (tools/bench_panel.py): the main loop alone runs at ~2.0 PFLOP/s (the MFMA rate at the clock
+// the chip sustains); prologue, epilogue and the output burst of a single-round kernel are NOT overlapped with it.
+//
+// VMEM ordering contract (the counted waits depend on it): see the table in front of the main loop.
+#pragma once
+#include "gemm_panel.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace ffm_panel {
+
+constexpr int PW = 4;                      // waves per block: one per SIMD
+constexpr int PT = PW * 64;
+constexpr int PSTAGES = 4;                 // A ring depth (K64 stages)
+typedef bf16x8 frag_t;
+
+template <int MF, bool RK> struct PanelGeom {
+    static constexpr int NB8 = 2 * MF + (RK ? 2 : 0);        // 8-row x 128-B DMA pieces per stage (+16 rank rows)
+    static constexpr int NI = NB8 / PW;                      // pieces per wave, the same for all waves (counted waits)
+    static_assert(NB8 % PW == 0, "pick MF so that every wave issues the same number of DMA pieces");
+    static constexpr int STAGE = NB8 * 1024;
+    static constexpr int RING = PSTAGES * STAGE;
+};
+
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// a wave-uniform pointer the compiler can keep in SGPRs (inline-asm "s" operands must be scalar registers)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }                // floats
+// persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] f32 | row groups [BM]
+__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk) {
+    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + 1024 + 16 * mf * 4 : 0);
+}
+
+template <int MF, int NF, bool RK, int FL>
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_panel_kernel(ffm_gemm_args p, int dbg) {
+    using G = PanelGeom<MF, RK>;
+    constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
+    constexpr int flags = FL;
+    static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
+    static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = p.N / BNp;
+    const int tiles_m = (p.M + BMp - 1) / BMp;
+    const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = logical / tiles_n, tn = logical % tiles_n;
+    const int m0 = tm * BMp, n0 = tn * BNp, n0w = n0 + wave * WN;
+    const int KT = p.K >> 6;
+    const int frow = lane & 15, fgrp = lane >> 4;
+
+    // ---- A ring: per-lane source addresses of this wave's DMA pieces (piece = 8 rows x 128 B)
+    const int rsub = lane >> 3, slot = lane & 7;
+    const char* asrc[G::NI];
+#pragma unroll
+    for (int i = 0; i < G::NI; ++i) {
+        const int piece = wave + PW * i;
+        const int chunk = (slot ^ rsub) << 4;
+        if (RK && piece >= 2 * MF) {
+            const int row = (piece - 2 * MF) * 8 + rsub;
+            asrc[i] = reinterpret_cast<const char*>(p.rk) + (size_t)row * (size_t)p.K * 2 + chunk;
+        } else {
+            int grow = m0 + piece * 8 + rsub;
+            grow = grow < p.M ? grow : p.M - 1;              // clamped rows are never stored
+            asrc[i] = reinterpret_cast<const char*>(p.a) + (size_t)grow * (size_t)p.lda * 2 + chunk;
+        }
+    }
+    auto dma_piece = [&](int kt, int i) {                    // piece i of ring stage kt
+        char* dst = smem + ((kt & 3) * G::STAGE) + wave * 1024 + i * (PW * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 128),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto dma = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < G::NI; ++i) dma_piece(kt, i);
+    };
+
+    // ---- B: fragment-packed weights, [N/16][K/32][64 lanes][8]; fragment (nf, hs) of this wave sits at
+    // bbase + hs*1024 + boff[nf].  The loads are inline asm on purpose: the compiler's own waitcnt insertion
+    // answers a mix of LDS-DMA and ordinary loads on vmcnt with s_waitcnt vmcnt(0), which would drain the
+    // whole pipeline twice per step.  Every wait on vmcnt in the main loop is therefore counted by hand.
+    const int K32 = p.K >> 5;
+    const char* bbase = uniform_ptr(reinterpret_cast<const char*>(p.b_packed) + ((size_t)(n0w >> 4) * (size_t)K32) * 1024);
+    int boff[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) boff[nf] = lane * 16 + nf * K32 * 1024;
+    frag_t bq[4][NF];
+    auto loadB1 = [&](int hs, int nf, frag_t& dst) {
+        const char* sb = uniform_ptr(bbase + (size_t)hs * 1024);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(boff[nf]), "s"(sb) : "memory");
+    };
+    auto loadB = [&](int hs, frag_t (&dst)[NF]) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) loadB1(hs, nf, dst[nf]);
+    };
+    // after a counted wait: tie the fragments to this point so that no MFMA reading them is scheduled above it
+    auto tieB = [&](frag_t (&b)[NF]) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) asm volatile("" : "+v"(b[nf]));
+    };
+
+    // Accumulators: 16*MF x 16*NF per wave = MF*NF fragments of 4 registers.  The first 64 live in AGPRs (all 256
+    // of them), the rest in VGPRs; the MFMAs are inline asm with the accumulator tied in place (left to itself the
+    // register allocator rotates MFMA destinations through extra registers, which a 312-register tile cannot afford).
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](auto IDX_, f32x4& c, const frag_t& a, const frag_t& b) {
+        if constexpr (decltype(IDX_)::value < 64)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+        else
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    };
+    // RANKOP: t = A_rows . rk^T for the block's rows; wave w owns fragment rows w, w+4, ... (VGPR accumulators)
+    constexpr int TI = (MF + PW - 1) / PW;
+    constexpr bool WSPEC = RK && MF * NF <= 32;               // specialise the main loop per wave (t fragment rows)
+    f32x4 tacc[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) tacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int offA0 = frow * 128 + ((fgrp ^ (lane & 7)) << 4);
+    const int offA1 = offA0 ^ 64;
+    // One half-step: MF A fragments (double-buffered by hand) x NF MFMAs each.  After fragment row mf the wave issues
+    // ONE vector-memory instruction (issue(mf)).
+    auto half = [&](auto W_, const char* st, int off, const frag_t (&b)[NF], auto&& issue) {
+        // A fragments: a ring of AD + 1 registers, AD reads in flight.  One wave per SIMD has nobody to hide an LDS
+        // round trip behind: with NF MFMAs (16 cycles each) per fragment, AD * NF * 16 cycles must cover it.  The
+        // reads are inline asm with counted s_waitcnt lgkmcnt (LDS returns in order): the compiler's own insertion
+        // falls back to lgkmcnt(0) around the asm MFMAs and would wait for the prefetches too.
+        constexpr int AD = NF >= 6 ? 2 : (NF >= 4 ? 3 : 5);
+        const uint32_t sa = (uint32_t)(uintptr_t)st + (uint32_t)off;
+        auto lds_read = [](frag_t& dst, uint32_t addr, auto OFF_) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFF_)::value) : "memory");
+        };
+        frag_t a[AD + 1];
+        frag_t kf;                                  // RANKOP: the 16 rank rows ride behind the A rows of the stage
+        if constexpr (RK) lds_read(kf, sa, std::integral_constant<int, MF * 2048>{});
+        static_for<(AD < MF ? AD : MF)>([&](auto I_) { lds_read(a[decltype(I_)::value], sa, std::integral_constant<int, decltype(I_)::value * 2048>{}); });
+        f32x4(&tr)[TI] = tacc;                      // (named outside the if constexpr so that the lambdas capture it)
+        const int wv = wave;
+        static_for<MF>([&](auto MF_) {
+            constexpr int mf = decltype(MF_)::value;
+            if constexpr (mf + AD < MF) lds_read(a[(mf + AD) % (AD + 1)], sa, std::integral_constant<int, (mf + AD) * 2048>{});
+            {
+                constexpr int younger = (MF - 1 - mf) < AD ? (MF - 1 - mf) : AD;      // reads issued after a[mf]
+                if constexpr (RK && mf == 0)
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a[0]), "+v"(kf) : "n"(younger) : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[mf % (AD + 1)]) : "n"(younger) : "memory");
+            }
+            static_for<NF>([&](auto NF_) {
+                constexpr int nf = decltype(NF_)::value;
+                mma(std::integral_constant<int, mf * NF + nf>{}, acc[mf][nf], a[mf % (AD + 1)], b[nf]);
+            });
+            if constexpr (RK) {
+                // t fragment row mf belongs to wave mf % 4: one more MFMA on the fragment that is already in registers
+                // (asm, VGPR form: a builtin MFMA would be given AGPRs and evict accumulator fragments from them).
+                // The wave index is a template parameter of the loop: a run-time test here costs a taken branch per
+                // fragment row, 0.4 us per K step.
+                // (Tiles whose accumulators already fill the register file cannot afford four loop copies: they spill.)
+                if constexpr (WSPEC) {
+                    if constexpr ((mf & (PW - 1)) == decltype(W_)::value)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                } else {
+                    if ((mf & (PW - 1)) == wv)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                }
+            }
+            issue(MF_);
+        });
+    };
+    static_assert(NF + G::NI <= MF, "one VMEM slot per fragment row");
+
+    // ---- prologue: ring stages 0..2 and the B fragments of half-steps 0..2, drained once before the loop
+    dma(0);
+    dma(1);
+    dma(2);
+    fence();
+    loadB(0, bq[0]);
+    loadB(1, bq[1]);
+    loadB(2, bq[2]);
+    fence();
+
+    // ---- persistent epilogue operands (their loads overlap the first ring fills)
+    float* Bias = reinterpret_cast<float*>(smem + G::RING);
+    bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
+    float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
+    int* Ga = reinterpret_cast<int*>(Sg + 256);               // group id of each tile row (-1: uniform mix)
+    const int r = RK ? p.rank : 0;
+    for (int i = tid; i < BNp; i += PT) Bias[i] = (flags & FFM_EPI_BIAS) ? p.bias[n0 + i] : 0.f;
+    if constexpr (RK) {
+        // LoRA matrix tile: thread -> column n; all of its global loads are issued before the first LDS store
+        // (a load -> store loop pays one memory round trip per iteration), then one 64-byte row is written.
+        constexpr int NCOL = (BNp + PT - 1) / PT;
+        float lwv[NCOL][16];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int n = tid + c * PT;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                lwv[c][j] = 0.f;
+                if (j < r && n < BNp)
+                    lwv[c][j] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const int n = tid + c * PT;
+            if (n < BNp) {
+                bf16x8 lo8, hi8, z8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { lo8[j] = (bf16_t)lwv[c][j]; hi8[j] = (bf16_t)lwv[c][8 + j]; z8[j] = (bf16_t)0.f; }
+                bf16x8* row = reinterpret_cast<bf16x8*>(LwB + n * 32);
+                row[0] = lo8; row[1] = hi8; row[2] = z8; row[3] = z8;
+            }
+        }
+        if (tid < p.G * r) Sg[tid] = p.S[tid];
+        for (int i = tid; i < BMp; i += PT) {
+            const int gm = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
+            Ga[i] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // VMEM issue order of step kt (nA = G::NI pieces, the same on every wave):
+    //   first half : B1 = the NF fragments of half-step 2kt+3, then the nA pieces of A stage kt+3
+    //   second half: B2 = the NF fragments of half-step 2kt+4
+    // Younger ops behind each counted wait, by steps left rem = KT - kt (B1 exists while rem >= 2, the A stage while
+    // rem >= 4, B2 while rem >= 3):
+    //                                                                             rem >= 4  | rem 3     | rem 2 | rem 1
+    //   first half  needs B2(kt-2):  ops(kt-1)                                  = 2NF + nA  | 2NF + nA  | 2NF   | NF
+    //   second half needs B1(kt-1):  A(kt-1) + B2(kt-1) + B1(kt) + A(kt)        = 2NF + 2nA | 2NF + nA  | 2NF   | 0
+    //   end of step needs A stage kt+1 (issued in step kt-2): B2(kt-2)+ops(kt-1)+ops(kt) = 5NF + 2nA | 5NF + nA | 4NF | -
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    constexpr int nA = G::NI;
+    auto step = [&](auto W_, int kt, auto P_, auto TAIL_) {
+        constexpr int P = decltype(P_)::value;
+        constexpr bool TAIL = decltype(TAIL_)::value != 0;      // tail: the last four steps, guarded by rem
+        const int rem = KT - kt;
+        const char* st = smem + (kt & 3) * G::STAGE;
+        if (!TAIL || rem >= 3) wait_vm<2 * NF + nA>();
+        else if (rem == 2) wait_vm<2 * NF>();
+        else wait_vm<NF>();
+        tieB(bq[2 * P]);
+        half(W_, st, offA0, bq[2 * P], [&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            if constexpr (j < NF) {
+                if (!TAIL || rem >= 2) loadB1(2 * kt + 3, j, bq[(2 * P + 3) & 3][j]);
+            } else if constexpr (j < NF + nA) {
+                if (!TAIL || rem >= 4) dma_piece(kt + 3, j - NF);
+            }
+        });
+        fence();
+        if (!TAIL || rem >= 4) wait_vm<2 * NF + 2 * nA>();
+        else if (rem == 3) wait_vm<2 * NF + nA>();
+        else if (rem == 2) wait_vm<2 * NF>();
+        else wait_vm<0>();
+        tieB(bq[2 * P + 1]);
+        half(W_, st, offA1, bq[2 * P + 1], [&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            if constexpr (j < NF) {
+                if (!TAIL || rem >= 3) loadB1(2 * kt + 4, j, bq[2 * P][j]);
+            }
+        });
+        fence();
+        if (!TAIL || rem >= 2) {
+            if (!TAIL || rem >= 4) wait_vm<5 * NF + 2 * nA>();
+            else if (rem == 3) wait_vm<5 * NF + nA>();
+            else wait_vm<4 * NF>();
+            block_barrier();
+        }
+    };
+    auto main_loop = [&](auto W_) {
+        int kt = (dbg & 16) ? KT : 0;
+        for (; kt < KT - 4; kt += 2) {                           // steady state: no guards, no branches
+            step(W_, kt, I0{}, I0{});
+            step(W_, kt + 1, I1{}, I0{});
+        }
+        for (; kt < KT; kt += 2) {                               // last four steps
+            step(W_, kt, I0{}, I1{});
+            step(W_, kt + 1, I1{}, I1{});
+        }
+    };
+    if constexpr (WSPEC) {                                       // one copy of the loop per wave (see half())
+        if (wave == 0) main_loop(I0{});
+        else if (wave == 1) main_loop(I1{});
+        else if (wave == 2) main_loop(std::integral_constant<int, 2>{});
+        else main_loop(std::integral_constant<int, 3>{});
+    } else {
+        main_loop(I0{});
+    }
+    // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire before the accumulators are read
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();                                                  // the ring is free from here on
+
+    // ---------------- epilogue ----------------
+    constexpr int PITCH = stage_pitch(NF);
+    constexpr int CPR = 2 * NF;                       // 8-column chunks per row of the wave's slab
+    constexpr int NRG = (MF + 1) / 2;                 // 32-row groups
+    constexpr int PF = NRG < 3 ? NRG : 3;             // row groups of residual / pre-activation rows kept in flight
+    float* Tt = reinterpret_cast<float*>(smem);                       // RANKOP: t tile [BM][16]
+    bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
+    float* Wv = reinterpret_cast<float*>(smem + BMp * 128);           // dS scratch [BM][16]
+    float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + wave * (32 * PITCH);
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
+
+    // residual / pre-activation rows of the first row groups: issued now, consumed after the rank-r update
+    constexpr bool PRE = (flags & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU)) != 0;
+    const bf16_t* prep = reinterpret_cast<const bf16_t*>((flags & FFM_EPI_RESIDUAL) ? p.res : p.aux);
+    bf16x8 rpre[PF][NF];
+    auto load_pre = [&](int rg, bf16x8 (&dst)[NF]) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
+            const int gm = m0 + rg * 32 + row;
+            if (gm < p.M && rg * 32 + row < BMp)
+                dst[i] = *reinterpret_cast<const bf16x8*>(prep + (size_t)gm * p.ldc + n0w + ch * 8);
+        }
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int g = 0; g < PF; ++g) load_pre(g, rpre[g]);
+    }
+
+    if (RK && !(dbg & 2)) {
+        auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
+            const int a = Ga[row];
+            return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
+        };
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int mfi = wave + PW * i;
+            if (mfi < MF) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Tt[(mfi * 16 + fgrp * 4 + e) * 16 + frow] = tacc[i][e];
+            }
+        }
+        __syncthreads();
+        // Every block of a tile row holds the same t: the stores of t / ts and the dS partial sums are split over
+        // the tiles_n blocks by rows, so that no block becomes a straggler of this single-round kernel.
+        const int rsl = (BMp + tiles_n - 1) / tiles_n;
+        const int rs0 = tn * rsl, rs1 = (rs0 + rsl) < BMp ? (rs0 + rsl) : BMp;
+        const bool do_ds = p.t_fwd && p.ds_part;
+        for (int idx = tid; idx < BMp * 16; idx += PT) {
+            const int row = idx >> 4, j = idx & 15;
+            const int gm = m0 + row;
+            float tsv = 0.f, wv = 0.f;
+            if (j < r && gm < p.M) {
+                const float tv = Tt[idx];
+                float sb = 0.f;
+                for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
+                tsv = p.scaling * tv * sb;
+                if (row >= rs0 && row < rs1) {
+                    if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
+                    if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv;
+                    if (do_ds) wv = p.scaling * p.t_fwd[(size_t)gm * r + j] * tv;
+                }
+            }
+            TsA[row * 32 + j] = (bf16_t)tsv;
+            TsA[row * 32 + 16 + j] = (bf16_t)0.f;
+            if (do_ds) Wv[idx] = wv;
+        }
+        __syncthreads();
+        if (do_ds && tid < p.G * r) {
+            // dS partial of this block's row slice: sum_rows pi_b[g] * scaling * t_fwd * t
+            const int g = tid / r, j = tid % r;
+            float sacc = 0.f;
+            for (int row = rs0; row < rs1; ++row) sacc += mixw(row, g) * Wv[row * 16 + j];
+            p.ds_part[((size_t)(tm * tiles_n + tn) * p.G + g) * r + j] = sacc;
+        }
+        // rank-r update on the matrix cores: acc += TsA . LwB^T (K = 32 rank slots, zero padded)
+        frag_t lb[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+            lb[nf] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(LwB) + (wave * WN + nf * 16 + frow) * 64 + fgrp * 16);
+        static_for<MF>([&](auto MF_) {
+            constexpr int mf = decltype(MF_)::value;
+            const frag_t a = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(TsA) + (mf * 16 + frow) * 64 + fgrp * 16);
+            static_for<NF>([&](auto NF_) {
+                constexpr int nf = decltype(NF_)::value;
+                mma(std::integral_constant<int, mf * NF + nf>{}, acc[mf][nf], a, lb[nf]);
+            });
+        });
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    }
+
+    // per wave: 32-row groups of the accumulator slab through a private LDS stage, then 16-byte row segments out.
+    // accumulator fragment -> stage: explicit ds_write_b32 (data straight from the AGPR / VGPR the MFMAs left it in)
+    const uint32_t cw_lane = (uint32_t)(uintptr_t)(Cw + fgrp * 4 * PITCH + frow);
+    static_for<NRG>([&](auto RG_) {
+        constexpr int rg = decltype(RG_)::value;
+        static_for<2 * NF * 4>([&](auto T_) {
+            constexpr int t = decltype(T_)::value;
+            constexpr int q = t / (NF * 4), nf = (t / 4) % NF, e = t % 4, mf = 2 * rg + q;
+            constexpr int off = ((q * 16 + e) * PITCH + nf * 16) * 4;
+            const uint32_t cwl = cw_lane;               // (named outside the if constexpr so that the lambda captures them)
+            const f32x4(&accr)[MF][NF] = acc;
+            if constexpr (mf < MF) {
+                if constexpr (mf * NF + nf < 64)
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(cwl), "a"(accr[mf][nf][e]), "n"(off) : "memory");
+                else
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(cwl), "v"(accr[mf][nf][e]), "n"(off) : "memory");
+            }
+        });
+        fence();
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
+            const int gm = m0 + rg * 32 + row;
+            const bool ok = gm < p.M && rg * 32 + row < BMp;
+            float v[8];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8 + 4]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8 + 4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] = c0[c] + b0[c]; v[4 + c] = c1[c] + b1[c]; }
+            if constexpr ((flags & FFM_EPI_RESIDUAL) != 0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];
+            }
+            if constexpr ((flags & FFM_EPI_DGELU) != 0) {
+                if (!(dbg & 4)) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] *= Act<bf16_t>::gelu_grad((float)rpre[rg % PF][i][c]);
+                }
+            }
+            if (ok && !(dbg & 8)) {
+                const size_t off = (size_t)gm * p.ldc + n0w + ch * 8;
+                Vec8<bf16_t>::store(C + off, v);
+                if constexpr ((flags & FFM_EPI_GELU) != 0) {
+                    float a[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a[c] = (dbg & 4) ? v[c] : Act<bf16_t>::gelu((float)(bf16_t)v[c]);
+                    Vec8<bf16_t>::store(reinterpret_cast<bf16_t*>(p.c2) + off, a);
+                }
+            }
+        }
+        if constexpr (PRE) {
+            if constexpr (rg + PF < NRG) load_pre(rg + PF, rpre[rg % PF]);
+        }
+        fence();
+    });
+}
+
+template <int MF, int NF, bool RK, int FL>
+int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
+    using G = PanelGeom<MF, RK>;
+    const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (PW * 16 * NF));
+    constexpr int lds = G::RING + persist_bytes(MF, NF, RK);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(!RK || 16 * MF * 192 + PW * 32 * stage_pitch(NF) * 4 <= G::RING, "epilogue tiles alias the ring");
+    static bool done = false;                         // one per instantiation
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    static int dbg = -1;
+    if (dbg < 0) { const char* f = getenv("FFM_PANEL_DBG"); dbg = f ? atoi(f) : 0; }
+    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL>), dim3(tiles), dim3(PT), lds, s, a, dbg);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+}  // namespace ffm_panel

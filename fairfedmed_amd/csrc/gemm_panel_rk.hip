@@ -1,0 +1,21 @@
+// Panel GEMM, FairLoRA epilogues (FFM_EPI_RANKOP): c_fc / c_proj forward and their dX products.
+#include "gemm_panel_impl.h"
+
+#define PANEL_RK_CASE(F)                                                                   \
+    case F:                                                                                \
+        switch (cfg) {                                                                     \
+            case 0: return ffm_panel::launch_panel<13, 6, true, F>(a, s);                  \
+            case 3: return ffm_panel::launch_panel<11, 2, true, F>(a, s);                  \
+        }                                                                                  \
+        return FFM_EINVAL;
+
+int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s) {
+    if (!a.rk || ((uintptr_t)a.rk & 15) || !a.S || !a.lw || a.rank <= 0 || a.rank > 16) return FFM_EINVAL;
+    switch (a.flags & ~FFM_EPI_RANKOP) {
+        PANEL_RK_CASE(FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU)                          // c_fc forward
+        PANEL_RK_CASE(FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)                      // c_proj forward
+        PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                      // dX of c_proj
+        PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR)                                      // dX of c_fc
+    }
+    return FFM_EINVAL;
+}

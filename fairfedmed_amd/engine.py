@@ -25,6 +25,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .config import ModelCfg
 from .synth import manifest, trainable_keys
@@ -73,6 +74,17 @@ class FlatParams:
                             dtype=torch.int64, device=self.flat.device)
 
 
+def _ds_rows(rows: int, N: int, K: int, rank: int, dtype, packed: Optional[bool] = None, dgelu: bool = False) -> int:
+    """dS partial rows a FairLoRA dX GEMM writes (packed=None: the larger of the kernels ffm_gemm_nt may pick)."""
+    fl = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_RANKOP | (L.EPI_DGELU if dgelu else 0)
+    if packed is None:
+        return max(ops.gemm_tiles_m(rows, N, K, fl, rank, dtype, p) for p in (False, True))
+    return ops.gemm_tiles_m(rows, N, K, fl, rank, dtype, packed)
+
+
+_PACKED = ("w_in", "w_in_t", "w_out", "w_out_t", "w_fc", "w_fc_t", "w_proj", "w_proj_t")
+
+
 @dataclass
 class _Block:
     """Frozen weights of one residual attention block in the compute dtype."""
@@ -93,6 +105,10 @@ class _Block:
     w_proj_t: Tensor
     b_proj: Tensor
     lora: Optional[Dict[str, str]] = None      # role -> flat key, vision blocks only
+    packed: Optional[Dict[str, Tensor]] = None # bf16 vision blocks: the eight weights in MFMA-fragment order (ops.pack_b)
+
+    def pk(self, name: str) -> Optional[Tensor]:
+        return self.packed[name] if self.packed else None
 
 
 class _Stack:
@@ -144,7 +160,7 @@ class _Stack:
             # (ffm_reduce_partials_multi) at the end of the backward pass
             ns = ops.lora_grad_splits(T)
             nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype),
-                     ops.gemm_tiles_m(T))  # TODO-tiles
+                     _ds_rows(T, 4 * w, w, rank, dtype, dgelu=True), _ds_rows(T, w, 4 * w, rank, dtype))
             self.part = [{"fc_A": f(ns * w * rank), "fc_B": f(ns * 4 * w * rank),
                           "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),
                           "fc_S": f(nb * 8 * rank), "proj_S": f(nb * 8 * rank)} for _ in range(layers)]
@@ -272,6 +288,12 @@ class FairLoRAEngine:
                     if isinstance(val, torch.Tensor):
                         getattr(old[i], name).copy_(val)
                 blk = old[i]
+            if lora and self.dtype == torch.bfloat16:
+                # frozen weights in MFMA-fragment order for the panel GEMM (csrc/gemm_panel_impl.h)
+                if blk.packed is None:
+                    blk.packed = {}
+                for name in _PACKED:
+                    blk.packed[name] = ops.pack_b(getattr(blk, name), blk.packed.get(name))
             stack.blocks.append(blk)
 
     def load_frozen(self, sd: Dict[str, Tensor]) -> None:
@@ -322,18 +344,19 @@ class FairLoRAEngine:
             pre, act = st.pre[i][:rows], st.act[i][:rows]
             h = st.h[:rows]
             ops.layernorm_fwd(x, h, blk.ln1_w, blk.ln1_b, st.st1[i][0], st.st1[i][1])
-            ops.gemm_nt(h, blk.w_in, qkv, bias=blk.b_in)
+            ops.gemm_nt(h, blk.w_in, qkv, bias=blk.b_in, b_packed=blk.pk("w_in"))
             ops.attention_fwd(qkv, o, st.lse[i], images, st.L, st.heads, st.causal)
-            ops.gemm_nt(o, blk.w_out, xm, bias=blk.b_out, res=x)
+            ops.gemm_nt(o, blk.w_out, xm, bias=blk.b_out, res=x, b_packed=blk.pk("w_out"))
             ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
             if r and self.fused_rank:
                 ro = ops.RankOp(self.rk[i]["fc_A"], self._lora_view(blk, "fc_S"), attr, rows_per_sample, lo.scaling,
                                 lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i])
-                ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro)
+                ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
+                            b_packed=blk.pk("w_fc"))
                 ro = ops.RankOp(self.rk[i]["proj_A"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
                                 lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i])
                 ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
-                            res=xm, rankop=ro)
+                            res=xm, rankop=ro, b_packed=blk.pk("w_proj"))
             elif r:
                 ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._lora_view(blk, "fc_S"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
@@ -374,7 +397,7 @@ class FairLoRAEngine:
                     ro = ops.RankOp(self.rk[i]["proj_B"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"])
                     ops.gemm_nt(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
-                                dgelu_aux=pre, rankop=ro)
+                                dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"))
                 else:
                     ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
@@ -385,7 +408,7 @@ class FairLoRAEngine:
                     ro = ops.RankOp(self.rk[i]["fc_B"], self._lora_view(blk, "fc_S"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"])
                     ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
-                                rankop=ro)
+                                rankop=ro, b_packed=blk.pk("w_fc_t"))
                 else:
                     ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
@@ -408,10 +431,10 @@ class FairLoRAEngine:
                 ops.gemm_nt(gi, blk.w_proj_t, dpre, dgelu_aux=pre)
                 ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows])
             ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], gi, g1)
-            ops.gemm_nt(g1, blk.w_out_t, st.do[:rows])
+            ops.gemm_nt(g1, blk.w_out_t, st.do[:rows], b_packed=blk.pk("w_out_t"))
             ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
                               images, st.L, st.heads, st.causal)
-            ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows])
+            ops.gemm_nt(st.dqkv[:rows], blk.w_in_t, st.dh[:rows], b_packed=blk.pk("w_in_t"))
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
         if r:
             with self._on(self.grad_stream):
@@ -431,8 +454,11 @@ class FairLoRAEngine:
                 gv = lambda role: self.params.view(blk.lora[role], "grad")
                 # dS partial rows: GEMM row tiles when the down projection is fused, lora_down blocks otherwise
                 # (block 0's c_fc has no dX GEMM, so it always uses the stand-alone kernel)
-                nb_p = ops.gemm_tiles_m(rows) if self.fused_rank else ops.lora_down_blocks(rows, w, r, self.dtype)
-                nb_f = ops.gemm_tiles_m(rows) if (self.fused_rank and (li > 0 or full_bwd)) \
+                # dS partial rows written by the dX GEMMs (c_proj: N = 4w, K = w; c_fc: N = w, K = 4w)
+                pk = st.blocks[li].packed is not None
+                nb_p = _ds_rows(rows, 4 * w, w, r, self.dtype, pk, dgelu=True) if self.fused_rank \
+                    else ops.lora_down_blocks(rows, w, r, self.dtype)
+                nb_f = _ds_rows(rows, w, 4 * w, r, self.dtype, pk) if (self.fused_rank and (li > 0 or full_bwd)) \
                     else ops.lora_down_blocks(rows, 4 * w, r, self.dtype)
                 ent += [(pt["proj_S"], nb_p, G * r, gv("proj_S"), 0, 0), (pt["fc_S"], nb_f, G * r, gv("fc_S"), 0, 0),
                         (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),

@@ -103,12 +103,14 @@ def gemm_tiles_m(M: int, N: int = 128, K: int = 128, flags: int = 0, rank: int =
     return L.load().ffm_gemm_tiles_m(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
 
 
-def pack_b(w: Tensor) -> Tensor:
+def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """Frozen bf16 weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
-    _dev(w)
+    _dev(w, out)
     assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
     N, K = w.shape
-    out = torch.empty(N * K, device=w.device, dtype=w.dtype)
+    if out is None:
+        out = torch.empty(N * K, device=w.device, dtype=w.dtype)
+    assert out.numel() == N * K and out.dtype == w.dtype and out.is_contiguous()
     _call("ffm_pack_b", L.ptr(w), L.ptr(out), N, K, w.stride(0), L.stream_ptr())
     return out
 

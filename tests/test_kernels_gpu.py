@@ -113,6 +113,92 @@ def test_gemm_rankop_fused_lora(ops, dt, r, G, kr, use_attr):
     check(dsp.double().sum(0), pi_rows.t() @ (0.25 * t_fwd.double() * ref_t), 5e-5, "dS")
 
 
+
+# ------------------------------------------------- panel GEMM (packed B) ---
+@pytest.mark.parametrize("M,N,K,mode", [(6304, 2304, 768, "b"), (6304, 768, 768, "br"), (6304, 768, 2304, ""),
+                                         (6000, 768, 3072, "br"), (4100, 1024, 512, "b")])
+def test_gemm_panel_plain(ops, M, N, K, mode):
+    """Frozen weights packed in MFMA-fragment order -> panel kernel (csrc/gemm_panel_impl.h); same contract as
+    ffm_gemm_nt on the row-major operand."""
+    dt = torch.bfloat16
+    flags = (1 if "b" in mode else 0) | (8 if "r" in mode else 0)
+    assert ops.gemm_tiles_m(M, N, K, flags, 0, dt, True) != ops.gemm_tiles_m(M, N, K, flags, 0, dt, False), \
+        "shape does not select the panel kernel"
+    a, b = rnd(M, K, dt=dt, seed=60), rnd(N, K, dt=dt, scale=K ** -0.5, seed=61)
+    kw = {}
+    ref = a.double() @ b.double().t()
+    if "b" in mode:
+        kw["bias"] = rnd(N, seed=62)
+        ref = ref + kw["bias"].double()
+    if "r" in mode:
+        kw["res"] = rnd(M, N, dt=dt, seed=63)
+        ref = ref + kw["res"].double()
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(a, b, out, b_packed=ops.pack_b(b), **kw)
+    check(out, ref, tol(dt), "panel " + mode)
+    out2 = torch.empty_like(out)
+    ops.gemm_nt(a, b, out2, **kw)                    # the 128x128 kernel on the same operands
+    check(out, out2.double(), 1e-2, "panel vs 128x128")
+
+
+@pytest.mark.parametrize("case", ["fc_fwd", "proj_fwd", "proj_dx", "fc_dx"])
+@pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (5500, 16, 2, False), (6304, 4, 3, True)])
+def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr):
+    """The four FairLoRA GEMMs of a block on the panel kernel: t / ts / dS partials / fused rank-r update / GELU."""
+    dt = torch.bfloat16
+    width, rps = 768, 197
+    N, K = (4 * width, width) if case in ("fc_fwd", "proj_dx") else (width, 4 * width)
+    kr = case in ("proj_dx", "fc_dx")
+    flags = {"fc_fwd": 1 | 2 | 16, "proj_fwd": 1 | 2 | 8, "proj_dx": 2 | 4 | 32, "fc_dx": 2 | 4}[case] | 64
+    nrows = ops.gemm_tiles_m(M, N, K, flags, r, dt, True)
+    assert nrows != ops.gemm_tiles_m(M, N, K, flags, r, dt, False), "shape does not select the panel kernel"
+    a, b = rnd(M, K, dt=dt, seed=70), rnd(N, K, dt=dt, scale=K ** -0.5, seed=71)
+    P = rnd(K, r, scale=0.1, seed=73)
+    S = rnd(G, r, seed=74)
+    lw = rnd(N, r, seed=75) if kr else rnd(r, N, seed=75)
+    nsamp = (M + rps - 1) // rps
+    attr = torch.randint(0, G, (nsamp,), device="cuda", dtype=torch.int32) if use_attr else None
+    rk = torch.zeros(16, K, device="cuda", dtype=dt)
+    ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    t, ts = torch.full((M, r), float("nan"), device="cuda"), torch.full((M, r), float("nan"), device="cuda")
+    kw, bwd = {}, kr
+    t_fwd = rnd(M, r, seed=76) if bwd else None
+    dsp = torch.full((nrows, G, r), float("nan"), device="cuda") if bwd else None
+    ro = ops.RankOp(rk, S, attr, rps, 0.25, 0.7, t_out=t, ts_out=ts, t_fwd=t_fwd, ds_part=dsp)
+    ref_t = a.double() @ P.to(dt).double()
+    pi = mix(attr, G)
+    rows = torch.arange(M, device="cuda") // rps
+    pi_rows = pi[rows] if attr is not None else pi.expand(M, G)
+    ref_ts = 0.25 * ref_t * (pi_rows @ S.double())
+    # the kernel feeds ts to the matrix cores as bf16 (like the 128x128 kernel's MFMA update)
+    ref = a.double() @ b.double().t() + ref_ts.to(dt).double() @ (lw.double().t() if kr else lw.double()).to(dt).double()
+    if case in ("fc_fwd", "proj_fwd"):
+        kw["bias"] = rnd(N, seed=72)
+        ref = ref + kw["bias"].double()
+    if case == "proj_fwd":
+        kw["res"] = rnd(M, N, dt=dt, seed=77)
+        ref = ref + kw["res"].double()
+    act = None
+    if case == "fc_fwd":
+        act = torch.empty(M, N, device="cuda", dtype=dt)
+        kw["gelu_out"] = act
+    if case == "proj_dx":
+        kw["dgelu_aux"] = rnd(M, N, dt=dt, seed=78)
+        x = kw["dgelu_aux"].double()
+        sg = torch.sigmoid(1.702 * x)
+        ref = ref * (sg * (1 + 1.702 * x * (1 - sg)))
+    ops.gemm_nt(a, b, out, lw=lw, lw_is_kr=kr, rankop=ro, b_packed=ops.pack_b(b), **kw)
+    check(t, ref_t, 2e-5, "t")
+    check(ts, ref_ts, 2e-5, "ts")
+    check(out, ref, tol(dt), "fused out")
+    if act is not None:
+        pre = out.double()
+        check(act, pre * torch.sigmoid(1.702 * pre), tol(dt), "quick_gelu(pre)")
+    if bwd:
+        check(dsp.double().sum(0), pi_rows.t() @ (0.25 * t_fwd.double() * ref_t), 5e-5, "dS")
+
+
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 def test_gemm_gelu_and_dgelu(ops, dt):
     M, N, K = 260, 256, 128

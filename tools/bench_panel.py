@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Panel GEMM (csrc/gemm_panel.hip) vs the 128x128 kernel on the vision-tower shapes:
-correctness against torch and us / TFLOP/s per shape."""
+"""Panel GEMM (csrc/gemm_panel_impl.h) vs the 128x128 kernel on the eight GEMMs of a vision block (bs 32):
+us / TFLOP/s per shape with the engine's epilogues."""
 import os
 import sys
 
@@ -8,9 +8,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fairfedmed_amd import ops
 
+dt = torch.bfloat16
+M, W, R, G, RPS = 6304, 768, 8, 3, 197
 
-def run(M, N, K, mode, packed, iters=30, check=True):
-    dt = torch.bfloat16
+
+def bench(fn, iters=40):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def case(name, N, K, mode):
     g = torch.Generator("cuda").manual_seed(1)
     a = torch.randn(M, K, device="cuda", generator=g).to(dt)
     b = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(dt)
@@ -20,39 +35,39 @@ def run(M, N, K, mode, packed, iters=30, check=True):
         kw["bias"] = torch.randn(N, device="cuda", generator=g)
     if "r" in mode:
         kw["res"] = torch.randn(M, N, device="cuda", generator=g).to(dt)
-    if packed:
-        kw["b_packed"] = ops.pack_b(b)
-    err = None
-    ops.gemm_nt(a, b, out, **kw)
-    torch.cuda.synchronize()
-    if check:
-        ref = a.float() @ b.float().t()
-        if "b" in mode:
-            ref += kw["bias"]
-        if "r" in mode:
-            ref += kw["res"].float()
-        err = float((out.float() - ref).abs().max() / ref.abs().max())
-    for _ in range(3):
-        ops.gemm_nt(a, b, out, **kw)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.gemm_nt(a, b, out, **kw)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    return us, 2.0 * M * N * K / us / 1e6, err
+    if "g" in mode:
+        kw["gelu_out"] = torch.empty(M, N, device="cuda", dtype=dt)
+    if "d" in mode:
+        kw["dgelu_aux"] = torch.randn(M, N, device="cuda", generator=g).to(dt)
+    if "l" in mode:
+        kr = "k" in mode
+        P = torch.randn(K, R, device="cuda", generator=g) * 0.1
+        rk = torch.zeros(16, K, device="cuda", dtype=dt)
+        ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+        attr = torch.randint(0, G, (32,), device="cuda", dtype=torch.int32)
+        t, ts = torch.empty(M, R, device="cuda"), torch.empty(M, R, device="cuda")
+        bwd = kr
+        rows = max(ops.gemm_tiles_m(M, N, K, 0, 0, dt, False), 512)
+        ro = ops.RankOp(rk, torch.randn(G, R, device="cuda", generator=g), attr, RPS, 0.25, 0.7, t_out=None if bwd else t,
+                        ts_out=ts, t_fwd=torch.randn(M, R, device="cuda", generator=g) if bwd else None,
+                        ds_part=torch.empty(rows, G, R, device="cuda") if bwd else None)
+        kw.update(lw=torch.randn(N, R, device="cuda", generator=g) if kr else torch.randn(R, N, device="cuda", generator=g),
+                  lw_is_kr=kr, rankop=ro)
+    bp = ops.pack_b(b)
+    u0 = bench(lambda: ops.gemm_nt(a, b, out, **kw))
+    u1 = bench(lambda: ops.gemm_nt(a, b, out, b_packed=bp, **kw))
+    fl = 2.0 * M * N * K
+    print(f"{name:10s} N{N:5d} K{K:5d} [{mode:5s}] 128x128 {u0:6.1f} us {fl / u0 / 1e6:7.1f} TF/s | panel {u1:6.1f} us "
+          f"{fl / u1 / 1e6:7.1f} TF/s", flush=True)
+    return u0, u1
 
-
-SHAPES = [("qkv fwd", 6304, 2304, 768, "b"), ("out fwd", 6304, 768, 768, "br"), ("fc plain", 6304, 3072, 768, "b"),
-          ("proj plain", 6304, 768, 3072, "br"), ("do bwd", 6304, 768, 768, ""), ("dh1 bwd", 6304, 768, 2304, ""),
-          ("odd M", 5000, 3072, 768, "b"), ("big", 8192, 6144, 4096, "")]
 
 if __name__ == "__main__":
-    for name, M, N, K, mode in SHAPES:
-        tiles = ops.gemm_tiles_m(M, N, K, (1 if "b" in mode else 0) | (8 if "r" in mode else 0), 0, torch.bfloat16, True)
-        u0, t0, e0 = run(M, N, K, mode, False)
-        u1, t1, e1 = run(M, N, K, mode, True)
-        print(f"{name:11s} M{M} N{N} K{K} [{mode:2s}] 128x128 {u0:7.1f} us {t0:7.1f} TF/s err {e0:.1e} | "
-              f"panel({tiles} row tiles) {u1:7.1f} us {t1:7.1f} TF/s err {e1:.1e}", flush=True)
+    tot = [0.0, 0.0]
+    for name, N, K, mode in [("qkv fwd", 3 * W, W, "b"), ("out fwd", W, W, "br"), ("fc fwd", 4 * W, W, "blg"),
+                             ("proj fwd", W, 4 * W, "blr"), ("proj dX", 4 * W, W, "lkd"), ("fc dX", W, 4 * W, "lk"),
+                             ("out dX", W, W, ""), ("qkv dX", W, 3 * W, "")]:
+        u = case(name, N, K, mode)
+        tot[0] += u[0]
+        tot[1] += u[1]
+    print(f"sum per block: 128x128 {tot[0]:.1f} us, panel {tot[1]:.1f} us")
