@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         for (int f = 0; f < NFP; ++f)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float p = __expf(s[f][e] - mx);
+                const float p = fast_expf(s[f][e] - mx);
                 s[f][e] = p;
                 sum += p;
             }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __rest
                 const int key = f * 16 + g * 4 + e;
                 float v = 0.f;
                 if (key < L && !(causal && key > q)) {
-                    const float p = __expf(sa[e] * 0.125f - lq);
+                    const float p = fast_expf(sa[e] * 0.125f - lq);
                     v = p * (pa[e] - dl) * 0.125f;
                 }
                 sa[e] = v;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
                 const int q = f * 16 + g * 4 + e;
                 float p = 0.f, d = 0.f;
                 if (q < L && key < L && !(causal && key > q)) {
-                    p = __expf(sa[e] * 0.125f - lse_s[q]);
+                    p = fast_expf(sa[e] * 0.125f - lse_s[q]);
                     d = p * (pa[e] - del_s[q]) * 0.125f;
                 }
                 sa[e] = p;

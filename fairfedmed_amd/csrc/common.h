@@ -129,6 +129,10 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// e^x on the raw v_exp_f32 (1 ulp): __expf / expf add range checks and denormal scaling around the same instruction,
+// several VALU ops per element of a softmax tile
+__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 __device__ __forceinline__ float quick_gelu_f(float x) {
     // clip/model.py:313-315: x * sigmoid(1.702 x)
     return x / (1.0f + expf(-1.702f * x));

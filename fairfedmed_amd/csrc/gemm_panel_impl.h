@@ -23,7 +23,6 @@
 #pragma once
 #include "gemm_panel.h"
 #include <type_traits>
-#include <cstdlib>
 
 namespace ffm_panel {
 
@@ -73,7 +72,7 @@ __host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk) {
 }
 
 template <int MF, int NF, bool RK, int FL>
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_panel_kernel(ffm_gemm_args p, int dbg) {
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_panel_kernel(ffm_gemm_args p) {
     using G = PanelGeom<MF, RK>;
     constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     };
     auto main_loop = [&](auto W_) {
-        int kt = (dbg & 16) ? KT : 0;
+        int kt = 0;
         for (; kt < KT - 4; kt += 2) {                           // steady state: no guards, no branches
             step(W_, kt, I0{}, I0{});
             step(W_, kt + 1, I1{}, I0{});
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int g = 0; g < PF; ++g) load_pre(g, rpre[g]);
     }
 
-    if (RK && !(dbg & 2)) {
+    if constexpr (RK) {
         auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
             const int a = Ga[row];
             return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
@@ -466,18 +465,16 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];
             }
             if constexpr ((flags & FFM_EPI_DGELU) != 0) {
-                if (!(dbg & 4)) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] *= Act<bf16_t>::gelu_grad((float)rpre[rg % PF][i][c]);
-                }
             }
-            if (ok && !(dbg & 8)) {
+            if (ok) {
                 const size_t off = (size_t)gm * p.ldc + n0w + ch * 8;
                 Vec8<bf16_t>::store(C + off, v);
                 if constexpr ((flags & FFM_EPI_GELU) != 0) {
                     float a[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) a[c] = (dbg & 4) ? v[c] : Act<bf16_t>::gelu((float)(bf16_t)v[c]);
+                    for (int c = 0; c < 8; ++c) a[c] = Act<bf16_t>::gelu((float)(bf16_t)v[c]);
                     Vec8<bf16_t>::store(reinterpret_cast<bf16_t*>(p.c2) + off, a);
                 }
             }
@@ -503,9 +500,7 @@ int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    static int dbg = -1;
-    if (dbg < 0) { const char* f = getenv("FFM_PANEL_DBG"); dbg = f ? atoi(f) : 0; }
-    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL>), dim3(tiles), dim3(PT), lds, s, a, dbg);
+    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL>), dim3(tiles), dim3(PT), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
