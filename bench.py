@@ -219,8 +219,23 @@ def main():
         eng.set_overlap(True)
         peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s> (vision-tower launches, M=%d)" % (args.dtype, BATCH * 197),
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        # HBM-side bytes per launch of the same kernels come from the committed PMC passes (rocprofv3 cannot be
+        # driven from inside the timed process): tools/pmc_traffic.py -> profiles/rNN_traffic.json
+        traffic, tsrc = None, None
+        try:
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            cand = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json"))
+            if cand and dtype == torch.bfloat16 and args.rank == 8:
+                traffic = json.load(open(os.path.join(pdir, cand[-1])))["traffic_bytes_per_launch"]
+                tsrc = "profiles/" + cand[-1]
+        except (OSError, KeyError, ValueError):
+            pass
+        roof = {"bound": "mfma",
+                "kernel": "ffm_gemm_nt on the vision tower (M=%d): gemm_panel_kernel<%s> on fragment-packed frozen "
+                          "weights (bf16), gemm_nt_kernel otherwise" % (BATCH * 197, args.dtype),
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), algorithmic mean 54.4e6",
+                "traffic_source": tsrc,
                 "launches_per_step": n // args.steps, "avg_launch_us": ms * 1e3 / n,
                 "gemm_ms_per_step": ms / args.steps,
                 "all_gemm_launches": {"launches_per_step": n_all // args.steps, "achieved": fl_all / (ms_all * 1e-3) / 1e12,
