@@ -129,8 +129,8 @@ __device__ __forceinline__ float group4_sum(float v) {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int NFP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+template <typename T, int NFP, int NTH>
+__global__ __launch_bounds__(NTH) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                        float* __restrict__ lse, int L, int heads, int causal,
                                                        int qsplit) {
     typedef typename AT<T>::frag_t frag_t;
@@ -146,15 +146,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
 
-    stage_rowmajor<T, LP, 256>(base + E, ld, L, Ks, tid);
-    stage_transposed<T, LP, 256>(base + 2 * E, ld, L, Vt, ts, tid);
+    stage_rowmajor<T, LP, NTH>(base + E, ld, L, Ks, tid);
+    stage_transposed<T, LP, NTH>(base + 2 * E, ld, L, Vt, ts, tid);
     __syncthreads();
 
     const int NF = (L + 15) / 16;
     const int per = (NF + qsplit - 1) / qsplit;
     const int qt0 = blockIdx.y * per;
     const int qt1 = (qt0 + per) < NF ? (qt0 + per) : NF;
-    for (int qt = qt0 + wave; qt < qt1; qt += 4) {
+    for (int qt = qt0 + wave; qt < qt1; qt += NTH / 64) {
         const int q = qt * 16 + col;
         frag_t qf[AT<T>::ND];
 #pragma unroll
@@ -540,11 +540,22 @@ inline int pick_split(int bh, int NF) {
 
 template <typename T, int NFP>
 int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int causal, hipStream_t s) {
-    const int NF = (L + 15) / 16, split = pick_split(B * heads, NF);
+    const int NF = (L + 15) / 16;
     const int lds = lds_fwd<T>(NFP);
-    int e = set_lds(attn_fwd_kernel<T, NFP>, lds);
+    if (sizeof(T) == 2 && B * heads >= 256 && NF >= 8) {
+        // enough (b, h) pairs to fill the chip: 8 waves per block and no q-split, so K / V are staged once per pair
+        // (two blocks of 58 KB per CU hold all 384 pairs of the bs-32 step in one round)
+        int e = set_lds(attn_fwd_kernel<T, NFP, 512>, lds);
+        if (e) return e;
+        hipLaunchKernelGGL((attn_fwd_kernel<T, NFP, 512>), dim3(B * heads, 1), dim3(512), lds, s, (const T*)qkv, (T*)out,
+                           lse, L, heads, causal, 1);
+        FFM_CHECK_LAUNCH();
+        return FFM_OK;
+    }
+    const int split = pick_split(B * heads, NF);
+    int e = set_lds(attn_fwd_kernel<T, NFP, 256>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((attn_fwd_kernel<T, NFP>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv, (T*)out,
+    hipLaunchKernelGGL((attn_fwd_kernel<T, NFP, 256>), dim3(B * heads, split), dim3(256), lds, s, (const T*)qkv, (T*)out,
                        lse, L, heads, causal, split);
     FFM_CHECK_LAUNCH();
     return FFM_OK;

@@ -46,6 +46,9 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
     for (int c = 0; c < FFM_PANEL_NCFG; ++c) {
         const int bm = 16 * FFM_PANEL_CFGS[c].mf, bn = 64 * FFM_PANEL_CFGS[c].nf;
         if (N % bn || FFM_PANEL_CFGS[c].rankop != rk) continue;
+        // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
+        // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
+        if (!rk && FFM_PANEL_CFGS[c].nf >= 4 && K < 1536) continue;
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
         const long cost = ((blocks + 255) / 256) * (bm + bn);
         if (cost < best) { best = cost; pick = c; }

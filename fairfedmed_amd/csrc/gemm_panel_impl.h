@@ -66,9 +66,10 @@ __device__ __forceinline__ void block_barrier() {
 }
 
 __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }                // floats
-// persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] f32 | row groups [BM]
+// persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
+// f32 | row groups [BM]
 __host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk) {
-    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + 1024 + 16 * mf * 4 : 0);
+    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0);
 }
 
 template <int MF, int NF, bool RK, int FL>
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     float* Bias = reinterpret_cast<float*>(smem + G::RING);
     bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
-    int* Ga = reinterpret_cast<int*>(Sg + 256);               // group id of each tile row (-1: uniform mix)
+    float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
+    int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
     const int r = RK ? p.rank : 0;
     for (int i = tid; i < BNp; i += PT) Bias[i] = (flags & FFM_EPI_BIAS) ? p.bias[n0 + i] : 0.f;
     if constexpr (RK) {
@@ -368,10 +370,16 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 
     if constexpr (RK) {
-        auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
-            const int a = Ga[row];
-            return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
-        };
+        // pi_b[g] = lambda on the sample's own group, (1 - lambda) / (G - 1) elsewhere, 1 / G without an attribute:
+        //   s_b[j] = sum_g pi_b[g] S[g][j] = w_o * Ssum[j] + (lambda - w_o) * S[a][j]      (a >= 0)
+        // (one LDS read and one FMA per entry instead of a loop over the groups with a division in it)
+        const float w_own = p.lambda_group, w_oth = (1.0f - p.lambda_group) / (float)(p.G > 1 ? p.G - 1 : 1);
+        const float w_uni = 1.0f / (float)p.G;
+        if (tid < r) {
+            float sacc = 0.f;
+            for (int g = 0; g < p.G; ++g) sacc += Sg[g * r + tid];
+            Ssum[tid] = sacc;
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int mfi = wave + PW * i;
@@ -392,8 +400,8 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             float tsv = 0.f, wv = 0.f;
             if (j < r && gm < p.M) {
                 const float tv = Tt[idx];
-                float sb = 0.f;
-                for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
+                const int a = Ga[row];
+                const float sb = a < 0 ? w_uni * Ssum[j] : w_oth * Ssum[j] + (w_own - w_oth) * Sg[a * r + j];
                 tsv = p.scaling * tv * sb;
                 if (row >= rs0 && row < rs1) {
                     if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
@@ -408,10 +416,15 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __syncthreads();
         if (do_ds && tid < p.G * r) {
             // dS partial of this block's row slice: sum_rows pi_b[g] * scaling * t_fwd * t
+            //   = w_o * sum_rows Wv + (lambda - w_o) * sum_{rows of group g} Wv     (uniform mix: w_uni * sum_rows Wv)
             const int g = tid / r, j = tid % r;
-            float sacc = 0.f;
-            for (int row = rs0; row < rs1; ++row) sacc += mixw(row, g) * Wv[row * 16 + j];
-            p.ds_part[((size_t)(tm * tiles_n + tn) * p.G + g) * r + j] = sacc;
+            float all = 0.f, own = 0.f, uni = 0.f;
+            for (int row = rs0; row < rs1; ++row) {
+                const float w = Wv[row * 16 + j];
+                const int a = Ga[row];
+                if (a < 0) uni += w; else { all += w; if (a == g) own += w; }
+            }
+            p.ds_part[((size_t)(tm * tiles_n + tn) * p.G + g) * r + j] = w_uni * uni + w_oth * all + (w_own - w_oth) * own;
         }
         // rank-r update on the matrix cores: acc += TsA . LwB^T (K = 32 rank slots, zero padded)
         frag_t lb[NF];
