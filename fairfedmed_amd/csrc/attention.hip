@@ -10,7 +10,7 @@
 // K / Q / dO are staged TRANSPOSED in LDS ([64 d][tokens], zero padded).
 //
 //   forward : one block per (b, h, q-split); waves own 16-row q tiles.
-//   backward: delta = rowsum(dO * O); dQ kernel (same shape as forward);
+//   backward: dQ kernel (same shape as forward); delta = rowsum(dO * O) is formed inside both kernels;
 //             dK/dV kernel: waves own 16-key tiles and sweep all queries.
 #include "common.h"
 
@@ -234,34 +234,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
-// ---------------------------------------------------------------------------
-// backward: delta[b,h,q] = sum_d dO[q][d] * O[q][d]
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
-                                                         float* __restrict__ delta, int B, int L, int heads) {
-    // 8 lanes per (row, head): each loads 8 consecutive d (16 B bf16 / 2 x 16 B f32), 3 shuffles combine them
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int pair = gid >> 3, sub = gid & 7;                     // pair = row * heads + h
-    const bool ok = pair < B * L * heads;
-    const int h = ok ? pair % heads : 0, row = ok ? pair / heads : 0;
-    const size_t off = (size_t)row * heads * HD + h * HD + sub * 8;
-    float a[8], g[8];
-    Vec8<T>::load(o + off, a);
-    Vec8<T>::load(d_o + off, g);
-    float v = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v += a[e] * g[e];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if (ok && sub == 0) {
-        const int b = row / L, l = row % L;
-        delta[((size_t)b * heads + h) * L + l] = v;
-    }
-}
-
-// Backward kernels: 8 waves per block, one block per (b, h).  With STAGED (bf16) the row-major
+// Backward kernels: one block per (b, h), one wave per 16-token tile (bf16; 4 waves in f32 mode).  With STAGED (bf16) the row-major
 // operand tiles live in LDS next to the transposed ones; the f32 parity mode would need > 160 KB
 // for that and reads those fragments from global memory (L2) instead.
 
@@ -279,7 +252,7 @@ template <typename T, int NFP, bool STAGED, int BW_THREADS>
 __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __restrict__ qkv,
                                                                  const T* __restrict__ d_o,
                                                                  const float* __restrict__ lse,
-                                                                 const float* __restrict__ delta,
+                                                                 const T* __restrict__ o_fwd,
                                                                  T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,68 +290,58 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __rest
             dof[ks] = gfrag<T>(dob, E, q, L, ks, g);
         }
         const float lq = lse[((size_t)b * heads + h) * L + qc];
-        const float dl = delta[((size_t)b * heads + h) * L + qc];
-
-        f32x4 ds[NFP];
-        frag_t kcur[AT<T>::ND], vcur[AT<T>::ND];
+        // delta[q] = sum_d dO[q][d] O[q][d]: the lane already holds 16 of the 64 dO values of its query; the four lane
+        // groups of the column cover the row (this replaced a separate kernel and its launch)
+        float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < AT<T>::ND; ++ks) {
-            kcur[ks] = opfrag<T, STAGED>(Ks, base + E, ld, col, L, ks, g);
-            vcur[ks] = opfrag<T, STAGED>(Vs, base + 2 * E, ld, col, L, ks, g);
+            const frag_t of = gfrag<T>(o_fwd + (size_t)b * L * E + h * HD, E, q, L, ks, g);
+#pragma unroll
+            for (int e = 0; e < AT<T>::CE; ++e) dl += (float)of[e] * (float)dof[ks][e];
         }
+        dl = group4_sum(dl);
+
+        // dS^T of one k-step (FPK key fragments) is formed and consumed right away (no 14-fragment array, no software
+        // prefetch: the other waves of the SIMD cover the LDS round trips, the registers saved keep 3-4 of them there)
+        f32x4 dq[4];
 #pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            frag_t knxt[AT<T>::ND], vnxt[AT<T>::ND];      // f+1 in flight while f multiplies
-            const int fn = (f + 1 < NFP) ? f + 1 : f;
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                knxt[ks] = opfrag<T, STAGED>(Ks, base + E, ld, fn * 16 + col, L, ks, g);
-                vnxt[ks] = opfrag<T, STAGED>(Vs, base + 2 * E, ld, fn * 16 + col, L, ks, g);
-            }
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                Mma16<T>::mma(sa, kcur[ks], qf[ks]);
-                Mma16<T>::mma(pa, vcur[ks], dof[ks]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = f * 16 + g * 4 + e;
-                float v = 0.f;
-                if (key < L && !(causal && key > q)) {
-                    const float p = fast_expf(sa[e] * 0.125f - lq);
-                    v = p * (pa[e] - dl) * 0.125f;
-                }
-                sa[e] = v;
-            }
-            ds[f] = sa;
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) { kcur[ks] = knxt[ks]; vcur[ks] = vnxt[ks]; }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 o[4];
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int NST = NFP / AT<T>::FPK;
-        frag_t tcur[4];
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd) tcur[fd] = AT<T>::tfrag(Kt, ts, fd * 16 + col, 0, g);
+        for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int FPK = AT<T>::FPK, NST = NFP / FPK;
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            frag_t tnxt[4];
+            f32x4 d2[FPK];
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) tnxt[fd] = AT<T>::tfrag(Kt, ts, fd * 16 + col, st + 1 < NST ? st + 1 : st, g);
-            const frag_t pf = AT<T>::pack(ds, st);
+            for (int ff = 0; ff < FPK; ++ff) {
+                const int f = st * FPK + ff;
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) Mma16<T>::mma(o[fd], tcur[fd], pf);
+                for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                    const frag_t kc = opfrag<T, STAGED>(Ks, base + E, ld, f * 16 + col, L, ks, g);
+                    const frag_t vc = opfrag<T, STAGED>(Vs, base + 2 * E, ld, f * 16 + col, L, ks, g);
+                    Mma16<T>::mma(sa, kc, qf[ks]);
+                    Mma16<T>::mma(pa, vc, dof[ks]);
+                }
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) tcur[fd] = tnxt[fd];
+                for (int e = 0; e < 4; ++e) {
+                    const int key = f * 16 + g * 4 + e;
+                    float v = 0.f;
+                    if (key < L && !(causal && key > q)) {
+                        const float p = fast_expf(sa[e] * 0.125f - lq);
+                        v = p * (pa[e] - dl) * 0.125f;
+                    }
+                    sa[e] = v;
+                }
+                d2[ff] = sa;
+            }
+            const frag_t df = AT<T>::pack(d2, 0);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) Mma16<T>::mma(dq[fd], AT<T>::tfrag(Kt, ts, fd * 16 + col, st, g), df);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q < L) {
             T* drow = dqkv + ((size_t)b * L + q) * ld + h * HD;
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) Vec4<T>::store(drow + fd * 16 + g * 4, o[fd]);
+            for (int fd = 0; fd < 4; ++fd) Vec4<T>::store(drow + fd * 16 + g * 4, dq[fd]);
         }
     }
 }
@@ -390,7 +353,7 @@ template <typename T, int NFP, bool STAGED, int BW_THREADS>
 __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __restrict__ qkv,
                                                                   const T* __restrict__ d_o,
                                                                   const float* __restrict__ lse,
-                                                                  const float* __restrict__ delta,
+                                                                  const T* __restrict__ o_fwd,
                                                                   T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -416,9 +379,34 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
         stage_rowmajor<T, LP, BW_THREADS>(base, ld, L, Qs, tid);
         stage_rowmajor<T, LP, BW_THREADS>(dob, E, L, dOs, tid);
     }
-    for (int i = tid; i < LP; i += BW_THREADS) {
-        lse_s[i] = i < L ? lse[((size_t)b * heads + h) * L + i] : 0.f;
-        del_s[i] = i < L ? delta[((size_t)b * heads + h) * L + i] : 0.f;
+    for (int i = tid; i < LP; i += BW_THREADS) lse_s[i] = i < L ? lse[((size_t)b * heads + h) * L + i] : 0.f;
+    // delta[q] = sum_d dO[q][d] O[q][d], 4 threads per query row (16 values each), all loads issued before the sums
+    {
+        const T* ob = o_fwd + (size_t)b * L * E + h * HD;
+        constexpr int NQ = (4 * LP + BW_THREADS - 1) / BW_THREADS, NC = 16 / AT<T>::CE;
+        frag_t fo[NQ][NC], fd[NQ][NC];
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            const int idx = tid + it * BW_THREADS, row = idx >> 2, part = idx & 3;
+            const int rr = row < L ? row : L - 1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                fo[it][c] = *reinterpret_cast<const frag_t*>(ob + (size_t)rr * E + part * 16 + c * AT<T>::CE);
+                fd[it][c] = *reinterpret_cast<const frag_t*>(dob + (size_t)rr * E + part * 16 + c * AT<T>::CE);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NQ; ++it) {
+            const int idx = tid + it * BW_THREADS, row = idx >> 2;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int e = 0; e < AT<T>::CE; ++e) acc += (float)fo[it][c][e] * (float)fd[it][c][e];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if ((idx & 3) == 0 && row < LP) del_s[row] = row < L ? acc : 0.f;
+        }
     }
     __syncthreads();
 
@@ -432,73 +420,52 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
             kf[ks] = gfrag<T>(base + E, ld, key, L, ks, g);
             vf[ks] = gfrag<T>(base + 2 * E, ld, key, L, ks, g);
         }
-        f32x4 pp[NFP], ds[NFP];
-        frag_t qcur[AT<T>::ND], dcur[AT<T>::ND];
-#pragma unroll
-        for (int ks = 0; ks < AT<T>::ND; ++ks) {
-            qcur[ks] = opfrag<T, STAGED>(Qs, base, ld, col, L, ks, g);
-            dcur[ks] = opfrag<T, STAGED>(dOs, dob, E, col, L, ks, g);
-        }
-#pragma unroll
-        for (int f = 0; f < NFP; ++f) {
-            frag_t qnxt[AT<T>::ND], dnxt[AT<T>::ND];
-            const int fn = (f + 1 < NFP) ? f + 1 : f;
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                qnxt[ks] = opfrag<T, STAGED>(Qs, base, ld, fn * 16 + col, L, ks, g);
-                dnxt[ks] = opfrag<T, STAGED>(dOs, dob, E, fn * 16 + col, L, ks, g);
-            }
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) {
-                Mma16<T>::mma(sa, qcur[ks], kf[ks]);
-                Mma16<T>::mma(pa, dcur[ks], vf[ks]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int q = f * 16 + g * 4 + e;
-                float p = 0.f, d = 0.f;
-                if (q < L && key < L && !(causal && key > q)) {
-                    p = fast_expf(sa[e] * 0.125f - lse_s[q]);
-                    d = p * (pa[e] - del_s[q]) * 0.125f;
-                }
-                sa[e] = p;
-                pa[e] = d;
-            }
-            pp[f] = sa;
-            ds[f] = pa;
-#pragma unroll
-            for (int ks = 0; ks < AT<T>::ND; ++ks) { qcur[ks] = qnxt[ks]; dcur[ks] = dnxt[ks]; }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // The two products of a k-step (FPK query fragments) are formed and consumed right away: P and dS of the whole
+        // query range are never live together (that was 112 registers and kept this kernel at 2 waves per SIMD).
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int fd = 0; fd < 4; ++fd) { dv[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        constexpr int NST = NFP / AT<T>::FPK;
-        frag_t a1c[4], a2c[4];
-#pragma unroll
-        for (int fd = 0; fd < 4; ++fd) {
-            a1c[fd] = AT<T>::tfrag(dOt, ts, fd * 16 + col, 0, g);
-            a2c[fd] = AT<T>::tfrag(Qt, ts, fd * 16 + col, 0, g);
-        }
+        constexpr int FPK = AT<T>::FPK, NST = NFP / FPK;
+        // (No software prefetch of the next fragments here: at 3-4 waves per SIMD the other waves cover the LDS
+        // round trip, and the prefetch registers are exactly what would push the kernel over 128 VGPRs.)
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            frag_t a1n[4], a2n[4];
-            const int sn = st + 1 < NST ? st + 1 : st;
+            f32x4 p2[FPK], d2[FPK];
+#pragma unroll
+            for (int ff = 0; ff < FPK; ++ff) {
+                const int f = st * FPK + ff;
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < AT<T>::ND; ++ks) {
+                    const frag_t qc = opfrag<T, STAGED>(Qs, base, ld, f * 16 + col, L, ks, g);
+                    const frag_t dc = opfrag<T, STAGED>(dOs, dob, E, f * 16 + col, L, ks, g);
+                    Mma16<T>::mma(sa, qc, kf[ks]);
+                    Mma16<T>::mma(pa, dc, vf[ks]);
+                }
+                const int qb = f * 16 + g * 4;                    // this lane's 4 consecutive queries
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[qb]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[qb]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = qb + e;
+                    float p = 0.f, d = 0.f;
+                    if (q < L && key < L && !(causal && key > q)) {
+                        p = fast_expf(sa[e] * 0.125f - l4[e]);
+                        d = p * (pa[e] - d4[e]) * 0.125f;
+                    }
+                    sa[e] = p;
+                    pa[e] = d;
+                }
+                p2[ff] = sa;
+                d2[ff] = pa;
+            }
+            const frag_t pf = AT<T>::pack(p2, 0);
+            const frag_t df = AT<T>::pack(d2, 0);
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
-                a1n[fd] = AT<T>::tfrag(dOt, ts, fd * 16 + col, sn, g);
-                a2n[fd] = AT<T>::tfrag(Qt, ts, fd * 16 + col, sn, g);
+                Mma16<T>::mma(dv[fd], AT<T>::tfrag(dOt, ts, fd * 16 + col, st, g), pf);
+                Mma16<T>::mma(dk[fd], AT<T>::tfrag(Qt, ts, fd * 16 + col, st, g), df);
             }
-            const frag_t pf = AT<T>::pack(pp, st);
-            const frag_t df = AT<T>::pack(ds, st);
-#pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                Mma16<T>::mma(dv[fd], a1c[fd], pf);
-                Mma16<T>::mma(dk[fd], a2c[fd], df);
-            }
-#pragma unroll
-            for (int fd = 0; fd < 4; ++fd) { a1c[fd] = a1n[fd]; a2c[fd] = a2n[fd]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (key < L) {
@@ -513,7 +480,10 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
 }
 
 template <typename T> constexpr bool kStaged() { return sizeof(T) == 2; }
-template <typename T> constexpr int kBwThreads() { return sizeof(T) == 2 ? 512 : 256; }   // f32 needs the 512-VGPR budget
+// bf16: one wave per 16-token tile (a 16-row tile of dQ or a 16-key tile of dK/dV), up to 14 waves per block, so a
+// wave never runs two tiles back to back (with 8 waves the 13 tiles of L = 197 took two rounds inside every block);
+// longer sequences fall back to 8 waves.  f32 needs the 512-VGPR budget of 256 threads.
+template <typename T, int NFP> constexpr int kBwThreads() { return sizeof(T) == 2 ? (NFP <= 14 ? (NFP < 8 ? 512 : 64 * NFP) : 512) : 256; }
 template <typename T> int lds_fwd(int NFP) { return NFP * 16 * AT<T>::ROWB + HD * tstride<T>(NFP * 16) * AT<T>::ES; }
 template <typename T> int lds_dq(int NFP) {
     return HD * tstride<T>(NFP * 16) * AT<T>::ES + (kStaged<T>() ? 2 * NFP * 16 * AT<T>::ROWB : 0);
@@ -564,20 +534,18 @@ int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int
 template <typename T, int NFP>
 int run_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
             int L, int heads, int causal, hipStream_t s) {
-    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((B * L * heads * 8 + 255) / 256), dim3(256), 0, s, (const T*)out,
-                       (const T*)dout, delta, B, L, heads);
-    FFM_CHECK_LAUNCH();
+    (void)delta;          // kept in the ABI as scratch; the row sums of dO * O are formed inside the two kernels
     int lds = lds_dq<T>(NFP);
-    int e = set_lds(attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>, lds);
+    int e = set_lds(attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T, NFP>()>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>), dim3(B * heads), dim3(kBwThreads<T>()), lds, s,
-                       (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NFP, kStaged<T>(), kBwThreads<T, NFP>()>), dim3(B * heads), dim3(kBwThreads<T, NFP>()), lds, s,
+                       (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv, L, heads, causal);
     FFM_CHECK_LAUNCH();
     lds = lds_dkv<T>(NFP);
-    e = set_lds(attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>, lds);
+    e = set_lds(attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T, NFP>()>, lds);
     if (e) return e;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T>()>), dim3(B * heads), dim3(kBwThreads<T>()), lds, s,
-                       (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, L, heads, causal);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NFP, kStaged<T>(), kBwThreads<T, NFP>()>), dim3(B * heads), dim3(kBwThreads<T, NFP>()), lds, s,
+                       (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv, L, heads, causal);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

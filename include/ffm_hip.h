@@ -185,7 +185,8 @@ int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int 
 
 /*
  * Backward of the above: given dout, recomputes P from qkv and lse and writes
- * dqkv [B*L, 3*heads*64].  delta: [B, heads, L] fp32 scratch.
+ * dqkv [B*L, 3*heads*64].  delta: [B, heads, L] fp32, unused (the row sums
+ * of dO * O are formed inside the kernels since ABI 3); kept so that callers need not change.
  */
 int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                       float* delta, void* dqkv, int B, int L, int heads, int causal,
