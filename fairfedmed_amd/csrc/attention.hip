@@ -513,11 +513,12 @@ int run_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int
     const int NF = (L + 15) / 16;
     const int lds = lds_fwd<T>(NFP);
     if (sizeof(T) == 2 && B * heads >= 256 && NF >= 8) {
-        // enough (b, h) pairs to fill the chip: 8 waves per block and no q-split, so K / V are staged once per pair
-        // (two blocks of 58 KB per CU hold all 384 pairs of the bs-32 step in one round)
-        int e = set_lds(attn_fwd_kernel<T, NFP, 512>, lds);
+        // enough (b, h) pairs to fill the chip: one wave per 16-query tile and no q-split, so K / V are staged once
+        // per pair and no wave runs two tiles back to back
+        constexpr int NTH = NFP <= 14 ? 64 * NFP : 512;
+        int e = set_lds(attn_fwd_kernel<T, NFP, NTH>, lds);
         if (e) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, NFP, 512>), dim3(B * heads, 1), dim3(512), lds, s, (const T*)qkv, (T*)out,
+        hipLaunchKernelGGL((attn_fwd_kernel<T, NFP, NTH>), dim3(B * heads, 1), dim3(NTH), lds, s, (const T*)qkv, (T*)out,
                            lse, L, heads, causal, 1);
         FFM_CHECK_LAUNCH();
         return FFM_OK;
