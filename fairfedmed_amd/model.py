@@ -139,12 +139,18 @@ class FairLoRALinear(nn.Module):
         assert num_attrs > 0, "Number of attributes must be provided!"
         if global_s:
             raise NotImplementedError("GLOBAL_S is False in every FairLoRA script; not built")
-        if original_linear.weight.dim() != 2:
-            raise NotImplementedError("1x1-conv FairLoRA (RN50, BASELINE configs[4]) is not built yet")
+        self.is_1x1_conv = isinstance(original_linear, nn.Conv2d)
+        if self.is_1x1_conv:
+            # RN50 form (trainers/GLP_OT_SVLoRA.py:344-352, 469-480): a 1x1 convolution is the same product on the
+            # rows (b, h, w) of the NHWC view of the feature map
+            if original_linear.kernel_size != (1, 1) or original_linear.stride != (1, 1) or original_linear.groups != 1:
+                raise NotImplementedError("FairLoRA wraps 1x1, stride-1 convolutions only")
+            fin, fout = original_linear.in_channels, original_linear.out_channels
+        else:
+            fin, fout = original_linear.in_features, original_linear.out_features
         self.original_linear = original_linear
         self.rank, self.alpha, self.scaling = rank, alpha, alpha / rank
-        self.global_s, self.num_attrs, self.is_1x1_conv = global_s, num_attrs, False
-        fin, fout = original_linear.in_features, original_linear.out_features
+        self.global_s, self.num_attrs = global_s, num_attrs
         self.lora_A, self.lora_S, self.lora_B = _Emb(fin, rank), _Emb(num_attrs, rank), _Emb(rank, fout)
         dev = original_linear.weight.device
         self.to(dev)
@@ -164,6 +170,7 @@ class FairLoRALinear(nn.Module):
 
     def _frozen(self, dtype):
         w = self.original_linear.weight
+        w = w.reshape(w.shape[0], -1)
         if self._cache is None or self._cache[0] != (w.data_ptr(), w._version, dtype):
             self._cache = ((w.data_ptr(), w._version, dtype), ops.cast_from_f32(w.detach().float(), dtype),
                            ops.transpose_cast(w.detach().float(), dtype))
@@ -173,6 +180,16 @@ class FairLoRALinear(nn.Module):
         """x: [L, Bn, in] token-major as in the reference (clip/model.py:438); Bn = b*S."""
         if not x.is_cuda:
             raise RuntimeError("FairLoRALinear runs on the MI355X HIP kernels only; there is no CPU path")
+        if self.is_1x1_conv:
+            Bn, fin, H, Wd = x.shape                       # x: [Bn, C, H, W] -> rows (b, h, w)
+            b = Bn if attr is None else attr.shape[0]
+            W, Wt = self._frozen(x.dtype)
+            x2d = x.permute(0, 2, 3, 1).reshape(Bn * H * Wd, fin).contiguous()
+            bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
+            a32 = None if attr is None else attr.to(torch.int32).contiguous()
+            y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight, self.lora_B.weight, a32,
+                                  H * Wd * (Bn // b), self.scaling, 0.7)
+            return y.reshape(Bn, H, Wd, -1).permute(0, 3, 1, 2)
         L, Bn, fin = x.shape
         b = Bn if attr is None else attr.shape[0]
         S = Bn // b
@@ -183,6 +200,49 @@ class FairLoRALinear(nn.Module):
         y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight, self.lora_B.weight, a32,
                               L * S, self.scaling, 0.7)
         return y.reshape(Bn, L, -1).permute(1, 0, 2)
+
+
+class LoRALinear(nn.Module):
+    """Plain LoRA, y = x W^T + b + (alpha / r) (x A) B (trainers/GLP_OT_SVLoRA.py:203-252; the RN50 attention pool's
+    q/k/v/c projections).  It is the FairLoRA product with one group and s = 1, so it runs on the same kernels.
+    (The reference's SVLoRALinear is not mirrored: its forward applies torch.diag to an [r, 1] weight, which only
+    type-checks for r = 1, and no script selects it.)"""
+
+    def __init__(self, original_linear: nn.Linear, rank: int = 4, alpha: float = 0.04):
+        super().__init__()
+        self.original_linear = original_linear
+        self.rank, self.alpha, self.scaling = rank, alpha, alpha / rank
+        self.lora_A, self.lora_B = _Emb(original_linear.in_features, rank), _Emb(rank, original_linear.out_features)
+        self.to(original_linear.weight.device)
+        self.register_buffer("_ones", torch.ones(1, rank, device=original_linear.weight.device), persistent=False)
+        for p in self.original_linear.parameters():
+            p.requires_grad = False
+        self.reset_parameters()
+        self._cache = None
+
+    def reset_parameters(self):
+        nn.init.zeros_(self.lora_A.weight)
+        nn.init.normal_(self.lora_B.weight)
+
+    def weight(self, x=None, attr=None):
+        """Dense W + scaling (A B)^T, as the attention pool consumes it (clip/model.py:90-93)."""
+        return self.original_linear.weight + self.scaling * (self.lora_A.weight @ self.lora_B.weight).t()
+
+    def bias(self):
+        return self.original_linear.bias
+
+    _frozen = FairLoRALinear._frozen
+
+    def forward(self, x: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("LoRALinear runs on the MI355X HIP kernels only; there is no CPU path")
+        lead, fin = x.shape[:-1], x.shape[-1]
+        W, Wt = self._frozen(x.dtype)
+        x2d = x.reshape(-1, fin).contiguous()
+        bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
+        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self._ones, self.lora_B.weight, None,
+                              x2d.shape[0], self.scaling, 0.7)
+        return y.reshape(*lead, -1)
 
 
 def apply_lora_to_model(model: nn.Module, unfreeze_image_encoder: bool, rank: int = 4, alpha: float = 0.04,

@@ -196,6 +196,28 @@ def golden_layers(M, out):
         print("layer", name, "y", tuple(y.shape), "|dA|", float(layer.lora_A.weight.grad.norm()))
 
 
+def golden_lora_plain(M, out):
+    """LoRALinear (plain LoRA, the RN50 attention-pool projections): forward, input/LoRA gradients, dense weight()."""
+    import torch.nn as nn
+    L, Bn, fin, fout, r = 50, 4, 128, 192, 8
+    x = rng_tensor("lora_plain.x", (L, Bn, fin))
+    g = rng_tensor("lora_plain.g", (L, Bn, fout))
+    lin = nn.Linear(fin, fout)
+    lin.weight.data = rng_tensor("lora_plain.W", (fout, fin)) * fin ** -0.5
+    lin.bias.data = rng_tensor("lora_plain.b", (fout,)) * 0.1
+    layer = M.LoRALinear(lin, rank=r, alpha=2.0)
+    layer.lora_A.weight.data = rng_tensor("lora_plain.A", (fin, r)) * 0.1
+    layer.lora_B.weight.data = rng_tensor("lora_plain.B", (r, fout))
+    xin = x.clone().requires_grad_(True)
+    y = layer(xin)
+    y.backward(g)
+    out["lora_plain.y"] = y.detach().numpy()
+    out["lora_plain.dx"] = xin.grad.numpy()
+    out["lora_plain.dA"] = layer.lora_A.weight.grad.numpy()
+    out["lora_plain.dB"] = layer.lora_B.weight.grad.numpy()
+    out["lora_plain.weight"] = layer.weight(x).detach().numpy()
+
+
 def golden_s_init(M, out):
     import torch.nn as nn
     for r in (4, 8, 12, 16, 32):
@@ -316,6 +338,7 @@ def main():
 
     out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
     golden_layers(M, out)
+    golden_lora_plain(M, out)
     golden_s_init(M, out)
     golden_fedavg(FU, out, meta)
     golden_auc(compute_auc, out, meta)

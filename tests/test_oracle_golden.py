@@ -57,6 +57,23 @@ def test_fairlora_layer(unit, case):
     close(dB.numpy(), unit[f"layer.{name}.dB"], rtol=2e-5, atol=2e-6, what="dB")
 
 
+def test_lora_plain_layer(unit):
+    """LoRALinear (plain LoRA) == the FairLoRA product with one group and s = 1; weight() is W + scaling (A B)^T."""
+    L, Bn, fin, fout, r = 50, 4, 128, 192, 8
+    x, g = rng_tensor("lora_plain.x", (L, Bn, fin)), rng_tensor("lora_plain.g", (L, Bn, fout))
+    W = rng_tensor("lora_plain.W", (fout, fin)) * fin ** -0.5
+    bias = rng_tensor("lora_plain.b", (fout,)) * 0.1
+    A, Bm = rng_tensor("lora_plain.A", (fin, r)) * 0.1, rng_tensor("lora_plain.B", (r, fout))
+    ones = torch.ones(1, r)
+    y = O.fairlora_linear(x, W, bias, A, ones, Bm, None, 2.0 / r)
+    dx, dA, dS, dB = O.fairlora_backward(x, g, W, A, ones, Bm, None, 2.0 / r)
+    close(y.numpy(), unit["lora_plain.y"], rtol=2e-5, atol=2e-6, what="y")
+    close(dx.numpy(), unit["lora_plain.dx"], rtol=2e-5, atol=2e-6, what="dx")
+    close(dA.numpy(), unit["lora_plain.dA"], rtol=2e-5, atol=2e-6, what="dA")
+    close(dB.numpy(), unit["lora_plain.dB"], rtol=2e-5, atol=2e-6, what="dB")
+    close((W + (2.0 / r) * (A @ Bm).t()).numpy(), unit["lora_plain.weight"], rtol=1e-6, atol=1e-7, what="weight()")
+
+
 def test_fairlora_backward_matches_autograd():
     case = LAYER_CASES[0]
     name, L, Bn, fin, fout, r, G, S, hw = case

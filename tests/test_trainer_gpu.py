@@ -43,31 +43,67 @@ def test_state_dict_keys_shapes_and_sharing():
     assert float(model.engine.params.view("prompt_learner.ctx").abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", [c for c in LAYER_CASES if c[8] is None], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: c[0])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_fairlora_linear_vs_reference_golden(golden_dir, case, dtype):
-    """FairLoRALinear.forward/backward (HIP) vs the imported reference layer."""
+    """FairLoRALinear.forward/backward (HIP) vs the imported reference layer, nn.Linear and 1x1-conv (RN50) forms."""
     from fairfedmed_amd.model import FairLoRALinear
     unit = np.load(os.path.join(golden_dir, "unit.npz"))
     name, L, Bn, fin, fout, r, G, S, hw = case
     x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
-    lin = torch.nn.Linear(fin, fout)
-    lin.weight.data, lin.bias.data = W.clone(), bias.clone()
+    if hw:
+        lin = torch.nn.Conv2d(fin, fout, 1, bias=False)
+        lin.weight.data = W.reshape(fout, fin, 1, 1).clone()
+    else:
+        lin = torch.nn.Linear(fin, fout)
+        lin.weight.data, lin.bias.data = W.clone(), bias.clone()
     layer = FairLoRALinear(lin.cuda(), rank=r, alpha=2.0, num_attrs=G)
     layer.lora_A.weight.data.copy_(A)
     layer.lora_S.weight.data.copy_(Sm)
     layer.lora_B.weight.data.copy_(Bm)
-    xin = x.cuda().to(dtype).requires_grad_(True)
-    y = layer(xin, attr.cuda())
-    y.backward(g.cuda().to(dtype))
+    if hw:
+        xin = x.permute(1, 2, 0).reshape(Bn, fin, hw[0], hw[1]).cuda().to(dtype).requires_grad_(True)
+        y = layer(xin, attr.cuda())
+        y.backward(g.reshape(hw[0], hw[1], Bn, fout).permute(2, 3, 0, 1).cuda().to(dtype))
+        y_tok = y.detach().reshape(Bn, fout, -1).permute(2, 0, 1)
+        dx_tok = xin.grad.reshape(Bn, fin, -1).permute(2, 0, 1)
+    else:
+        xin = x.cuda().to(dtype).requires_grad_(True)
+        y = layer(xin, attr.cuda())
+        y.backward(g.cuda().to(dtype))
+        y_tok, dx_tok = y.detach(), xin.grad
     f32 = dtype == torch.float32
     t1, t2 = (3e-5, 1e-4) if f32 else (1.5e-2, 4e-2)
     pick = lambda t: t.float().cpu().numpy() if t.numel() <= 65536 else sub(t.float().cpu())
-    assert rel(pick(y.detach()), unit[f"layer.{name}.y"]) < t1
-    assert rel(pick(xin.grad), unit[f"layer.{name}.dx"]) < t1
+    assert rel(pick(y_tok), unit[f"layer.{name}.y"]) < t1
+    assert rel(pick(dx_tok), unit[f"layer.{name}.dx"]) < t1
     assert rel(layer.lora_A.weight.grad, unit[f"layer.{name}.dA"]) < t2
     assert rel(layer.lora_S.weight.grad, unit[f"layer.{name}.dS"]) < t2
     assert rel(layer.lora_B.weight.grad, unit[f"layer.{name}.dB"]) < t2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_lora_linear_vs_reference_golden(golden_dir, dtype):
+    """LoRALinear (plain LoRA of the RN50 attention pool) on the HIP kernels vs the imported reference layer."""
+    from fairfedmed_amd.model import LoRALinear
+    from tests.golden.make_golden import rng_tensor
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    L, Bn, fin, fout, r = 50, 4, 128, 192, 8
+    lin = torch.nn.Linear(fin, fout)
+    lin.weight.data = rng_tensor("lora_plain.W", (fout, fin)) * fin ** -0.5
+    lin.bias.data = rng_tensor("lora_plain.b", (fout,)) * 0.1
+    layer = LoRALinear(lin.cuda(), rank=r, alpha=2.0)
+    layer.lora_A.weight.data.copy_(rng_tensor("lora_plain.A", (fin, r)) * 0.1)
+    layer.lora_B.weight.data.copy_(rng_tensor("lora_plain.B", (r, fout)))
+    xin = rng_tensor("lora_plain.x", (L, Bn, fin)).cuda().to(dtype).requires_grad_(True)
+    y = layer(xin)
+    y.backward(rng_tensor("lora_plain.g", (L, Bn, fout)).cuda().to(dtype))
+    t1, t2 = (3e-5, 1e-4) if dtype == torch.float32 else (1.5e-2, 4e-2)
+    assert rel(y.detach().float().cpu(), unit["lora_plain.y"]) < t1
+    assert rel(xin.grad.float().cpu(), unit["lora_plain.dx"]) < t1
+    assert rel(layer.lora_A.weight.grad, unit["lora_plain.dA"]) < t2
+    assert rel(layer.lora_B.weight.grad, unit["lora_plain.dB"]) < t2
+    assert rel(layer.weight().detach(), unit["lora_plain.weight"]) < 1e-6
 
 
 def make_cfg(prec="fp32", rank=4, bs=8):
