@@ -1,0 +1,240 @@
+"""Federated round loop of the FairLoRA runs: the ``FedOTPLoRA`` branch of the reference's
+``federated_main.py`` (:604-726) and ``average_weights_EMA`` (utils/fed_utils.py:42-100) for a list of clients.
+
+SURVEY §8(f) rank 1.  Same flag names as the reference's argparse (``--num_users --frac --round --avg_prompt
+--num_prompt --idxs_users_train --idxs_users_test --shared_half_s``), carried in ``FedArgs``.  The loop is control
+plane: it sequences ``trainer.train / trainer.test / model.state_dict / load_state_dict(strict=False)`` and
+averages a few hundred KB of trainable tensors per round; the local training it calls is the HIP engine.
+
+Two drivers:
+  * ``run_fedotplora``        one process, clients trained one after the other on one GPU (the reference's shape);
+  * ``run_fedotplora_ranks``  one process per GPU under torch.distributed: the round's clients are dealt
+    round-robin to the ranks, every rank trains its share, and the weighted sum is ONE all-reduce of the flat
+    trainable buffer (fedavg.element_weights gives the reference's per-element weights).
+"""
+from __future__ import annotations
+
+import copy
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class FedArgs:
+    """The reference's CLI flags that the FedOTPLoRA branch reads (federated_main.py:791-881)."""
+    num_users: int
+    frac: float = 1.0
+    round: int = 50
+    avg_prompt: int = 1
+    num_prompt: int = 2
+    idxs_users_train: List[int] = field(default_factory=list)
+    idxs_users_test: List[int] = field(default_factory=list)
+    shared_half_s: bool = False
+    local_s: bool = False                 # cfg.TRAINER.GLP_OT_LORA.LOCAL_S
+    seed: Optional[int] = None            # seeds numpy's global generator like the reference's set_random_seed
+
+
+def average_weights_ema(w_g: Dict[str, Tensor], w: Dict[int, Dict[str, Tensor]], idxs_users: Sequence[int],
+                        datanumber_client: Sequence[int], datanumber_client_by_attr, epoch: int, max_epoch: int,
+                        beta: float = 0.999, shared_half_s: bool = False) -> Dict[str, Tensor]:
+    """Weighted FedAvg + EMA with the previous global weights (utils/fed_utils.py:42-100).  Entries are weighted
+    by n_k / sum n; row g of every ``lora_S`` [G, r] tensor by n_{k,g} / sum_k n_{k,g}; optional column mean over the
+    groups on the first half of the rank ("shared_half_s"); then (1 - b) avg + b w_g with b = beta * epoch / max_epoch."""
+    idxs_users = [int(u) for u in idxs_users]
+    total = sum(datanumber_client[u] for u in idxs_users)
+    by_attr = tot_by_attr = None
+    if datanumber_client_by_attr is not None:
+        by_attr = torch.tensor(datanumber_client_by_attr)
+        tot_by_attr = by_attr[idxs_users].sum(0)
+    G = None if by_attr is None else by_attr.shape[1]
+    beta_decay = beta * (epoch / max(max_epoch, 1))
+    out: Dict[str, Tensor] = {}
+    for key, first in w[idxs_users[0]].items():
+        grouped = by_attr is not None and "lora_S" in key and first.shape[0] == G
+        acc = None
+        for u in idxs_users:
+            x = w[u][key]
+            if grouped:
+                term = x * (by_attr[u] / tot_by_attr)[:, None].to(x.device)
+            else:
+                term = x * (datanumber_client[u] / total)
+            acc = term if acc is None else acc + term
+        if shared_half_s and grouped:
+            n_groups, n_dim = acc.shape
+            acc = torch.cat([acc[:, : n_dim // 2].mean(0, keepdim=True).repeat(n_groups, 1), acc[:, n_dim // 2:]], dim=1)
+        out[key] = (1 - beta_decay) * acc + beta_decay * w_g[key]
+    return out
+
+
+def select_clients(epoch: int, args: FedArgs, dataset_users: int) -> List[int]:
+    """federated_main.py:606-613: an explicit list wins; round 0 trains every client; later rounds draw
+    max(int(frac * num_users), 1) of them without replacement from numpy's global generator."""
+    if len(args.idxs_users_train) > 0:
+        return list(args.idxs_users_train)
+    if epoch == 0:
+        return list(range(dataset_users))
+    m = max(int(args.frac * args.num_users), 1)
+    return [int(i) for i in np.random.choice(range(args.num_users), m, replace=False)]
+
+
+def personalize(global_weights: Dict[str, Tensor], idx: int, args: FedArgs, local_ctx: Dict[int, Tensor],
+                local_s: Dict[int, Dict[str, Tensor]]) -> Dict[str, Tensor]:
+    """federated_main.py:645-652: a client listed in --idxs_users_train keeps its own local prompts
+    ctx[avg_prompt:num_prompt] and, under LOCAL_S, its own lora_S tensors; everything else is the new global."""
+    w = copy.deepcopy(global_weights)
+    if idx in args.idxs_users_train:
+        w["prompt_learner.ctx"][args.avg_prompt:args.num_prompt] = local_ctx[idx]
+        if args.local_s:
+            for k, v in local_s[idx].items():
+                w[k] = v
+    return w
+
+
+def _counts(trainer, attribute: str, n_users: int):
+    n_client = [len(trainer.fed_train_loader_x_dict[i].dataset) for i in range(n_users)]
+    by_attr = [trainer.fed_train_loader_x_dict[i].dataset.count_by_attribute(attribute) for i in range(n_users)]
+    return n_client, by_attr
+
+
+def run_fedotplora(trainer, args: FedArgs, attribute: Optional[str] = None, log=print) -> Dict[str, list]:
+    """One process, one GPU: the reference's round loop verbatim in structure.  Returns the per-round means of
+    [accuracy, error_rate, macro_f1, auc] over the tested clients, and the final per-client weights."""
+    cfg = trainer.cfg
+    users = cfg.DATASET.USERS if hasattr(cfg.DATASET, "USERS") else args.num_users
+    attribute = attribute or cfg.DATASET.ATTRIBUTE_TYPE
+    if args.seed is not None:
+        np.random.seed(args.seed)
+    n_client, by_attr = _counts(trainer, attribute, users)
+    trainer.fed_before_train()
+    # Only the trainable tensors travel: the reference averages the whole state_dict, but frozen tensors are
+    # identical on every client, so their weighted mean is the tensor itself up to one rounding per round
+    # (SURVEY §5 quirk 10); leaving them out also keeps the engine's packed copies of the frozen weights valid.
+    keys = set(trainer.engine.params.keys) if hasattr(trainer, "engine") else None
+    snap = lambda: copy.deepcopy({k: v for k, v in trainer.model.state_dict().items() if keys is None or k in keys})
+    global_weights = snap()
+    local_weights: Dict[int, Dict[str, Tensor]] = {}
+    local_weights_per = {i: copy.deepcopy(global_weights) for i in range(users)}
+    local_ctx: Dict[int, Tensor] = {}
+    local_s: Dict[int, Dict[str, Tensor]] = {}
+    hist = {"acc": [], "err": [], "f1": [], "auc": [], "epoch": [], "time": []}
+    start = time.time()
+    for epoch in range(args.round):
+        idxs_users = select_clients(epoch, args, users)
+        log(f"------------local train start epoch: {epoch} -------------")
+        for idx in idxs_users:
+            trainer.model.load_state_dict(global_weights if epoch == 0 else local_weights_per[idx], strict=False)
+            trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
+            lw = snap()
+            local_ctx[idx] = copy.deepcopy(lw["prompt_learner.ctx"][args.avg_prompt:args.num_prompt])
+            local_s[idx] = copy.deepcopy({k: v for k, v in lw.items() if "lora_S" in k})
+            local_weights[idx] = lw
+        global_weights = average_weights_ema(global_weights, local_weights, idxs_users, n_client, by_attr, epoch,
+                                             args.round, shared_half_s=args.shared_half_s)
+        all_users = list(args.idxs_users_test) if len(args.idxs_users_test) > 0 else list(range(users))
+        results = []
+        for idx in all_users:
+            local_weights_per[idx] = personalize(global_weights, idx, args, local_ctx, local_s)
+            trainer.model.load_state_dict(local_weights_per[idx], strict=False)
+            results.append(trainer.test(idx=idx, current_epoch=epoch))
+        for name, col in (("acc", 0), ("err", 1), ("f1", 2)):
+            hist[name].append(sum(r[col] for r in results) / len(results))
+        if len(results[0]) > 3:
+            hist["auc"].append(sum(r[3] for r in results) / len(results))
+        hist["epoch"].append(epoch)
+        hist["time"].append(time.time() - start)
+        log(f"Global test acc: {hist['acc'][-1]}  macro_f1: {hist['f1'][-1]}"
+            + (f"  auc: {hist['auc'][-1]}" if hist["auc"] else ""))
+    trainer.fed_after_train()
+    hist["global_weights"] = global_weights
+    hist["local_weights_per"] = local_weights_per
+    return hist
+
+
+def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None, log=print) -> Dict[str, list]:
+    """One process per GPU.  Round r: client idxs_users[j] trains on rank j % world; every rank then contributes
+    sum_k w_k (.) theta_k of ITS clients to one all-reduce of the flat trainable buffer (RCCL over xGMI, gloo on
+    CPU), and finishes shared_half_s + EMA locally.  Frozen tensors are identical on all ranks and stay put."""
+    from .fedavg import element_weights
+    assert dist.is_initialized(), "launch under torch.distributed.run"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = trainer.cfg
+    users = cfg.DATASET.USERS if hasattr(cfg.DATASET, "USERS") else args.num_users
+    attribute = attribute or cfg.DATASET.ATTRIBUTE_TYPE
+    if args.seed is not None:
+        np.random.seed(args.seed)                       # same draws on every rank
+    n_client, by_attr = _counts(trainer, attribute, users)
+    params = trainer.engine.params
+    flat, offsets = params.flat, params.offsets
+    lo = trainer.engine.cfg.lora
+    trainer.fed_before_train()
+    global_flat = flat.detach().clone()
+    per_client = {i: global_flat.clone() for i in range(users)}      # personalised flat buffers (this rank's view)
+    ctx_off, ctx_shape = offsets["prompt_learner.ctx"]
+    n_ctx_row = int(np.prod(ctx_shape[1:]))
+    lo_a, lo_b = ctx_off + args.avg_prompt * n_ctx_row, ctx_off + args.num_prompt * n_ctx_row
+    s_slices = [(off, off + int(np.prod(shp))) for k, (off, shp) in offsets.items() if "lora_S" in k]
+    hist = {"acc": [], "err": [], "f1": [], "auc": [], "epoch": []}
+    for epoch in range(args.round):
+        idxs_users = select_clients(epoch, args, users)
+        acc = torch.zeros_like(flat)
+        local_after: Dict[int, Tensor] = {}
+        for j, idx in enumerate(idxs_users):
+            if j % world != rank:
+                continue
+            flat.copy_(global_flat if epoch == 0 else per_client[idx])
+            trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
+            local_after[idx] = flat.detach().clone()
+            w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
+            acc += w * flat
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        if args.shared_half_s:
+            G, r = lo.num_groups, lo.rank
+            for k, (off, shp) in offsets.items():
+                if "lora_S" in k and shp[0] == G:
+                    blk = acc[off:off + G * r].view(G, r)
+                    blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
+        beta_decay = 0.999 * (epoch / max(args.round, 1))
+        global_flat = (1 - beta_decay) * acc + beta_decay * global_flat
+        # personalisation needs every trained client's local prompts / lora_S on every rank that may test it:
+        # exchange them (a few KB) with one more all-reduce of a zero-padded buffer
+        keep = torch.zeros(users, flat.numel(), device=flat.device) if args.idxs_users_train else None
+        if keep is not None:
+            for idx, f in local_after.items():
+                keep[idx] = f
+            dist.all_reduce(keep, op=dist.ReduceOp.SUM)
+        all_users = list(args.idxs_users_test) if len(args.idxs_users_test) > 0 else list(range(users))
+        results = []
+        for idx in all_users:
+            per_client[idx] = global_flat.clone()
+            if idx in args.idxs_users_train and keep is not None:
+                per_client[idx][lo_a:lo_b] = keep[idx][lo_a:lo_b]
+                if args.local_s:
+                    for a, b in s_slices:
+                        per_client[idx][a:b] = keep[idx][a:b]
+        for j, idx in enumerate(all_users):                          # evaluation is dealt to the ranks as well
+            if j % world != rank:
+                continue
+            flat.copy_(per_client[idx])
+            results.append((idx, trainer.test(idx=idx, current_epoch=epoch)))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, results)
+        flat_res = [r for part in gathered for r in part]
+        for name, col in (("acc", 0), ("err", 1), ("f1", 2), ("auc", 3)):
+            vals = [r[1][col] for r in flat_res if len(r[1]) > col]
+            if vals:
+                hist[name].append(sum(vals) / len(vals))
+        hist["epoch"].append(epoch)
+        if rank == 0:
+            log(f"round {epoch}: acc {hist['acc'][-1]:.3f} f1 {hist['f1'][-1]:.3f}"
+                + (f" auc {hist['auc'][-1]:.4f}" if hist["auc"] else ""))
+    flat.copy_(global_flat)
+    trainer.fed_after_train()
+    hist["global_flat"] = global_flat
+    return hist

@@ -203,3 +203,49 @@ def test_trainer_round_api_and_lr_schedule(tmp_path):
     assert "prompt_learner.ctx" in saved and "prompt_learner.token_prefix" in saved
     assert not any("original_linear" in k for k in saved)
     tr.fed_after_train()
+
+
+def _fed_setup(users=2, rounds=2):
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData
+    import fairfedmed_amd.trainer  # noqa: F401
+    mcfg = C.vit_tiny(rank=4)
+    cfg = make_cfg(bs=8)
+    cfg.DATASET.USERS = users
+    cfg.TEST.NO_TEST = True
+    cfg.TRAIN.METRICS_EVERY = 0
+    cfg.DATA = SyntheticFedData(mcfg, users, 2, 1, 8, signal=0.3)
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+    return build_trainer(cfg)
+
+
+def test_federated_round_loop_single_process_and_ranks_agree():
+    """fairfedmed_amd.federated: the FedOTPLoRA round loop (federated_main.py:604-726) on the HIP trainer; the
+    one-process driver and the torch.distributed driver (world 1 here, flat all-reduce) reach the same weights."""
+    import torch.distributed as dist
+    from fairfedmed_amd import federated as F
+    args = F.FedArgs(num_users=2, frac=1.0, round=2, shared_half_s=True, seed=0)
+    tr = _fed_setup()
+    init = {k: v.clone() for k, v in tr.model.state_dict().items() if k in set(tr.engine.params.keys)}
+    hist = F.run_fedotplora(tr, args, log=lambda *_: None)
+    assert len(hist["acc"]) == 2 and len(hist["auc"]) == 2 and all(np.isfinite(hist["acc"]))
+    moved = sum(float((hist["global_weights"][k].cpu() - init[k].cpu()).abs().sum()) for k in init)
+    assert moved > 0, "training did not change the global weights"
+    # the same two rounds through the distributed driver
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tr2 = _fed_setup()
+        hist2 = F.run_fedotplora_ranks(tr2, args, log=lambda *_: None)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    params = tr2.engine.params
+    for k, v in hist["global_weights"].items():
+        off, shp = params.offsets[k]
+        got = hist2["global_flat"][off:off + v.numel()].view(shp).cpu()
+        assert rel(got, v.cpu()) < 1e-5, k
+    assert abs(hist["acc"][-1] - hist2["acc"][-1]) < 1e-6
