@@ -112,3 +112,72 @@ def test_single_process_matches_oracle_without_attr_counts():
     agg.aggregate(0, [0], [10], None, 2, 4)
     ref = O.average_weights_ema(w_g, {0: loc}, [0], [10], None, 2, 4, shared_half_s=True)
     assert torch.allclose(flat, _flatten(ref, offsets, numel), rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# fairfedmed_amd.federated.run_fedotplora_ranks over gloo, world 2: three clients dealt to two ranks, "training" is a
+# deterministic edit of the flat buffer.  The result must equal the one-process driver (list-of-clients average).
+# ----------------------------------------------------------------------------------------------------------------
+class _FlatTrainer:
+    """Stand-in for the HIP trainer: engine.params.{flat, offsets}, train(idx) edits the flat buffer."""
+
+    def __init__(self, users):
+        from types import SimpleNamespace as NS
+        mcfg = C.vit_tiny(rank=4)
+        offsets, numel = _layout(mcfg)
+        flat = _flatten(_client_state(mcfg, 99, 0), offsets, numel)
+        self.engine = NS(params=NS(flat=flat, offsets=offsets, keys=list(offsets)), cfg=mcfg)
+        self.cfg = NS(DATASET=NS(USERS=users, ATTRIBUTE_TYPE="race"))
+        self.fed_train_loader_x_dict = {
+            i: NS(dataset=type("D", (), {"__len__": lambda s, n=40 * (i + 1): n,
+                                         "count_by_attribute": lambda s, a, i=i: [10 + i, 20, 5 * (i + 1)]})())
+            for i in range(users)}
+        outer = self
+
+        class _Model:
+            def state_dict(self):
+                p = outer.engine.params
+                return {k: p.flat[o:o + int(torch.tensor(s).prod())].view(s) for k, (o, s) in p.offsets.items()}
+
+            def load_state_dict(self, sd, strict=True):
+                p = outer.engine.params
+                for k, v in sd.items():
+                    o, s = p.offsets[k]
+                    p.flat[o:o + v.numel()] = v.reshape(-1)
+        self.model = _Model()
+
+    def fed_before_train(self): pass
+    def fed_after_train(self): pass
+
+    def train(self, idx, global_epoch, is_fed, is_last_client):
+        f = self.engine.params.flat
+        f.mul_(1.0 + 0.01 * (idx + 1)).add_(0.001 * (global_epoch + 1) * (idx + 1))
+
+    def test(self, idx, current_epoch):
+        return [float(self.engine.params.flat.mean()), 0.0, 0.0, 0.5]
+
+
+def _fed_worker(rank, world, port, outdir):
+    from fairfedmed_amd import federated as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = F.FedArgs(num_users=3, frac=0.7, round=3, shared_half_s=True, seed=5)
+    hist = F.run_fedotplora_ranks(_FlatTrainer(3), args, log=lambda *_: None)
+    torch.save({"flat": hist["global_flat"], "acc": hist["acc"]}, os.path.join(outdir, f"fed{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_round_loop_over_two_ranks_equals_the_single_process_driver():
+    from fairfedmed_amd import federated as F
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_fed_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, f"fed{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])
+    tr = _FlatTrainer(3)
+    hist = F.run_fedotplora(tr, F.FedArgs(num_users=3, frac=0.7, round=3, shared_half_s=True, seed=5), log=lambda *_: None)
+    p = tr.engine.params
+    for k, v in hist["global_weights"].items():
+        o, s = p.offsets[k]
+        ref = v.reshape(-1)
+        assert torch.allclose(got[0]["flat"][o:o + ref.numel()], ref, rtol=1e-5, atol=1e-7), k
+    assert all(abs(a - b) < 1e-6 for a, b in zip(got[0]["acc"], hist["acc"]))
