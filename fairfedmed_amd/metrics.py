@@ -1,8 +1,17 @@
 """Host-side metrics the trainer reports: AUC as the reference's ``compute_auc``
 (evaluation/metrics.py:340-356 -> sklearn roc_auc_score on one-hot labels,
-macro average over the one-vs-rest columns) and macro-F1
-(evaluation/evaluator_oph.py).  Everything else in evaluation/ (ES-AUC, DPD,
-EOD ...) is out of scope for this round."""
+macro average over the one-vs-rest columns), macro-F1
+(evaluation/evaluator_oph.py) and the fairness scores of ``evalute_comprehensive_perf_scores``
+(evaluation/metrics.py:197-311): per-group AUC, equity-scaled AUC, between-group disparity, and the
+demographic-parity / equalized-odds differences.
+
+The last two come from a third-party package that is absent from the build image, ``fairlearn`` (the reference
+pins no version; the definitions below are those of fairlearn 0.7-0.10, ``fairlearn.metrics``:
+``demographic_parity_difference`` = max - min over groups of the selection rate P(y_hat = 1 | g);
+``equalized_odds_difference`` = the larger of the max - min gaps of the true-positive and false-positive rates).
+They are restated from the published definition and are NOT pinned against the reference (parity unpinned);
+AUC, per-group AUC, ES-AUC and the disparity ratios are pinned against the imported reference functions
+(tests/golden/make_golden.py, ``fair.*``)."""
 from __future__ import annotations
 
 import numpy as np
@@ -54,3 +63,66 @@ def macro_f1(pred: np.ndarray, label: np.ndarray, num_classes: int) -> float:
         d = 2 * tp + fp + fn
         f.append(0.0 if d == 0 else 2 * tp / d)
     return float(np.mean(f))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Fairness scores (evaluation/metrics.py:197-311, 513-552).  prob [N, n_cls], label [N], attr [N] (-1 = unknown).
+# ------------------------------------------------------------------------------------------------------------
+def group_aucs(prob: np.ndarray, label: np.ndarray, attr: np.ndarray) -> np.ndarray:
+    """AUC of every group present in attr (ascending group id, -1 skipped), evaluation/metrics.py:232-244."""
+    prob, label, attr = np.asarray(prob), np.asarray(label), np.asarray(attr)
+    return np.array([auc_macro_ovr(prob[attr == g], label[attr == g]) for g in np.unique(attr).astype(int) if g != -1])
+
+
+def equity_scaled_auc(prob: np.ndarray, label: np.ndarray, attr: np.ndarray, alpha: float = 1.0) -> float:
+    """ES-AUC = AUC / (1 + alpha * sum_g |AUC_g - AUC|), evaluation/metrics.py:513-547."""
+    overall = auc_macro_ovr(prob, label)
+    gaps = np.abs(group_aucs(prob, label, attr) - overall).sum()
+    return float(overall / (alpha * gaps + 1.0))
+
+
+def between_group_disparity(aucs: np.ndarray, overall: float):
+    """(std, max - min) of the group AUCs relative to the overall AUC, evaluation/metrics.py:549-550."""
+    aucs = np.asarray(aucs, dtype=np.float64)
+    return float(np.std(aucs) / overall), float((aucs.max() - aucs.min()) / overall)
+
+
+def _rates(pred: np.ndarray, label: np.ndarray, mask: np.ndarray):
+    p, y = pred[mask], label[mask]
+    sel = float(p.mean()) if len(p) else 0.0
+    tpr = float(p[y == 1].mean()) if np.any(y == 1) else 0.0
+    fpr = float(p[y == 0].mean()) if np.any(y == 0) else 0.0
+    return sel, tpr, fpr
+
+
+def demographic_parity_difference(label: np.ndarray, pred: np.ndarray, attr: np.ndarray) -> float:
+    """fairlearn.metrics.demographic_parity_difference: max - min over groups of P(pred = 1 | group)."""
+    pred, label, attr = np.asarray(pred).astype(np.float64), np.asarray(label), np.asarray(attr)
+    sel = [_rates(pred, label, attr == g)[0] for g in np.unique(attr)]
+    return float(max(sel) - min(sel))
+
+
+def equalized_odds_difference(label: np.ndarray, pred: np.ndarray, attr: np.ndarray) -> float:
+    """fairlearn.metrics.equalized_odds_difference: max(TPR gap, FPR gap), gap = max - min over groups."""
+    pred, label, attr = np.asarray(pred).astype(np.float64), np.asarray(label), np.asarray(attr)
+    r = [_rates(pred, label, attr == g) for g in np.unique(attr)]
+    tpr, fpr = [x[1] for x in r], [x[2] for x in r]
+    return float(max(max(tpr) - min(tpr), max(fpr) - min(fpr)))
+
+
+def comprehensive_scores(prob: np.ndarray, label: np.ndarray, attrs: np.ndarray) -> dict:
+    """The dictionary Classification_oph.evaluate adds for binary tasks (evaluation/evaluator_oph.py:69-113):
+    attrs is [n_attr, N]."""
+    prob, label, attrs = np.asarray(prob), np.asarray(label), np.atleast_2d(np.asarray(attrs))
+    overall = auc_macro_ovr(prob, label)
+    pred = prob.argmax(-1)
+    out = {"overall_auc": overall, "esaucs_by_attrs": [], "aucs_by_attrs": [], "dpds": [], "eods": [],
+           "between_group_disparity": []}
+    for a in attrs:
+        ga = group_aucs(prob, label, a)
+        out["aucs_by_attrs"].append(ga)
+        out["esaucs_by_attrs"].append(equity_scaled_auc(prob, label, a))
+        out["between_group_disparity"].append(between_group_disparity(ga, overall))
+        out["dpds"].append(demographic_parity_difference(label, pred, a))
+        out["eods"].append(equalized_odds_difference(label, pred, a))
+    return out

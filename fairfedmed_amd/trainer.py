@@ -23,7 +23,7 @@ import torch
 
 from . import config as C
 from . import synth
-from .metrics import auc_macro_ovr, macro_f1
+from .metrics import comprehensive_scores, auc_macro_ovr, macro_f1
 from .model import CustomCLIP
 from .registry import TRAINER_REGISTRY
 
@@ -289,14 +289,19 @@ class GLP_OT_SVLoRA:
         """[acc, err, macro_f1, auc] over the client's test loader (SimpleTrainer.test,
         Dassl/dassl/engine/trainer.py:523-569; federated_main.py:685-690 indexes [0..3])."""
         self.set_model_mode("eval")
-        probs, labels = [], []
+        probs, labels, attrs_all = [], [], []
         for batch in self.fed_test_loader_x_dict[idx]:
-            image, label, _, attr = self.parse_batch_test(batch)
+            image, label, attrs, attr = self.parse_batch_test(batch)
             logits = self.model_inference(image, attr)
             probs.append(torch.softmax(logits, -1))
             labels.append(label)
+            attrs_all.append(attrs)
         prob = torch.cat(probs).cpu().numpy()
         y = torch.cat(labels).cpu().numpy()
         pred = prob.argmax(-1)
         acc = 100.0 * float((pred == y).mean())
+        # the fairness block of Classification_oph.evaluate (evaluation/evaluator_oph.py:69-113), binary tasks
+        self.last_results = {"accuracy": acc, "error_rate": 100.0 - acc}
+        if prob.shape[1] == 2 and y.min() != y.max():
+            self.last_results.update(comprehensive_scores(prob, y, torch.cat(attrs_all, dim=1).cpu().numpy()))
         return [acc, 100.0 - acc, 100.0 * macro_f1(pred, y, prob.shape[1]), auc_macro_ovr(prob, y)]

@@ -327,6 +327,27 @@ def golden_auc(compute_auc, out, meta):
     meta["auc"] = cases
 
 
+def golden_fairness(out, meta):
+    """ES-AUC, per-group AUC and between-group disparity from the reference's own functions
+    (evaluation/metrics.py:513-552; the fairlearn-based DPD / EOD cannot be generated: fairlearn is absent)."""
+    import evaluation.metrics as EM
+    g = synth._rng("fair", 11)
+    res = {}
+    for name, n, G in (("n300g3", 300, 3), ("n120g2", 120, 2)):
+        y = g.integers(0, 2, size=(n,))
+        attr = g.integers(0, G, size=(n,))
+        logit = g.standard_normal((n, 2)).astype(np.float32) \
+            + (y[:, None] * np.array([[-0.6, 0.6]], np.float32)) * (1.0 - 0.25 * attr[:, None]).astype(np.float32)
+        prob = torch.softmax(torch.from_numpy(logit), -1).numpy()
+        overall = float(EM.compute_auc(prob, y))
+        aucs = [float(EM.compute_auc(prob[attr == e], y[attr == e])) for e in np.unique(attr)]
+        res[name] = {"overall": overall, "group_aucs": aucs,
+                     "es_auc": float(EM.equity_scaled_AUC(prob, y, attr, num_classes=2)),
+                     "disparity": [float(v) for v in EM.compute_between_group_disparity(aucs, overall)]}
+        out[f"fair.{name}.prob"], out[f"fair.{name}.y"], out[f"fair.{name}.attr"] = prob, y.astype(np.int64), attr.astype(np.int64)
+    meta["fair"] = res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
@@ -342,6 +363,7 @@ def main():
     golden_s_init(M, out)
     golden_fedavg(FU, out, meta)
     golden_auc(compute_auc, out, meta)
+    golden_fairness(out, meta)
     np.savez_compressed(os.path.join(HERE, "unit.npz"), **out)
 
     out = {}

@@ -88,3 +88,29 @@ def test_engine_fails_loudly_without_gpu():
     from fairfedmed_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.layernorm_fwd(torch.zeros(4, 128), torch.zeros(4, 128), torch.ones(128), torch.zeros(128))
+
+
+def test_fairness_scores_vs_reference(golden_dir):
+    """Per-group AUC, ES-AUC and between-group disparity against the imported reference functions
+    (evaluation/metrics.py:513-552); DPD / EOD against hand-computed rates (fairlearn's published definition)."""
+    import json
+    import numpy as np
+    from fairfedmed_amd import metrics as Mx
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["fair"]
+    for name, ref in meta.items():
+        prob, y, attr = unit[f"fair.{name}.prob"], unit[f"fair.{name}.y"], unit[f"fair.{name}.attr"]
+        assert abs(Mx.auc_macro_ovr(prob, y) - ref["overall"]) < 1e-12
+        ga = Mx.group_aucs(prob, y, attr)
+        assert np.allclose(ga, ref["group_aucs"], atol=1e-12)
+        assert abs(Mx.equity_scaled_auc(prob, y, attr) - ref["es_auc"]) < 1e-12
+        assert np.allclose(Mx.between_group_disparity(ga, ref["overall"]), ref["disparity"], atol=1e-12)
+        sc = Mx.comprehensive_scores(prob, y, attr[None])
+        assert abs(sc["esaucs_by_attrs"][0] - ref["es_auc"]) < 1e-12 and 0.0 <= sc["dpds"][0] <= 1.0
+    # DPD / EOD on a case small enough to do by hand: group 0 -> preds 1,1,0,0 labels 1,0,1,0; group 1 -> preds 1,0,0,0 labels 1,1,0,0
+    pred = np.array([1, 1, 0, 0, 1, 0, 0, 0])
+    lab = np.array([1, 0, 1, 0, 1, 1, 0, 0])
+    att = np.array([0, 0, 0, 0, 1, 1, 1, 1])
+    assert abs(Mx.demographic_parity_difference(lab, pred, att) - (0.5 - 0.25)) < 1e-12
+    # TPR: g0 1/2, g1 1/2 -> gap 0; FPR: g0 1/2, g1 0 -> gap 0.5
+    assert abs(Mx.equalized_odds_difference(lab, pred, att) - 0.5) < 1e-12
