@@ -50,6 +50,9 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
         if (!rk && FFM_PANEL_CFGS[c].nf >= 4 && K < 1536) continue;
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
+        // more than one round of one-block-per-CU tiles loses to the 128x128 kernel, whose two blocks per CU overlap
+        // one tile's epilogue with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
+        if (blocks > 256) continue;
         const long cost = ((blocks + 255) / 256) * (bm + bn);
         if (cost < best) { best = cost; pick = c; }
     }
