@@ -9,7 +9,7 @@ settings (configs/trainers/GLP_OT/vit_b16_oph.yaml:15-22).
 from __future__ import annotations
 
 from dataclasses import dataclass, field, asdict
-from typing import Tuple
+from typing import Tuple, Union
 
 # CLIP normalisation constants used by every FairLoRA yaml
 # (configs/trainers/GLP_OT/vit_b16_oph.yaml:9-13).
@@ -37,6 +37,32 @@ class VisionCfg:
     @property
     def head_dim(self) -> int:
         return self.width // self.heads
+
+
+@dataclass(frozen=True)
+class ResNetCfg:
+    """CLIP's ModifiedResNet (clip/model.py:227-301): 3-conv stem, Bottleneck stages with anti-aliasing average
+    pools, attention pool returning all (H/32)^2 + 1 tokens.  heads and embed_dim follow CLIP.__init__ (:474-486)."""
+    image_size: int = 224
+    width: int = 64
+    layers: Tuple[int, int, int, int] = (3, 4, 6, 3)
+    out_dim: int = 1024
+
+    @property
+    def embed_dim(self) -> int:
+        return self.width * 32
+
+    @property
+    def heads(self) -> int:
+        return self.width * 32 // 64
+
+    @property
+    def spacial(self) -> int:
+        return self.image_size // 32
+
+    @property
+    def tokens(self) -> int:
+        return self.spacial * self.spacial + 1
 
 
 @dataclass(frozen=True)
@@ -70,7 +96,7 @@ class OptimCfg:
 
 @dataclass(frozen=True)
 class ModelCfg:
-    vision: VisionCfg = field(default_factory=VisionCfg)
+    vision: Union[VisionCfg, ResNetCfg] = field(default_factory=VisionCfg)
     text: TextCfg = field(default_factory=TextCfg)
     lora: LoraCfg = field(default_factory=LoraCfg)
     n_prompts: int = 2         # TRAINER.GLP_OT.N
@@ -113,3 +139,17 @@ def vit_tiny_3d(rank: int = 4, dim_per_3d_slice: int = 4, num_groups: int = 3) -
     `dim_per_3d_slice` B-scans goes through the trainable 5x5 conv (trainers/GLP_OT_SVLoRA.py:634-639)."""
     import dataclasses
     return dataclasses.replace(vit_tiny(rank=rank, num_groups=num_groups), dim_per_3d_slice=dim_per_3d_slice)
+
+
+def rn50(rank: int = 8, alpha: float = 8.0, num_groups: int = 2) -> ModelCfg:
+    """CLIP RN50 FairLoRA (BASELINE.json configs[4]): FairLoRA on the 1x1 convolutions conv1/conv3 of every
+    Bottleneck, plain LoRA on the attention pool, train-mode BatchNorm (trainers/GLP_OT_SVLoRA.py:541-573, 822-829)."""
+    return ModelCfg(vision=ResNetCfg(), lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups))
+
+
+def rn_tiny(rank: int = 4, alpha: float = 2.0, num_groups: int = 2) -> ModelCfg:
+    """RN50's channel widths (the GEMM wants K % 64 == 0) with one Bottleneck per stage on 64x64 images:
+    4 + 1 attention-pool tokens, 256-d joint space, the tiny text tower."""
+    return ModelCfg(vision=ResNetCfg(image_size=64, width=64, layers=(1, 1, 1, 1), out_dim=256),
+                    text=TextCfg(context_length=77, width=128, heads=2, layers=2),
+                    lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups), eot=(9, 8))

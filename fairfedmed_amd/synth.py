@@ -19,7 +19,7 @@ from typing import Dict, Tuple
 import numpy as np
 import torch
 
-from .config import ModelCfg
+from .config import ModelCfg, ResNetCfg
 
 
 def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
@@ -35,6 +35,10 @@ def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
     m["prompt_learner.token_prefix"] = (nrow, 1, t.width)
     m["prompt_learner.token_suffix"] = (nrow, t.context_length - 1 - cfg.n_ctx, t.width)
     ie = "image_encoder."
+    if isinstance(v, ResNetCfg):
+        _manifest_resnet(m, cfg)
+        _manifest_text(m, cfg)
+        return m
     m[ie + "class_embedding"] = (v.width,)
     m[ie + "positional_embedding"] = (v.tokens, v.width)
     m[ie + "proj"] = (v.width, v.out_dim)
@@ -60,6 +64,67 @@ def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
         m[p + "ln_2.bias"] = (v.width,)
     m[ie + "ln_post.weight"] = (v.width,)
     m[ie + "ln_post.bias"] = (v.width,)
+    _manifest_text(m, cfg)
+    return m
+
+
+def _bn(m, p: str, c: int) -> None:
+    m[p + "weight"] = (c,)
+    m[p + "bias"] = (c,)
+    m[p + "running_mean"] = (c,)
+    m[p + "running_var"] = (c,)
+    m[p + "num_batches_tracked"] = ()
+
+
+def _manifest_resnet(m, cfg: ModelCfg) -> None:
+    """ModifiedResNet_GLP_OT after apply_lora_to_model (clip/model.py:227-301, trainers/GLP_OT_SVLoRA.py:541-573):
+    FairLoRALinear on Bottleneck.conv1 / conv3 (1x1), LoRALinear on the four attention-pool projections."""
+    v, lo = cfg.vision, cfg.lora
+    ie, w = "image_encoder.", v.width
+    m[ie + "conv1.weight"] = (w // 2, 3, 3, 3)
+    _bn(m, ie + "bn1.", w // 2)
+    m[ie + "conv2.weight"] = (w // 2, w // 2, 3, 3)
+    _bn(m, ie + "bn2.", w // 2)
+    m[ie + "conv3.weight"] = (w, w // 2, 3, 3)
+    _bn(m, ie + "bn3.", w)
+    inpl = w
+    for li, nblk in enumerate(v.layers):
+        planes = w * (2 ** li)
+        for j in range(nblk):
+            stride = 2 if (li > 0 and j == 0) else 1
+            p = f"{ie}layer{li + 1}.{j}."
+            for name, cin, cout in (("conv1", inpl, planes),):
+                q = p + name + "."
+                m[q + "original_linear.weight"] = (cout, cin, 1, 1)
+                m[q + "lora_A.weight"] = (cin, lo.rank)
+                m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+                m[q + "lora_B.weight"] = (lo.rank, cout)
+            _bn(m, p + "bn1.", planes)
+            m[p + "conv2.weight"] = (planes, planes, 3, 3)
+            _bn(m, p + "bn2.", planes)
+            q = p + "conv3."
+            m[q + "original_linear.weight"] = (planes * 4, planes, 1, 1)
+            m[q + "lora_A.weight"] = (planes, lo.rank)
+            m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+            m[q + "lora_B.weight"] = (lo.rank, planes * 4)
+            _bn(m, p + "bn3.", planes * 4)
+            if stride > 1 or inpl != planes * 4:
+                m[p + "downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+                _bn(m, p + "downsample.1.", planes * 4)
+            inpl = planes * 4
+    e = v.embed_dim
+    ap = ie + "attnpool."
+    m[ap + "positional_embedding"] = (v.tokens, e)
+    for name, fout in (("k_proj", e), ("q_proj", e), ("v_proj", e), ("c_proj", v.out_dim)):
+        q = ap + name + "."
+        m[q + "original_linear.weight"] = (fout, e)
+        m[q + "original_linear.bias"] = (fout,)
+        m[q + "lora_A.weight"] = (e, lo.rank)
+        m[q + "lora_B.weight"] = (lo.rank, fout)
+
+
+def _manifest_text(m, cfg: ModelCfg) -> None:
+    v, t = cfg.vision, cfg.text
     te = "text_encoder."
     m[te + "positional_embedding"] = (t.context_length, t.width)
     m[te + "text_projection"] = (t.width, v.out_dim)
@@ -79,7 +144,6 @@ def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
         m[p + "ln_2.bias"] = (t.width,)
     m[te + "ln_final.weight"] = (t.width,)
     m[te + "ln_final.bias"] = (t.width,)
-    return m
 
 
 def trainable_keys(cfg: ModelCfg):
@@ -90,7 +154,20 @@ def trainable_keys(cfg: ModelCfg):
     for k in manifest(cfg):
         if k == "prompt_learner.ctx" or k.startswith("proj_per_3d_slice.") or ".lora_" in k:
             out.append(k)
+        elif _is_bn_param(k):                       # BatchNorm2d weight / bias stay trainable (:825-827)
+            out.append(k)
     return out
+
+
+def _is_bn_param(k: str) -> bool:
+    parts = k.split(".")
+    return len(parts) >= 2 and (parts[-2].startswith("bn") or (len(parts) >= 3 and parts[-3] == "downsample" and parts[-2] == "1")) \
+        and parts[-1] in ("weight", "bias") and k.startswith("image_encoder.")
+
+
+def buffer_keys(cfg: ModelCfg):
+    """Non-parameter state that training changes: BatchNorm running statistics and counters (RN50 only)."""
+    return [k for k in manifest(cfg) if k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 
 
 def _rng(key: str, seed: int) -> np.random.Generator:
@@ -113,6 +190,20 @@ def _std_for(key: str, cfg: ModelCfg) -> Tuple[str, float, float]:
     """(kind, mean, std) per key; scales follow CLIP.initialize_parameters
     (clip/model.py:533-560) so activations stay O(1) through 12 layers."""
     v, t = cfg.vision, cfg.text
+    if isinstance(v, ResNetCfg) and key.startswith("image_encoder."):
+        if key.endswith("running_mean"):
+            return "const", 0.0, 0.0
+        if key.endswith("running_var"):
+            return "const", 1.0, 0.0
+        if key.endswith("num_batches_tracked"):
+            return "const", 0.0, 0.0
+        if _is_bn_param(key):
+            return ("normal", 1.0, 0.1) if key.endswith("weight") else ("normal", 0.0, 0.1)
+        if key.endswith("positional_embedding"):
+            return "normal", 0.0, v.embed_dim ** -0.5
+        if "attnpool" in key:
+            return ("normal", 0.0, v.embed_dim ** -0.5) if key.endswith("weight") else ("normal", 0.0, 0.02)
+        return "normal", 0.0, 0.0          # convolutions: He-style std from the fan-in, set by the caller
     width = v.width if key.startswith("image_encoder.") else t.width
     layers = v.layers if key.startswith("image_encoder.") else t.layers
     if key == "logit_scale":
@@ -170,10 +261,15 @@ def make_state_dict(cfg: ModelCfg, seed: int = 1, lora_init: str = "reference") 
                 x = x + g.standard_normal(shape, dtype=np.float32) * 0.05
         else:
             kind, mean, std = _std_for(key, cfg)
+            if kind == "normal" and std == 0.0 and len(shape) == 4:       # convolution: He-style std from the fan-in
+                std = (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
             if kind == "const":
                 x = np.full(shape, mean, np.float32)
             else:
                 x = mean + g.standard_normal(shape, dtype=np.float32) * np.float32(std)
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.zeros((), dtype=torch.int64)
+            continue
         sd[key] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(shape)
     return sd
 

@@ -161,10 +161,81 @@ def vision_block(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int, attr: Opt
     return x + h
 
 
-def vision_forward(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg) -> Tensor:
+# --------------------------------------------------------------------------
+# RN50 trunk (clip/model.py:11-118, 227-301) with the FairLoRA / LoRA wrappers of
+# trainers/GLP_OT_SVLoRA.py:541-573; BatchNorm in train mode updates its running
+# statistics IN PLACE in `sd`, as nn.BatchNorm2d does during the reference's forward.
+# --------------------------------------------------------------------------
+def batch_norm(sd: Dict[str, Tensor], p: str, x: Tensor, training: bool) -> Tensor:
+    if training:
+        sd[p + "num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"],
+                        training, 0.1, 1e-5)
+
+
+def bottleneck(sd: Dict[str, Tensor], p: str, x: Tensor, attr: Optional[Tensor], stride: int, scaling: float,
+               training: bool) -> Tensor:
+    """Bottleneck.forward (clip/model.py:41-60): all convolutions have stride 1, an average pool follows conv2 when
+    stride > 1, and the downsample path is avgpool -> 1x1 conv -> BN."""
+    def lora_conv(name, inp):
+        q = p + name + "."
+        return fairlora_linear(inp, sd[q + "original_linear.weight"], None, sd[q + "lora_A.weight"],
+                               sd[q + "lora_S.weight"], sd[q + "lora_B.weight"], attr, scaling)
+
+    out = F.relu(batch_norm(sd, p + "bn1.", lora_conv("conv1", x), training))
+    out = F.relu(batch_norm(sd, p + "bn2.", F.conv2d(out, sd[p + "conv2.weight"], None, padding=1), training))
+    if stride > 1:
+        out = F.avg_pool2d(out, stride)
+    out = batch_norm(sd, p + "bn3.", lora_conv("conv3", out), training)
+    identity = x
+    if p + "downsample.0.weight" in sd:
+        identity = F.avg_pool2d(x, stride) if stride > 1 else x
+        identity = batch_norm(sd, p + "downsample.1.", F.conv2d(identity, sd[p + "downsample.0.weight"]), training)
+    return F.relu(out + identity)
+
+
+def attention_pool(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int, scaling: float) -> Tensor:
+    """AttentionPool2d.forward (clip/model.py:75-118) with the dense LoRA weights W + scaling (A B)^T of
+    LoRALinear.weight (trainers/GLP_OT_SVLoRA.py:235-236): returns all HW + 1 tokens, [HW+1, B, out]."""
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(2, 0, 1)                  # NCHW -> (HW) N C
+    x = torch.cat([x.mean(dim=0, keepdim=True), x], dim=0)
+    x = x + sd[p + "positional_embedding"][:, None, :]
+
+    def dense(name):
+        q = p + name + "."
+        return (sd[q + "original_linear.weight"] + scaling * (sd[q + "lora_A.weight"] @ sd[q + "lora_B.weight"]).t(),
+                sd[q + "original_linear.bias"])
+
+    (wq, bq), (wk, bk), (wv, bv), (wc, bc) = dense("q_proj"), dense("k_proj"), dense("v_proj"), dense("c_proj")
+    L, N, E = x.shape
+    hd = E // heads
+    q = F.linear(x, wq, bq).reshape(L, N * heads, hd).transpose(0, 1) * (hd ** -0.5)
+    k = F.linear(x, wk, bk).reshape(L, N * heads, hd).transpose(0, 1)
+    v = F.linear(x, wv, bv).reshape(L, N * heads, hd).transpose(0, 1)
+    o = (torch.softmax(q @ k.transpose(1, 2), dim=-1) @ v).transpose(0, 1).reshape(L, N, E)
+    return F.linear(o, wc, bc)
+
+
+def resnet_forward(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg, training: bool = True) -> Tensor:
+    """ModifiedResNet_GLP_OT.forward (clip/model.py:270-301): [B,3,H,W] -> [HW/1024 + 1, B, out_dim]."""
+    v, ie, sc = cfg.vision, "image_encoder.", cfg.lora.scaling
+    x = image
+    for i, stride in ((1, 2), (2, 1), (3, 1)):
+        x = F.relu(batch_norm(sd, f"{ie}bn{i}.", F.conv2d(x, sd[f"{ie}conv{i}.weight"], None, stride=stride, padding=1),
+                              training))
+    x = F.avg_pool2d(x, 2)
+    for li, nblk in enumerate(v.layers):
+        for j in range(nblk):
+            x = bottleneck(sd, f"{ie}layer{li + 1}.{j}.", x, attr, 2 if (li > 0 and j == 0) else 1, sc, training)
+    return attention_pool(sd, ie + "attnpool.", x, v.heads, sc)
+
+
+def vision_forward(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg, training: bool = True) -> Tensor:
     """ModifiedVisionTransformer.forward (clip/model.py:430-449): returns ALL
-    tokens projected to out_dim, [L, B, out]."""
+    tokens projected to out_dim, [L, B, out].  (RN50 configs dispatch to resnet_forward.)"""
     v = cfg.vision
+    if hasattr(v, "embed_dim"):
+        return resnet_forward(sd, image, attr, cfg, training)
     ie = "image_encoder."
     x = F.conv2d(image, sd[ie + "conv1.weight"], None, stride=v.patch)
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
@@ -228,11 +299,12 @@ def preprocess(sd: Dict[str, Tensor], image: Tensor, cfg) -> Tensor:
     return (x - mean) / std
 
 
-def clip_logits(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg) -> Tensor:
-    """CustomCLIP.forward with OT='None' (trainers/GLP_OT_SVLoRA.py:677-763)."""
+def clip_logits(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg, training: bool = True) -> Tensor:
+    """CustomCLIP.forward with OT='None' (trainers/GLP_OT_SVLoRA.py:677-763).  `training` only matters for the
+    BatchNorm layers of the RN50 trunk."""
     b = image.shape[0]
     x = preprocess(sd, image, cfg)
-    feats = vision_forward(sd, x, attr, cfg)                        # [L, B*S, d]
+    feats = vision_forward(sd, x, attr, cfg, training)              # [L, B*S, d]
     feats = feats[1:]                                               # drop the class token (:696-697)
     M = feats.shape[0]
     text = text_forward(sd, cfg)                                    # [N, n_cls, d]

@@ -107,11 +107,14 @@ def ref_cfg(mcfg: C.ModelCfg, lambda_fairness=0.0):
 def build_reference_model(M, CLIP, mcfg: C.ModelCfg, sd):
     v, t = mcfg.vision, mcfg.text
     dd = {"trainer": "GLP_OT", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0}
-    clip_model = CLIP(v.out_dim, v.image_size, v.layers, v.width, v.patch, t.context_length, 49408,
-                      t.width, t.heads, t.layers, dd).float()
+    is_rn = isinstance(v, C.ResNetCfg)
+    clip_model = CLIP(v.out_dim, v.image_size, tuple(v.layers) if is_rn else v.layers, v.width,
+                      None if is_rn else v.patch, t.context_length, 49408, t.width, t.heads, t.layers, dd).float()
     model = M.CustomCLIP(ref_cfg(mcfg), ["NOT Glaucoma", "Glaucoma"], clip_model)
+    bn_params = {id(p) for mod in model.modules() if isinstance(mod, torch.nn.BatchNorm2d) for p in mod.parameters()}
     for n, p in model.named_parameters():
-        p.requires_grad_("prompt_learner" in n or "proj_per_3d_slice" in n)
+        # the freeze loop of GLP_OT_SVLoRA.build_model (:822-829): prompts, the 3D conv and BatchNorm2d stay trainable
+        p.requires_grad_("prompt_learner" in n or "proj_per_3d_slice" in n or id(p) in bn_params)
     M.apply_lora_to_model(model, True, rank=mcfg.lora.rank, alpha=mcfg.lora.alpha, lora_type="FairLoRA",
                           global_s=False, num_attrs=mcfg.lora.num_groups)
     ref_sd = model.state_dict()
@@ -271,7 +274,7 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
         if p.requires_grad:
             gr = p.grad if p.grad is not None else torch.zeros_like(p)
             gn[n] = float(gr.norm())
-            if p.numel() <= 8192 or tag.startswith("tiny"):
+            if p.numel() <= 8192 or tag.startswith("tiny") or tag.startswith("rn"):
                 out[f"{tag}.grad.{n}"] = gr.numpy().copy()
             else:
                 out[f"{tag}.gradsub.{n}"] = sub(gr, 1024)
@@ -288,8 +291,10 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
         print(tag, "step", i, s)
     meta[f"{tag}.traj"] = traj
     post = model.state_dict()
+    for k in synth.buffer_keys(mcfg):                              # RN50: BatchNorm running statistics after the steps
+        out[f"{tag}.post.{k}"] = post[k].detach().numpy().copy()
     for k in synth.trainable_keys(mcfg):
-        if post[k].numel() <= 8192 or tag.startswith("tiny"):
+        if post[k].numel() <= 8192 or tag.startswith("tiny") or tag.startswith("rn"):
             out[f"{tag}.post.{k}"] = post[k].detach().numpy().copy()
     meta[f"{tag}.post_checksum"] = {k: float(post[k].double().sum()) for k in synth.trainable_keys(mcfg)}
     return model
@@ -375,6 +380,10 @@ def main():
     out = {}   # 3D OCT front end: 6 samples x 2 slice groups of 4 B-scans -> 12 ViT images
     golden_model(M, CLIP, C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), "tiny3d_r4", 6, 3, out, meta)
     np.savez_compressed(os.path.join(HERE, "tiny3d.npz"), **out)
+
+    out = {}   # RN50 trunk (one Bottleneck per stage, RN50's channel widths, 64x64 images), G = 2 as in configs[4]
+    golden_model(M, CLIP, C.rn_tiny(rank=4, num_groups=2), "rn_tiny_r4g2", 6, 3, out, meta)
+    np.savez_compressed(os.path.join(HERE, "rn_tiny.npz"), **out)
 
     if args.vitb:
         out = {}

@@ -127,13 +127,15 @@ TINY = {
     "tiny_r8g2": (C.vit_tiny(rank=8, num_groups=2), 6, "random"),
     "tiny_refinit": (C.vit_tiny(rank=4), 8, "reference"),
     "tiny3d_r4": (C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random"),      # 3D OCT front end (§8 a4)
+    "rn_tiny_r4g2": (C.rn_tiny(rank=4, num_groups=2), 6, "random"),             # RN50 trunk (§8 a12)
 }
 
 
 @pytest.mark.parametrize("tag", list(TINY))
 def test_tiny_model_step_and_trajectory(golden_dir, meta, tag):
     mcfg, bs, init = TINY[tag]
-    gold = np.load(os.path.join(golden_dir, "tiny3d.npz" if mcfg.dim_per_3d_slice else "tiny.npz"))
+    gold = np.load(os.path.join(golden_dir, "rn_tiny.npz" if tag.startswith("rn") else
+                                "tiny3d.npz" if mcfg.dim_per_3d_slice else "tiny.npz"))
     sd = synth.make_state_dict(mcfg, seed=1, lora_init=init)
     batch = synth.make_batch(mcfg, bs, seed=1234)
     keys = synth.trainable_keys(mcfg)
@@ -150,6 +152,8 @@ def test_tiny_model_step_and_trajectory(golden_dir, meta, tag):
         assert abs(s["acc"] - ref["acc"]) < 1e-4
         assert abs(s["auc"] - ref["auc"]) < 1e-9
     for k in keys:
+        close(sd[k].numpy(), gold[f"{tag}.post.{k}"], rtol=1e-5, atol=1e-6, what="post." + k)
+    for k in synth.buffer_keys(mcfg):                               # BatchNorm running statistics after the steps
         close(sd[k].numpy(), gold[f"{tag}.post.{k}"], rtol=1e-5, atol=1e-6, what="post." + k)
 
 
