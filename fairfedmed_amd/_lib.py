@@ -61,6 +61,16 @@ SIGNATURES = {
     "ffm_embed_lnpre_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_slice_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_f32),
                       _i32, _vp],
+    "ffm_stem_im2col": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _vp],
+    "ffm_im2col3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_bn_blocks": [_i32],
+    "ffm_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_avgpool2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
+    "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
+    "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,

@@ -1,0 +1,528 @@
+// RN50 trunk building blocks on NHWC rows (row = (b, y, x), C contiguous): everything of ModifiedResNet that is not a
+// 1x1 convolution (those are ffm_gemm_nt on the rows, with the FairLoRA epilogue).  clip/model.py:11-118, 227-301.
+//   3x3 convolutions (frozen weights): im2col -> ffm_gemm_nt with W as [Cout, (ky,kx,c)] -> (backward) dcols = dY W,
+//                                      col2im by gathering the <= 9 taps of every input pixel (no atomics)
+//   BatchNorm2d, TRAIN mode, trainable: two-stage column sums, finalize in double, normalise (+ReLU); backward likewise
+//   AvgPool2d(2), residual add + ReLU, attention-pool token assembly (mean token + positional embedding)
+// All of it is HBM-bound elementwise / reduction work; 16-byte accesses along C.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct VecC;             // 16-byte chunk of channels <-> floats
+template <> struct VecC<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { Vec8<bf16_t>::load(p, v); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) { Vec8<bf16_t>::store(p, v); }
+};
+template <> struct VecC<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+};
+
+inline int grid1d(size_t n, int cap = 16384) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > (size_t)cap ? cap : (b < 1 ? 1 : b));
+}
+
+// ---- stem conv1: raw NCHW fp32 image -> normalised 3x3 / pad 1 patches, k = (ky*3 + kx)*3 + c, zero padded to Kp
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H,
+                                                          int W, int stride, int Kp, f32x4 mean3, f32x4 std3) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const size_t total = (size_t)B * Ho * Wo * Kp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        size_t r = i / Kp;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float v = 0.f;
+        if (k < 27) {
+            const int c = k % 3, tap = k / 3, ky = tap / 3, kx = tap % 3;
+            const int y = oy * stride + ky - 1, x = ox * stride + kx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W)
+                v = (img[(((size_t)b * 3 + c) * H + y) * W + x] / 255.0f - mean3[c]) / std3[c];
+        }
+        cols[i] = Elem<T>::from_f(v);
+    }
+}
+
+// ---- generic 3x3 / pad 1: x [B*H*W, C] -> cols [B*Ho*Wo, Kp], k = (ky*3 + kx)*C + c
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ cols, int B, int H, int W,
+                                                        int C, int stride, int Kp) {
+    constexpr int VN = VecC<T>::N;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1, kc = Kp / VN;
+    const size_t total = (size_t)B * Ho * Wo * kc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kc) * VN;
+        size_t r = i / kc;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float v[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) v[e] = 0.f;
+        if (k < 9 * C) {
+            const int tap = k / C, c = k % C, ky = tap / 3, kx = tap % 3;
+            const int y = oy * stride + ky - 1, xx = ox * stride + kx - 1;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) VecC<T>::load(x + (((size_t)b * H + y) * W + xx) * C + c, v);
+        }
+        VecC<T>::store(cols + ((((size_t)b * Ho + oy) * Wo + ox)) * Kp + k, v);
+    }
+}
+
+// ---- backward of the above: dx[b,y,x,c] = sum over the taps whose output position exists
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dcols, T* __restrict__ dx, int B, int H, int W,
+                                                        int C, int stride, int Kp) {
+    constexpr int VN = VecC<T>::N;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1, cc = C / VN;
+    const size_t total = (size_t)B * H * W * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * VN;
+        size_t r = i / cc;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        float acc[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = y + 1 - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = x + 1 - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                float v[VN];
+                VecC<T>::load(dcols + (((size_t)b * Ho + oy) * Wo + ox) * Kp + (ky * 3 + kx) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] += v[e];
+            }
+        }
+        VecC<T>::store(dx + i * VN, acc);
+    }
+}
+
+// ---- column sums over the rows: part[blk][0][c] = sum a, part[blk][1][c] = sum a*b   (block = 64 channels x 4 row lanes)
+//  MODE 0: a = x, b = x                                (BatchNorm statistics)
+//  MODE 1: a = g, b = g * xhat, g = dy * (y > 0 if mask) (BatchNorm backward)
+constexpr int CS_ROWS = 512;     // rows per block
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, const T* __restrict__ p1,
+                                                     const T* __restrict__ mask, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ part, int rows,
+                                                     int C) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int r0 = blockIdx.x * CS_ROWS, r1 = (r0 + CS_ROWS) < rows ? (r0 + CS_ROWS) : rows;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t o = (size_t)r * C + c;
+            if (MODE == 0) {
+                const float v = Elem<T>::to_f(p0[o]);
+                s0 += v;
+                s1 += v * v;
+            } else {
+                float g = Elem<T>::to_f(p0[o]);
+                if (mask && !(Elem<T>::to_f(mask[o]) > 0.f)) g = 0.f;
+                s0 += g;
+                s1 += g * (Elem<T>::to_f(p1[o]) - mu) * rs;
+            }
+        }
+    }
+    red[0][rl][cl] = s0;
+    red[1][rl][cl] = s1;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+// mean / rstd of the batch (biased variance, eps 1e-5) + running statistics update (unbiased variance, momentum)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int C,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    const double mu = s / rows;
+    double var = q / rows - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+}
+
+// eval mode: mean / rstd from the running statistics
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = run_mean[c];
+    rstd[c] = 1.0f / sqrtf(run_var[c] + eps);
+}
+
+// y = (x - mean) * rstd * gamma + beta  (+ residual) (ReLU)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const T* __restrict__ res,
+                                                       T* __restrict__ y, size_t rows, int C, int relu) {
+    constexpr int VN = VecC<T>::N;
+    const int cc = C / VN;
+    const size_t total = rows * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * VN;
+        float v[VN], rr[VN];
+        VecC<T>::load(x + i * VN, v);
+        if (res) VecC<T>::load(res + i * VN, rr);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float o = (v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
+            if (res) o += rr[e];
+            v[e] = relu ? fmaxf(o, 0.f) : o;
+        }
+        VecC<T>::store(y + i * VN, v);
+    }
+}
+
+// dgamma = sum g xhat, dbeta = sum g; k1 = sum g / N, k2 = sum g xhat / N for the apply pass
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ k12) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    k12[c] = (float)(s / rows);
+    k12[C + c] = (float)(q / rows);
+}
+
+// dx = gamma * rstd * (g - k1 - xhat * k2), g = dy * (mask > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ mask,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ k12, T* __restrict__ dx, size_t rows,
+                                                           int C) {
+    constexpr int VN = VecC<T>::N;
+    const int cc = C / VN;
+    const size_t total = rows * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * VN;
+        float g[VN], xv[VN], m[VN];
+        VecC<T>::load(dy + i * VN, g);
+        VecC<T>::load(x + i * VN, xv);
+        if (mask) VecC<T>::load(mask + i * VN, m);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float gg = g[e];
+            if (mask && !(m[e] > 0.f)) gg = 0.f;
+            const float xh = (xv[e] - mean[c + e]) * rstd[c + e];
+            g[e] = gamma[c + e] * rstd[c + e] * (gg - k12[c + e] - xh * k12[C + c + e]);
+        }
+        VecC<T>::store(dx + i * VN, g);
+    }
+}
+
+// ---- AvgPool2d(2) on NHWC
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W,
+                                                       int C) {
+    constexpr int VN = VecC<T>::N;
+    const int Ho = H / 2, Wo = W / 2, cc = C / VN;
+    // forward: one thread per pooled element chunk; backward: one thread per input element chunk
+    const size_t total = BWD ? (size_t)B * H * W * cc : (size_t)B * Ho * Wo * cc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cc) * VN;
+        size_t r = i / cc;
+        float v[VN];
+        if (!BWD) {
+            const int ox = (int)(r % Wo); r /= Wo;
+            const int oy = (int)(r % Ho);
+            const int b = (int)(r / Ho);
+            float acc[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    VecC<T>::load(in + (((size_t)b * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c, v);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[e] += v[e];
+                }
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] *= 0.25f;
+            VecC<T>::store(out + i * VN, acc);
+        } else {
+            const int x = (int)(r % W); r /= W;
+            const int y = (int)(r % H);
+            const int b = (int)(r / H);
+            VecC<T>::load(in + (((size_t)b * Ho + y / 2) * Wo + x / 2) * C + c, v);     // in = d(pooled)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] *= 0.25f;
+            VecC<T>::store(out + i * VN, v);
+        }
+    }
+}
+
+// out = a + b  (gradient accumulation of the two branches of a Bottleneck)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                  size_t n) {
+    constexpr int VN = VecC<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / VN; i += (size_t)gridDim.x * blockDim.x) {
+        float x[VN], y[VN];
+        VecC<T>::load(a + i * VN, x);
+        VecC<T>::load(b + i * VN, y);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) x[e] += y[e];
+        VecC<T>::store(out + i * VN, x);
+    }
+}
+
+// out = g * (y > 0): gradient through a ReLU whose output is y
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ out,
+                                                       size_t n) {
+    constexpr int VN = VecC<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / VN; i += (size_t)gridDim.x * blockDim.x) {
+        float a[VN], m[VN];
+        VecC<T>::load(g + i * VN, a);
+        VecC<T>::load(y + i * VN, m);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) a[e] = m[e] > 0.f ? a[e] : 0.f;
+        VecC<T>::store(out + i * VN, a);
+    }
+}
+
+// ---- attention pool tokens: tok[b,0] = mean_hw x[b,hw] + pos[0]; tok[b,1+hw] = x[b,hw] + pos[1+hw]  (clip/model.py:76-78)
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const T* __restrict__ in, const T* __restrict__ pos,
+                                                              T* __restrict__ out, int B, int HW, int E) {
+    constexpr int VN = VecC<T>::N;
+    const int ec = E / VN, L = HW + 1;
+    const size_t total = BWD ? (size_t)B * HW * ec : (size_t)B * L * ec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e0 = (int)(i % ec) * VN;
+        size_t r = i / ec;
+        float v[VN], acc[VN];
+        if (!BWD) {
+            const int l = (int)(r % L), b = (int)(r / L);
+            if (l == 0) {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] = 0.f;
+                for (int hw = 0; hw < HW; ++hw) {
+                    VecC<T>::load(in + ((size_t)b * HW + hw) * E + e0, v);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[e] += v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[e] /= (float)HW;
+            } else {
+                VecC<T>::load(in + ((size_t)b * HW + l - 1) * E + e0, acc);
+            }
+            // the mean token is rounded to the activation dtype before the positional embedding is added, as
+            // torch.cat([x.mean(0), x]) + pos does
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] = Elem<T>::to_f(Elem<T>::from_f(acc[e]));
+            VecC<T>::load(pos + (size_t)l * E + e0, v);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] += v[e];
+            VecC<T>::store(out + i * VN, acc);
+        } else {
+            const int hw = (int)(r % HW), b = (int)(r / HW);        // in = d(tokens) [B*L, E]
+            VecC<T>::load(in + ((size_t)b * L + 1 + hw) * E + e0, acc);
+            VecC<T>::load(in + ((size_t)b * L) * E + e0, v);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[e] += v[e] / (float)HW;
+            VecC<T>::store(out + i * VN, acc);
+        }
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+    if ((dtype) == FFM_BF16) { CALL_BF16; } else if ((dtype) == FFM_F32) { CALL_F32; } else return FFM_EINVAL;
+
+extern "C" int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
+                               const float* std3, int dtype, void* stream) {
+    if (!img || !cols || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || Kp < 27) return FFM_EINVAL;
+    const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int g = grid1d((size_t)B * Ho * Wo * Kp);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((stem_im2col_kernel<bf16_t>), dim3(g), dim3(256), 0, s, img, (bf16_t*)cols, B, H, W, stride, Kp, m, sd),
+               hipLaunchKernelGGL((stem_im2col_kernel<float>), dim3(g), dim3(256), 0, s, img, (float*)cols, B, H, W, stride, Kp, m, sd))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+static bool conv_args_ok(const void* a, const void* b, int B, int H, int W, int C, int stride, int Kp, int dtype) {
+    const int vn = dtype == FFM_BF16 ? 8 : 4;
+    return a && b && B > 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2) && C % vn == 0 && Kp >= 9 * C &&
+           Kp % vn == 0 && !(((uintptr_t)a | (uintptr_t)b) & 15);
+}
+
+extern "C" int ffm_im2col3x3(const void* x, void* cols, int B, int H, int W, int C, int stride, int Kp, int dtype,
+                             void* stream) {
+    if (!conv_args_ok(x, cols, B, H, W, C, stride, Kp, dtype)) return FFM_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int g = grid1d((size_t)B * Ho * Wo * Kp / 4);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((im2col3x3_kernel<bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)cols, B, H, W, C, stride, Kp),
+               hipLaunchKernelGGL((im2col3x3_kernel<float>), dim3(g), dim3(256), 0, s, (const float*)x, (float*)cols, B, H, W, C, stride, Kp))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, int C, int stride, int Kp, int dtype,
+                             void* stream) {
+    if (!conv_args_ok(dcols, dx, B, H, W, C, stride, Kp, dtype)) return FFM_EINVAL;
+    const int g = grid1d((size_t)B * H * W * C / 4);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((col2im3x3_kernel<bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)dcols, (bf16_t*)dx, B, H, W, C, stride, Kp),
+               hipLaunchKernelGGL((col2im3x3_kernel<float>), dim3(g), dim3(256), 0, s, (const float*)dcols, (float*)dx, B, H, W, C, stride, Kp))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_bn_blocks(int rows) { return (rows + CS_ROWS - 1) / CS_ROWS; }
+
+extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                          float* mean, float* rstd, float* part, const void* res, void* y, int rows, int C, int training,
+                          int relu, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !run_mean || !run_var || !mean || !rstd || !y || rows <= 0 || C <= 0) return FFM_EINVAL;
+    if (C % (dtype == FFM_BF16 ? 8 : 4) || (training && !part)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (training) {
+        const int nblk = ffm_bn_blocks(rows);
+        dim3 g(nblk, (C + 63) / 64);
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C),
+                   hipLaunchKernelGGL((colsum_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C))
+        FFM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
+                           run_var, 0.1f, 1e-5f);
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, run_var, mean, rstd, C, 1e-5f);
+    }
+    FFM_CHECK_LAUNCH();
+    const int g2 = grid1d((size_t)rows * C / 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(g2), dim3(256), 0, s, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)y, (size_t)rows, C, relu),
+               hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, (const float*)res, (float*)y, (size_t)rows, C, relu))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
+                          const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows,
+                          int C, int dtype, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !part || !k12 || !dgamma || !dbeta || !dx || rows <= 0 || C <= 0)
+        return FFM_EINVAL;
+    if (C % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = ffm_bn_blocks(rows);
+    dim3 g(nblk, (C + 63) / 64);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C),
+               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C))
+    FFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
+    FFM_CHECK_LAUNCH();
+    const int g2 = grid1d((size_t)rows * C / 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(g2), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)relu_out, (const bf16_t*)x, mean, rstd, gamma, k12, (bf16_t*)dx, (size_t)rows, C),
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)dy, (const float*)relu_out, (const float*)x, mean, rstd, gamma, k12, (float*)dx, (size_t)rows, C))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_avgpool2(const void* in, void* out, int B, int H, int W, int C, int backward, int dtype, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid1d((size_t)B * H * W * C / (backward ? 4 : 16));
+    if (backward) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((avgpool2_kernel<bf16_t, true>), dim3(g), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C),
+                   hipLaunchKernelGGL((avgpool2_kernel<float, true>), dim3(g), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C))
+    } else {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((avgpool2_kernel<bf16_t, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C),
+                   hipLaunchKernelGGL((avgpool2_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)in, (float*)out, B, H, W, C))
+    }
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0 || n % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid1d((size_t)n / 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, (size_t)n),
+               hipLaunchKernelGGL((add_kernel<float>), dim3(g), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, (size_t)n))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_relu_bwd(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream) {
+    if (!g || !y || !out || n <= 0 || n % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int gr = grid1d((size_t)n / 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL((relu_bwd_kernel<bf16_t>), dim3(gr), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)out, (size_t)n),
+               hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(gr), dim3(256), 0, s, (const float*)g, (const float*)y, (float*)out, (size_t)n))
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_attnpool_tokens(const void* in, const void* pos, void* out, int B, int HW, int E, int backward, int dtype,
+                                   void* stream) {
+    if (!in || !out || (!backward && !pos) || B <= 0 || HW <= 0 || E % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid1d((size_t)B * (HW + 1) * E / 4);
+    if (backward) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((attnpool_tokens_kernel<bf16_t, true>), dim3(g), dim3(256), 0, s, (const bf16_t*)in, (const bf16_t*)pos, (bf16_t*)out, B, HW, E),
+                   hipLaunchKernelGGL((attnpool_tokens_kernel<float, true>), dim3(g), dim3(256), 0, s, (const float*)in, (const float*)pos, (float*)out, B, HW, E))
+    } else {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((attnpool_tokens_kernel<bf16_t, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)in, (const bf16_t*)pos, (bf16_t*)out, B, HW, E),
+                   hipLaunchKernelGGL((attnpool_tokens_kernel<float, false>), dim3(g), dim3(256), 0, s, (const float*)in, (const float*)pos, (float*)out, B, HW, E))
+    }
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}

@@ -248,6 +248,86 @@ def slice_bwd(dcols: Tensor, img: Tensor, conv: Tensor, mnmx: Tensor, cnt: Tenso
           L.stream_ptr())
 
 
+# ---------------------------------------------------------------- RN50 trunk (NHWC rows) ----
+def conv_out(h: int, stride: int) -> int:
+    return (h - 1) // stride + 1
+
+
+def stem_im2col(img: Tensor, cols: Tensor, stride: int, mean3, std3) -> None:
+    _dev(img, cols)
+    B, Cc, H, W = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and cols.is_contiguous()
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    _call("ffm_stem_im2col", L.ptr(img), L.ptr(cols), B, H, W, stride, cols.shape[1], m, s, L.dtype_code(cols.dtype),
+          L.stream_ptr())
+
+
+def im2col3x3(x: Tensor, cols: Tensor, B: int, H: int, W: int, stride: int) -> None:
+    _dev(x, cols)
+    assert x.is_contiguous() and cols.is_contiguous() and x.dtype == cols.dtype and x.shape[0] == B * H * W
+    _call("ffm_im2col3x3", L.ptr(x), L.ptr(cols), B, H, W, x.shape[1], stride, cols.shape[1], L.dtype_code(x.dtype),
+          L.stream_ptr())
+
+
+def col2im3x3(dcols: Tensor, dx: Tensor, B: int, H: int, W: int, stride: int) -> None:
+    _dev(dcols, dx)
+    assert dx.is_contiguous() and dcols.is_contiguous() and dx.dtype == dcols.dtype and dx.shape[0] == B * H * W
+    _call("ffm_col2im3x3", L.ptr(dcols), L.ptr(dx), B, H, W, dx.shape[1], stride, dcols.shape[1], L.dtype_code(dx.dtype),
+          L.stream_ptr())
+
+
+def bn_blocks(rows: int) -> int:
+    return L.load().ffm_bn_blocks(rows)
+
+
+def bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, run_mean: Tensor, run_var: Tensor, mean: Tensor, rstd: Tensor,
+           part: Optional[Tensor], y: Tensor, training: bool, relu: bool, res: Optional[Tensor] = None) -> None:
+    _dev(x, gamma, beta, run_mean, run_var, mean, rstd, part, y, res)
+    rows, Cc = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype and (res is None or res.dtype == x.dtype)
+    _call("ffm_bn_fwd", L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(_f32(run_mean)), L.ptr(_f32(run_var)),
+          L.ptr(_f32(mean)), L.ptr(_f32(rstd)), L.ptr(_f32(part)), L.ptr(res), L.ptr(y), rows, Cc, int(training), int(relu),
+          L.dtype_code(x.dtype), L.stream_ptr())
+
+
+def bn_bwd(dy: Tensor, relu_out: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, part: Tensor,
+           k12: Tensor, dgamma: Tensor, dbeta: Tensor, dx: Tensor) -> None:
+    _dev(dy, relu_out, x, gamma, mean, rstd, part, k12, dgamma, dbeta, dx)
+    rows, Cc = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dy.dtype == x.dtype == dx.dtype
+    _call("ffm_bn_bwd", L.ptr(dy), L.ptr(relu_out), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
+          L.ptr(_f32(part)), L.ptr(_f32(k12)), L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), L.ptr(dx), rows, Cc,
+          L.dtype_code(x.dtype), L.stream_ptr())
+
+
+def avgpool2(inp: Tensor, out: Tensor, B: int, H: int, W: int, backward: bool = False) -> None:
+    """forward: inp [B*H*W, C] -> out [B*(H/2)*(W/2), C]; backward: inp = d(pooled), out = d(x) [B*H*W, C]."""
+    _dev(inp, out)
+    assert inp.is_contiguous() and out.is_contiguous() and inp.dtype == out.dtype
+    _call("ffm_avgpool2", L.ptr(inp), L.ptr(out), B, H, W, inp.shape[1], int(backward), L.dtype_code(inp.dtype),
+          L.stream_ptr())
+
+
+def add(a: Tensor, b: Tensor, out: Tensor) -> None:
+    _dev(a, b, out)
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and a.dtype == b.dtype == out.dtype
+    _call("ffm_add", L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.dtype_code(a.dtype), L.stream_ptr())
+
+
+def relu_bwd(g: Tensor, y: Tensor, out: Tensor) -> None:
+    _dev(g, y, out)
+    assert g.is_contiguous() and y.is_contiguous() and out.is_contiguous() and g.dtype == y.dtype == out.dtype
+    _call("ffm_relu_bwd", L.ptr(g), L.ptr(y), L.ptr(out), g.numel(), L.dtype_code(g.dtype), L.stream_ptr())
+
+
+def attnpool_tokens(inp: Tensor, pos: Optional[Tensor], out: Tensor, B: int, HW: int, backward: bool = False) -> None:
+    _dev(inp, pos, out)
+    assert inp.is_contiguous() and out.is_contiguous() and inp.dtype == out.dtype
+    _call("ffm_attnpool_tokens", L.ptr(inp), L.ptr(pos), L.ptr(out), B, HW, inp.shape[1], int(backward),
+          L.dtype_code(inp.dtype), L.stream_ptr())
+
+
 def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok: int, heads: int,
                   causal: bool = False) -> Tensor:
     _dev(qkv, out, lse)

@@ -174,6 +174,38 @@ int ffm_slice_bwd(const void* dcols, const float* img, const float* conv, const 
                   const float* std3, int dtype, void* stream);
 
 /*
+ * RN50 trunk (BASELINE.json configs[4]; clip/model.py:11-118, 227-301) on NHWC rows: row = (b, y, x), C contiguous.
+ * 1x1 convolutions (Bottleneck.conv1 / conv3 with FairLoRA, downsample.0) are ffm_gemm_nt on these rows.
+ *   ffm_stem_im2col      raw fp32 NCHW image -> normalised 3x3 / pad 1 patches of conv1 (stride 2), k = (ky*3+kx)*3 + c,
+ *                        zero padded to Kp columns (trainers/GLP_OT_SVLoRA.py:680,692-693 + clip/model.py:240)
+ *   ffm_im2col3x3        x [B*H*W, C] -> cols [B*Ho*Wo, Kp], k = (ky*3+kx)*C + c  (weights as [Cout, 3, 3, Cin])
+ *   ffm_col2im3x3        dcols -> dx, gathering the <= 9 taps of every input pixel (autograd of F.conv2d w.r.t. input)
+ *   ffm_bn_fwd           nn.BatchNorm2d, eps 1e-5, momentum 0.1: training != 0 uses batch statistics (biased variance)
+ *                        and updates run_mean / run_var (unbiased) in place; y = bn(x) (+ res) (ReLU if relu != 0);
+ *                        mean / rstd [C] are saved for the backward; part: scratch [ffm_bn_blocks(rows)][2][C]
+ *   ffm_bn_bwd           g = dy * (relu_out > 0 if relu_out); dgamma, dbeta, dx (train-mode formula); k12: scratch [2][C]
+ *   ffm_avgpool2         nn.AvgPool2d(2) forward (in [B,H,W,C] -> out [B,H/2,W/2,C]) / backward (in = d pooled, out = d x)
+ *   ffm_add, ffm_relu_bwd   a + b;  g * (y > 0)
+ *   ffm_attnpool_tokens  AttentionPool2d's token assembly (mean token + positional embedding) and its backward
+ */
+int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
+                    const float* std3, int dtype, void* stream);
+int ffm_im2col3x3(const void* x, void* cols, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);
+int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);
+int ffm_bn_blocks(int rows);
+int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
+               float* rstd, float* part, const void* res, void* y, int rows, int C, int training, int relu, int dtype,
+               void* stream);
+int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
+               const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows, int C,
+               int dtype, void* stream);
+int ffm_avgpool2(const void* in, void* out, int B, int H, int W, int C, int backward, int dtype, void* stream);
+int ffm_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int ffm_relu_bwd(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);
+int ffm_attnpool_tokens(const void* in, const void* pos, void* out, int B, int HW, int E, int backward, int dtype,
+                        void* stream);
+
+/*
  * Multi-head self-attention core, softmax(Q K^T / sqrt(64)) V, head_dim 64,
  * optional causal mask (text tower, clip/model.py:562-568); no dropout.
  * qkv: [B*L, 3*heads*64] rows (b,l) with q|k|v concatenated as nn.MultiheadAttention's

@@ -1,0 +1,158 @@
+"""RN50 trunk building blocks (csrc/conv.hip) against PyTorch on the GPU: 3x3 convolution as im2col + ffm_gemm_nt and
+its input gradient, train-/eval-mode BatchNorm forward and backward, AvgPool2d(2), the attention-pool tokens."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F = torch.nn.functional
+DT = [torch.float32, torch.bfloat16]
+IDS = ["f32", "bf16"]
+
+
+def tol(dt):
+    return 3e-5 if dt == torch.float32 else 1.5e-2
+
+
+def rel(got, ref):
+    got, ref = got.double(), ref.double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, dt=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(dt)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fairfedmed_amd import ops
+    return ops
+
+
+def nhwc(x):      # [B,C,H,W] -> rows [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def nchw(r, B, H, W):
+    return r.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("B,H,C,Co,stride", [(2, 16, 64, 64, 1), (3, 14, 32, 64, 1), (2, 16, 32, 64, 2)])
+def test_conv3x3_forward_and_input_gradient(ops, dt, B, H, C, Co, stride):
+    x = rnd(B, C, H, H, dt=dt, seed=1)
+    w = rnd(Co, C, 3, 3, dt=dt, scale=(9 * C) ** -0.5, seed=2)
+    Ho = ops.conv_out(H, stride)
+    ke = 64 if dt == torch.bfloat16 else 32
+    Kp = (9 * C + ke - 1) // ke * ke
+    cols = torch.empty(B * Ho * Ho, Kp, device="cuda", dtype=dt)
+    ops.im2col3x3(nhwc(x), cols, B, H, H, stride)
+    wk = torch.zeros(Co, Kp, device="cuda", dtype=dt)
+    wk[:, :9 * C] = w.permute(0, 2, 3, 1).reshape(Co, 9 * C)            # [Cout, ky, kx, c]
+    y = torch.empty(B * Ho * Ho, Co, device="cuda", dtype=dt)
+    ops.gemm_nt(cols, wk, y)
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=1)
+    assert rel(nchw(y, B, Ho, Ho), ref) < tol(dt)
+    # dX: dcols = dY W, then the gather
+    dy = rnd(B, Co, Ho, Ho, dt=dt, seed=3)
+    wt = torch.zeros(Kp, Co, device="cuda", dtype=dt)
+    wt[:9 * C] = wk[:, :9 * C].t()
+    dcols = torch.empty(B * Ho * Ho, Kp, device="cuda", dtype=dt)
+    ops.gemm_nt(nhwc(dy), wt, dcols)
+    dx = torch.empty(B * H * H, C, device="cuda", dtype=dt)
+    ops.col2im3x3(dcols, dx, B, H, H, stride)
+    xr = x.double().requires_grad_()
+    F.conv2d(xr, w.double(), stride=stride, padding=1).backward(dy.double())
+    assert rel(nchw(dx, B, H, H), xr.grad) < tol(dt) * 2
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_stem_im2col(ops, dt):
+    B, H, Co = 2, 32, 32
+    img = torch.rand(B, 3, H, H, device="cuda", generator=torch.Generator("cuda").manual_seed(5)) * 255
+    mean3, std3 = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    w = rnd(Co, 3, 3, 3, dt=dt, scale=27 ** -0.5, seed=6)
+    Ho = ops.conv_out(H, 2)
+    cols = torch.empty(B * Ho * Ho, 64, device="cuda", dtype=dt)
+    ops.stem_im2col(img, cols, 2, mean3, std3)
+    wk = torch.zeros(Co, 64, device="cuda", dtype=dt)
+    wk[:, :27] = w.permute(0, 2, 3, 1).reshape(Co, 27)
+    y = torch.empty(B * Ho * Ho, Co, device="cuda", dtype=dt)
+    ops.gemm_nt(cols, wk, y)
+    xn = (img / 255.0 - torch.tensor(mean3, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std3, device="cuda").view(1, 3, 1, 1)
+    ref = F.conv2d(xn.double(), w.double(), stride=2, padding=1)
+    assert rel(nchw(y, B, Ho, Ho), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("rows,C,relu,with_res", [(2 * 16 * 16, 64, True, False), (1000, 256, False, False), (3 * 49, 2048, True, True)])
+def test_batchnorm_train_forward_backward_and_eval(ops, dt, rows, C, relu, with_res):
+    x = rnd(rows, C, dt=dt, seed=7) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
+    rm, rv = 0.05 * rnd(C, seed=10), 1 + 0.1 * rnd(C, seed=11).abs()
+    res = rnd(rows, C, dt=dt, seed=12) if with_res else None
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    part = torch.empty(ops.bn_blocks(rows) * 2 * C, device="cuda")
+    y = torch.empty_like(x)
+    rm1, rv1 = rm.clone(), rv.clone()
+    ops.bn_fwd(x, gamma, beta, rm1, rv1, mean, rstd, part, y, True, relu, res)
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    ref = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    assert rel(y, ref.detach()) < tol(dt)
+    assert rel(rm1, rmr) < 1e-5 and rel(rv1, rvr) < 1e-5
+    # backward (through the ReLU mask when there is one)
+    dy = rnd(rows, C, dt=dt, seed=13)
+    ref.backward(dy.double())
+    k12, dg, db = torch.empty(2 * C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = torch.empty_like(x)
+    ops.bn_bwd(dy, y if relu else None, x, gamma, mean, rstd, part, k12, dg, db, dx)
+    t = tol(dt) * (3 if dt == torch.float32 else 1)
+    assert rel(dx, xr.grad) < t and rel(dg, gr.grad) < t and rel(db, br.grad) < t
+    # eval mode: running statistics, nothing updated
+    rm2, rv2 = rm.clone(), rv.clone()
+    ops.bn_fwd(x, gamma, beta, rm2, rv2, mean, rstd, None, y, False, False)
+    ref_e = F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    assert rel(y, ref_e) < tol(dt) and torch.equal(rm2, rm) and torch.equal(rv2, rv)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_avgpool_add_relu_and_attnpool_tokens(ops, dt):
+    B, H, C = 3, 8, 64
+    x = rnd(B, C, H, H, dt=dt, seed=20)
+    out = torch.empty(B * 16, C, device="cuda", dtype=dt)
+    ops.avgpool2(nhwc(x), out, B, H, H)
+    assert rel(nchw(out, B, 4, 4), F.avg_pool2d(x.double(), 2)) < tol(dt)
+    dp = rnd(B * 16, C, dt=dt, seed=21)
+    dx = torch.empty(B * H * H, C, device="cuda", dtype=dt)
+    ops.avgpool2(dp, dx, B, H, H, backward=True)
+    xr = x.double().requires_grad_()
+    F.avg_pool2d(xr, 2).backward(nchw(dp, B, 4, 4).double())
+    assert rel(nchw(dx, B, H, H), xr.grad) < tol(dt)
+    a, b = rnd(640, C, dt=dt, seed=22), rnd(640, C, dt=dt, seed=23)
+    o = torch.empty_like(a)
+    ops.add(a, b, o)
+    assert rel(o, a.double() + b.double()) < tol(dt)
+    ops.relu_bwd(a, b, o)
+    assert rel(o, a.double() * (b.double() > 0)) < 1e-7
+    # attention-pool tokens
+    HW, E = 4, 128
+    feat = rnd(B * HW, E, dt=dt, seed=24)
+    pos = rnd(HW + 1, E, dt=dt, scale=0.1, seed=25)
+    tok = torch.empty(B * (HW + 1), E, device="cuda", dtype=dt)
+    ops.attnpool_tokens(feat, pos, tok, B, HW)
+    fr = feat.double().reshape(B, HW, E).requires_grad_()
+    ref = torch.cat([fr.mean(1, keepdim=True), fr], 1) + pos.double()
+    assert rel(tok.reshape(B, HW + 1, E), ref.detach()) < tol(dt)
+    dt_ = rnd(B * (HW + 1), E, dt=dt, seed=26)
+    ref.backward(dt_.double().reshape(B, HW + 1, E))
+    df = torch.empty_like(feat)
+    ops.attnpool_tokens(dt_, None, df, B, HW, backward=True)
+    assert rel(df.reshape(B, HW, E), fr.grad) < tol(dt)
