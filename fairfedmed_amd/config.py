@@ -57,6 +57,10 @@ class ResNetCfg:
         return self.width * 32 // 64
 
     @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.heads
+
+    @property
     def spacial(self) -> int:
         return self.image_size // 32
 

@@ -183,7 +183,6 @@ class FairLoRAEngine:
         v, t = cfg.vision, cfg.text
         self.params = FlatParams(cfg, self.device)
         self.params.load(state_dict)
-        self.vis = _Stack(v.width, v.heads, v.layers, v.tokens, max_images, False, cfg.lora.rank, dtype, self.device)
         self.n_text = cfg.n_prompts * cfg.n_cls
         # Text tower: the mask is causal and only the EOT row of each prompt is read (clip/model.py:562-568,
         # trainers/GLP_OT_SVLoRA.py:62-64), so tokens after the last EOT position influence neither the features nor
@@ -192,8 +191,67 @@ class FairLoRAEngine:
         self.txt_len = min(t.context_length, max(cfg.eot) + 1)
         assert self.txt_len >= 1 + cfg.n_ctx
         self.txt = _Stack(t.width, t.heads, t.layers, self.txt_len, self.n_text, True, 0, dtype, self.device)
-        self.load_frozen(state_dict)
         dev, f32 = self.device, torch.float32
+        self._init_vision(max_images)                 # tower-specific buffers (ViT here, RN50 in engine_rn.py)
+        self.load_frozen(state_dict)
+        self._init_vision_late()
+        self.feat = torch.zeros(max_images * v.tokens, v.out_dim, device=dev, dtype=dtype)
+        self.dfeat = torch.zeros_like(self.feat)
+        self.fbar = torch.zeros(max_images, v.out_dim, device=dev, dtype=f32)
+        self.rnorm = torch.zeros(max_images * v.tokens, device=dev, dtype=f32)
+        self.logits_img = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
+        self.dlogits_img = torch.zeros_like(self.logits_img)
+        self.logits = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
+        self.prob = torch.zeros_like(self.logits)
+        self.loss = torch.zeros(1, device=dev, dtype=f32)
+        self.finite = torch.ones(1, device=dev, dtype=torch.int32)
+        self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
+        self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
+        self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.step_plans: Dict[tuple, list] = {}
+        self.use_replay = True                        # replay recorded launch plans (host-side "graph")
+        self.eot_rows = torch.tensor([i * self.txt_len + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
+                                     device=dev, dtype=torch.int64)
+        # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
+        # logits head, so it runs on its own HIP stream beside it (forward and backward).
+        self.side = self._side0 = torch.cuda.Stream(device=self.device)
+        self.grad_stream = self._grad0 = torch.cuda.Stream(device=self.device)
+        self.ev_layer = [torch.cuda.Event() for _ in range(self._n_layer_events())]
+        self.ev_grads = torch.cuda.Event()
+        self.ev_text_fwd = torch.cuda.Event()
+        self.ev_head_bwd = torch.cuda.Event()
+        self.ev_text_bwd = torch.cuda.Event()
+        self.ev_start = torch.cuda.Event()
+
+    # ---------------------------------------------------- vision tower hooks --
+    def _init_vision(self, max_images: int) -> None:
+        cfg, v, dtype, dev = self.cfg, self.cfg.vision, self.dtype, self.device
+        self.vis = _Stack(v.width, v.heads, v.layers, v.tokens, max_images, False, cfg.lora.rank, dtype, dev)
+        P = v.grid * v.grid
+        self.cols = torch.zeros(max_images * P, 3 * v.patch * v.patch, device=dev, dtype=dtype)
+        self.patch_out = torch.zeros(max_images * P, v.width, device=dev, dtype=dtype)
+        self.hpost = torch.zeros(max_images * v.tokens, v.width, device=dev, dtype=dtype)
+        self.post_stats = (torch.zeros(max_images * v.tokens, device=dev), torch.zeros(max_images * v.tokens, device=dev))
+        f32 = torch.float32
+        self.is3d = cfg.dim_per_3d_slice > 0
+        if self.is3d:
+            D, H = cfg.dim_per_3d_slice, v.image_size
+            nblk = ops.slice_blocks(H, H)
+            self.conv_out = torch.zeros(max_images, 3, H, H, device=dev, dtype=f32)
+            self.dconv = torch.zeros_like(self.conv_out)
+            self.mm_part = torch.zeros(max_images * nblk * 2, device=dev, dtype=f32)
+            self.mnmx = torch.zeros(max_images, 2, device=dev, dtype=f32)
+            self.mm_cnt = torch.zeros(max_images, 2, device=dev, dtype=torch.int32)
+            self.ab_part = torch.zeros(max_images * ops.slice_bwd_ab_blocks() * 2, device=dev, dtype=f32)
+            self.gmm = torch.zeros(max_images, 2, device=dev, dtype=f32)
+            self.wpart = torch.zeros(max_images * nblk * (3 * D * 25 + 3), device=dev, dtype=f32)
+            self.dcols = torch.zeros_like(self.cols)
+            self.dpatch = torch.zeros_like(self.patch_out)
+
+    def _init_vision_late(self) -> None:
+        """After the frozen weights are loaded: the packed rank operands of the FairLoRA GEMMs."""
+        cfg, v, dtype, dev = self.cfg, self.cfg.vision, self.dtype, self.device
         # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
         self.fused_rank = 0 < cfg.lora.rank <= 16
         if self.fused_rank:
@@ -209,53 +267,9 @@ class FairLoRAEngine:
                 for role, buf in pk.items():
                     ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf))
             self.pack_plan = ops.PackPlan(ent, dtype, dev)
-        P = v.grid * v.grid
-        self.cols = torch.zeros(max_images * P, 3 * v.patch * v.patch, device=dev, dtype=dtype)
-        self.patch_out = torch.zeros(max_images * P, v.width, device=dev, dtype=dtype)
-        self.hpost = torch.zeros(max_images * v.tokens, v.width, device=dev, dtype=dtype)
-        self.post_stats = (torch.zeros(max_images * v.tokens, device=dev), torch.zeros(max_images * v.tokens, device=dev))
-        self.feat = torch.zeros(max_images * v.tokens, v.out_dim, device=dev, dtype=dtype)
-        self.dfeat = torch.zeros_like(self.feat)
-        self.fbar = torch.zeros(max_images, v.out_dim, device=dev, dtype=f32)
-        self.rnorm = torch.zeros(max_images * v.tokens, device=dev, dtype=f32)
-        self.logits_img = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
-        self.dlogits_img = torch.zeros_like(self.logits_img)
-        self.logits = torch.zeros(max_images, cfg.n_cls, device=dev, dtype=f32)
-        self.prob = torch.zeros_like(self.logits)
-        self.loss = torch.zeros(1, device=dev, dtype=f32)
-        self.finite = torch.ones(1, device=dev, dtype=torch.int32)
-        self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
-        self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
-        self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
-        self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
-        self.is3d = cfg.dim_per_3d_slice > 0
-        if self.is3d:
-            D, H = cfg.dim_per_3d_slice, v.image_size
-            nblk = ops.slice_blocks(H, H)
-            self.conv_out = torch.zeros(max_images, 3, H, H, device=dev, dtype=f32)
-            self.dconv = torch.zeros_like(self.conv_out)
-            self.mm_part = torch.zeros(max_images * nblk * 2, device=dev, dtype=f32)
-            self.mnmx = torch.zeros(max_images, 2, device=dev, dtype=f32)
-            self.mm_cnt = torch.zeros(max_images, 2, device=dev, dtype=torch.int32)
-            self.ab_part = torch.zeros(max_images * ops.slice_bwd_ab_blocks() * 2, device=dev, dtype=f32)
-            self.gmm = torch.zeros(max_images, 2, device=dev, dtype=f32)
-            self.wpart = torch.zeros(max_images * nblk * (3 * D * 25 + 3), device=dev, dtype=f32)
-            self.dcols = torch.zeros_like(self.cols)
-            self.dpatch = torch.zeros_like(self.patch_out)
-        self.step_plans: Dict[tuple, list] = {}
-        self.use_replay = True                        # replay recorded launch plans (host-side "graph")
-        self.eot_rows = torch.tensor([i * self.txt_len + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
-                                     device=dev, dtype=torch.int64)
-        # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
-        # logits head, so it runs on its own HIP stream beside it (forward and backward).
-        self.side = self._side0 = torch.cuda.Stream(device=self.device)
-        self.grad_stream = self._grad0 = torch.cuda.Stream(device=self.device)
-        self.ev_layer = [torch.cuda.Event() for _ in range(v.layers)]
-        self.ev_grads = torch.cuda.Event()
-        self.ev_text_fwd = torch.cuda.Event()
-        self.ev_head_bwd = torch.cuda.Event()
-        self.ev_text_bwd = torch.cuda.Event()
-        self.ev_start = torch.cuda.Event()
+
+    def _n_layer_events(self) -> int:
+        return self.cfg.vision.layers
 
     # ------------------------------------------------------------ weights --
     def _w(self, x: Tensor) -> Tensor:
@@ -304,9 +318,7 @@ class FairLoRAEngine:
 
     def load_frozen(self, sd: Dict[str, Tensor]) -> None:
         """(Re)build the compute-dtype copies of every frozen tensor."""
-        cfg, v = self.cfg, self.cfg.vision
-        ie, te = "image_encoder.", "text_encoder."
-        self._load_stack(self.vis, sd, ie, True)
+        te = "text_encoder."
         self._load_stack(self.txt, sd, te, False)
         def put(name, val):                                       # stable addresses across reloads
             cur = getattr(self, name, None)
@@ -318,6 +330,19 @@ class FairLoRAEngine:
             else:
                 cur.copy_(val)
 
+        self._load_vision_frozen(sd, put)
+        put("logit_scale", self._f(sd["logit_scale"].reshape(1)))
+        # text side constants stay fp32 (tiny): prompt pieces, ln_final, projection
+        put("tok_prefix", self._f(sd["prompt_learner.token_prefix"]))
+        put("tok_suffix", self._f(sd["prompt_learner.token_suffix"]))
+        put("txt_pos", self._f(sd[te + "positional_embedding"]))
+        put("lnfinal", (self._f(sd[te + "ln_final.weight"]), self._f(sd[te + "ln_final.bias"])))
+        put("text_proj", self._f(sd[te + "text_projection"]))
+
+    def _load_vision_frozen(self, sd: Dict[str, Tensor], put) -> None:
+        cfg, v = self.cfg, self.cfg.vision
+        ie = "image_encoder."
+        self._load_stack(self.vis, sd, ie, True)
         put("conv_w", self._w(sd[ie + "conv1.weight"].reshape(v.width, -1)))
         if cfg.dim_per_3d_slice:
             put("conv_w_t", self._wt(sd[ie + "conv1.weight"].reshape(v.width, -1)))   # dX of the patch embedding
@@ -327,13 +352,6 @@ class FairLoRAEngine:
         put("lnpost", (self._f(sd[ie + "ln_post.weight"]), self._f(sd[ie + "ln_post.bias"])))
         put("proj", self._w(sd[ie + "proj"]))                     # [width, out]: B operand of dh = df proj^T
         put("proj_t", self._wt(sd[ie + "proj"]))                  # [out, width]: B operand of f = h proj
-        put("logit_scale", self._f(sd["logit_scale"].reshape(1)))
-        # text side constants stay fp32 (tiny): prompt pieces, ln_final, projection
-        put("tok_prefix", self._f(sd["prompt_learner.token_prefix"]))
-        put("tok_suffix", self._f(sd["prompt_learner.token_suffix"]))
-        put("txt_pos", self._f(sd[te + "positional_embedding"]))
-        put("lnfinal", (self._f(sd[te + "ln_final.weight"]), self._f(sd[te + "ln_final.bias"])))
-        put("text_proj", self._f(sd[te + "text_projection"]))
 
     # -------------------------------------------------------------- tower --
     def _lora_view(self, blk: _Block, role: str) -> Tensor:
@@ -617,6 +635,23 @@ class FairLoRAEngine:
         ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
                      images, L, cfg.n_cls)
 
+    def _vision_backward(self, b: int, S: int, has_attr: bool) -> None:
+        """dfeat -> gradients of every trainable tensor of the image side (params.grad)."""
+        cfg, v = self.cfg, self.cfg.vision
+        images, L = b * S, v.tokens
+        rows = images * L
+        a32 = self.attr_i32[:b] if has_attr else None
+        ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
+        ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
+                          self.post_stats[1], None, self.vis.g[:rows])
+        self._stack_backward(self.vis, rows, images, a32, L * S, self.is3d)
+        if self.is3d:
+            # dL/d(tokens) -> ln_pre / pos-add backward -> dX of the patch embedding (columns of the patches)
+            P = v.grid * v.grid
+            ops.embed_lnpre_bwd(self.vis.g[:rows], self.patch_out[:images * P], self.pos, self.lnpre[0],
+                                self.dpatch[:images * P], images, L)
+            ops.gemm_nt(self.dpatch[:images * P], self.conv_w_t, self.dcols[:images * P])
+
     # ---------------------------------------------------------------- API --
     @torch.no_grad()
     def forward(self, image: Tensor, attr: Optional[Tensor] = None) -> Tensor:
@@ -647,16 +682,7 @@ class FairLoRAEngine:
         with self._on(self.side):
             self._text_backward(self.side)
         self._ev_record(self.ev_text_bwd, self.side)
-        ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
-        ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
-                          self.post_stats[1], None, self.vis.g[:rows])
-        self._stack_backward(self.vis, rows, images, a32, L * S, self.is3d)
-        if self.is3d:
-            # dL/d(tokens) -> ln_pre / pos-add backward -> dX of the patch embedding (columns of the patches)
-            P = v.grid * v.grid
-            ops.embed_lnpre_bwd(self.vis.g[:rows], self.patch_out[:images * P], self.pos, self.lnpre[0],
-                                self.dpatch[:images * P], images, L)
-            ops.gemm_nt(self.dpatch[:images * P], self.conv_w_t, self.dcols[:images * P])
+        self._vision_backward(b, S, has_attr)
         self._ev_wait(main, self.ev_text_bwd)
 
     def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:

@@ -1,0 +1,457 @@
+"""RN50 image tower for the FairLoRA engine (BASELINE.json configs[4]).
+
+``ModifiedResNet_GLP_OT`` (clip/model.py:227-301) after ``apply_lora_to_model``
+(trainers/GLP_OT_SVLoRA.py:541-573): FairLoRALinear on every Bottleneck's 1x1
+conv1 / conv3, LoRALinear on the four attention-pool projections, BatchNorm
+weights and biases trainable (:822-829), everything else frozen.
+
+Data layout: activations are NHWC rows, row = (image, y, x), channels contiguous,
+so every 1x1 convolution IS ffm_gemm_nt on the rows (with the FairLoRA epilogue),
+3x3 convolutions are im2col + ffm_gemm_nt with the weight re-ordered once to
+[Cout, (ky, kx, cin)], and the attention pool runs on [image*L, E] token rows with
+the ViT attention kernels (head_dim 64, 32 heads).  The text tower, logits head,
+flat parameter buffer, SGD, streams and launch-plan replay are the base class's.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .engine import FairLoRAEngine, _round_up
+from .synth import buffer_keys
+
+Tensor = torch.Tensor
+
+
+class _Lora:
+    """One (Fair)LoRA-wrapped linear over token / pixel rows: y = x W^T (+b) + scaling ((x A) * s_b) B.
+    fair=False is the reference's LoRALinear (:218-241): the same update with s = 1 and no groups."""
+
+    def __init__(self, eng: "RN50Engine", prefix: str, K: int, N: int, max_rows: int, fair: bool):
+        self.eng, self.K, self.N, self.fair = eng, K, N, fair
+        self.kA, self.kB = prefix + "lora_A.weight", prefix + "lora_B.weight"
+        self.kS = prefix + "lora_S.weight" if fair else None
+        lo, dt = eng.cfg.lora, eng.dtype
+        r = lo.rank
+        f = lambda *s: torch.zeros(*s, device=eng.device, dtype=torch.float32)
+        self.t, self.ts, self.u, self.us = f(max_rows, r), f(max_rows, r), f(max_rows, r), f(max_rows, r)
+        ns = ops.lora_grad_splits(max_rows)
+        self.pA, self.pB = f(ns * K * r), f(ns * N * r)
+        self.pS = f(ops.lora_down_blocks(max_rows, N, r, dt) * lo.num_groups * r) if fair else None
+
+    def _s(self) -> Tuple[Tensor, int]:
+        e = self.eng
+        return (e.params.view(self.kS), e.cfg.lora.num_groups) if self.fair else (e.ones_s, 1)
+
+    def fwd(self, x: Tensor, W: Tensor, out: Tensor, attr: Optional[Tensor], rps: int, bias=None, res=None) -> None:
+        e, lo = self.eng, self.eng.cfg.lora
+        rows = x.shape[0]
+        S, G = self._s()
+        ops.lora_down(x, e.params.view(self.kA), False, S, attr if self.fair else None, lo.rank, G, rps, lo.scaling,
+                      lo.lambda_group, self.t[:rows], self.ts[:rows])
+        ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res)
+
+    def bwd(self, g: Tensor, Wt: Tensor, dx: Tensor, x: Tensor, attr: Optional[Tensor], rps: int, res=None) -> None:
+        """g = dL/dy; writes dx = g W (+ LoRA term) (+ res) and the partial sums of dA, dB, dS."""
+        e, lo = self.eng, self.eng.cfg.lora
+        rows = g.shape[0]
+        S, G = self._s()
+        ops.lora_down(g, e.params.view(self.kB), True, S, attr if self.fair else None, lo.rank, G, rps, lo.scaling,
+                      lo.lambda_group, self.u[:rows], self.us[:rows], self.t[:rows] if self.fair else None, self.pS)
+        ops.gemm_nt(g, Wt, dx, ts=self.us[:rows], lw=e.params.view(self.kA), lw_is_kr=True, res=res)
+        ops.lora_grad_partial(g, self.ts[:rows], lo.rank, self.pB)
+        ops.lora_grad_partial(x, self.us[:rows], lo.rank, self.pA)
+
+    def reduce_entries(self, rows: int) -> list:
+        e, lo = self.eng, self.eng.cfg.lora
+        r, nsp = lo.rank, ops.lora_grad_splits(rows)
+        gv = lambda k: e.params.view(k, "grad")
+        ent = [(self.pB, nsp, self.N * r, gv(self.kB), self.N, r), (self.pA, nsp, self.K * r, gv(self.kA), 0, 0)]
+        if self.fair:
+            ent.append((self.pS, ops.lora_down_blocks(rows, self.N, r, e.dtype), lo.num_groups * r, gv(self.kS), 0, 0))
+        return ent
+
+
+class _BN:
+    """nn.BatchNorm2d over NHWC rows; weight / bias live in the flat trainable buffer."""
+
+    def __init__(self, eng: "RN50Engine", prefix: str, C: int, max_rows: int):
+        self.eng, self.prefix, self.C = eng, prefix, C
+        f = lambda: torch.zeros(C, device=eng.device, dtype=torch.float32)
+        self.run_mean, self.run_var, self.mean, self.rstd = f(), f(), f(), f()
+        eng.bn_scratch = max(eng.bn_scratch, ops.bn_blocks(max_rows) * 2 * C)
+        eng.bn_cmax = max(eng.bn_cmax, C)
+        eng.bns.append(self)
+
+    def fwd(self, x: Tensor, y: Tensor, relu: bool, res: Optional[Tensor] = None) -> None:
+        e = self.eng
+        ops.bn_fwd(x, e.params.view(self.prefix + "weight"), e.params.view(self.prefix + "bias"), self.run_mean,
+                   self.run_var, self.mean, self.rstd, e.bn_part, y, e.bn_training, relu, res)
+
+    def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor) -> None:
+        e = self.eng
+        ops.bn_bwd(dy, relu_out, x, e.params.view(self.prefix + "weight"), self.mean, self.rstd, e.bn_part, e.bn_k12,
+                   e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx)
+
+
+class _Bneck:
+    """clip/model.py:11-60 with every convolution at stride 1 and an average pool after conv2 when stride > 1."""
+
+    def __init__(self, eng: "RN50Engine", p: str, inpl: int, planes: int, stride: int, H: int, max_images: int):
+        self.eng, self.p, self.inpl, self.planes, self.stride = eng, p, inpl, planes, stride
+        self.Hin, self.Hout = H, H // stride
+        Ri, Ro = max_images * H * H, max_images * self.Hout * self.Hout
+        e = lambda rows, C: torch.zeros(rows, C, device=eng.device, dtype=eng.dtype)
+        out = 4 * planes
+        self.has_down = stride > 1 or inpl != out
+        self.c1 = _Lora(eng, p + "conv1.", inpl, planes, Ri, True)
+        self.c3 = _Lora(eng, p + "conv3.", planes, out, Ro, True)
+        self.bn1, self.bn2 = _BN(eng, p + "bn1.", planes, Ri), _BN(eng, p + "bn2.", planes, Ri)
+        self.bn3 = _BN(eng, p + "bn3.", out, Ro)
+        self.Kp = _round_up(9 * planes, eng.kq)
+        eng.cols_elems = max(eng.cols_elems, Ri * self.Kp)
+        # saved activations
+        self.z1, self.a1, self.z2, self.a2 = e(Ri, planes), e(Ri, planes), e(Ri, planes), e(Ri, planes)
+        self.a2p = e(Ro, planes) if stride > 1 else None
+        self.z3, self.out = e(Ro, out), e(Ro, out)
+        # gradients
+        self.dz3, self.da2p, self.dz2, self.da1, self.dz1 = e(Ro, out), e(Ro, planes), e(Ri, planes), e(Ri, planes), e(Ri, planes)
+        self.da2 = e(Ri, planes) if stride > 1 else None
+        self.dx = e(Ri, inpl)
+        if self.has_down:
+            self.bnd = _BN(eng, p + "downsample.1.", out, Ro)
+            self.xp = e(Ro, inpl) if stride > 1 else None
+            self.zd, self.idn, self.dzd, self.dxp = e(Ro, out), e(Ro, out), e(Ro, out), e(Ro, inpl)
+            self.dxid = e(Ri, inpl) if stride > 1 else None
+        else:
+            self.gid = e(Ro, out)
+
+    def load(self, sd, putw) -> None:
+        e, p = self.eng, self.p
+        w1 = sd[p + "conv1.original_linear.weight"].reshape(self.planes, self.inpl)
+        w3 = sd[p + "conv3.original_linear.weight"].reshape(4 * self.planes, self.planes)
+        putw(p + "w1", e._w(w1)); putw(p + "w1t", e._wt(w1))
+        putw(p + "w3", e._w(w3)); putw(p + "w3t", e._wt(w3))
+        w2 = e.conv3x3_rows(sd[p + "conv2.weight"], self.Kp)
+        putw(p + "w2", e._w(w2)); putw(p + "w2t", e._wt(w2))
+        if self.has_down:
+            wd = sd[p + "downsample.0.weight"].reshape(4 * self.planes, self.inpl)
+            putw(p + "wd", e._w(wd)); putw(p + "wdt", e._wt(wd))
+
+    def forward(self, x: Tensor, images: int, attr: Optional[Tensor]) -> Tensor:
+        e, p, W = self.eng, self.p, self.eng.rnw
+        Hi, Ho = self.Hin, self.Hout
+        ri, ro = images * Hi * Hi, images * Ho * Ho
+        z1, a1, z2, a2, z3, out = self.z1[:ri], self.a1[:ri], self.z2[:ri], self.a2[:ri], self.z3[:ro], self.out[:ro]
+        self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi)
+        self.bn1.fwd(z1, a1, True)
+        cols = e.cols_view(ri, self.Kp)
+        ops.im2col3x3(a1, cols, images, Hi, Hi, 1)
+        ops.gemm_nt(cols, W[p + "w2"], z2)
+        self.bn2.fwd(z2, a2, True)
+        a = a2
+        if self.stride > 1:
+            a = self.a2p[:ro]
+            ops.avgpool2(a2, a, images, Hi, Hi)
+        self.c3.fwd(a, W[p + "w3"], z3, attr, Ho * Ho)
+        idn = x
+        if self.has_down:
+            xi = x
+            if self.stride > 1:
+                xi = self.xp[:ro]
+                ops.avgpool2(x, xi, images, Hi, Hi)
+            ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro])
+            idn = self.idn[:ro]
+            self.bnd.fwd(self.zd[:ro], idn, False)
+        self.bn3.fwd(z3, out, True, res=idn)                       # relu(bn3(conv3) + identity)
+        return out
+
+    def backward(self, g: Tensor, x: Tensor, images: int, attr: Optional[Tensor]) -> Tensor:
+        """g = dL/d(block output) -> dL/d(block input)."""
+        e, p, W = self.eng, self.p, self.eng.rnw
+        Hi, Ho = self.Hin, self.Hout
+        ri, ro = images * Hi * Hi, images * Ho * Ho
+        out = self.out[:ro]
+        self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro])
+        if self.has_down:
+            self.bnd.bwd(g, out, self.zd[:ro], self.dzd[:ro])
+            gid = self.dxp[:ro]
+            ops.gemm_nt(self.dzd[:ro], W[p + "wdt"], gid)
+            if self.stride > 1:
+                ops.avgpool2(gid, self.dxid[:ri], images, Hi, Hi, backward=True)
+                gid = self.dxid[:ri]
+        else:
+            gid = self.gid[:ro]
+            ops.relu_bwd(g, out, gid)
+        a = self.a2p[:ro] if self.stride > 1 else self.a2[:ri]
+        self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho)
+        da2 = self.da2p[:ro]
+        if self.stride > 1:
+            da2 = self.da2[:ri]
+            ops.avgpool2(self.da2p[:ro], da2, images, Hi, Hi, backward=True)
+        self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
+        dcols = e.cols_view(ri, self.Kp)
+        ops.gemm_nt(self.dz2[:ri], W[p + "w2t"], dcols)
+        ops.col2im3x3(dcols, self.da1[:ri], images, Hi, Hi, 1)
+        self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
+        self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid)
+        return self.dx[:ri]
+
+    def loras(self):
+        return [(self.c1, self.Hin), (self.c3, self.Hout)]
+
+
+class RN50Engine(FairLoRAEngine):
+    """FairLoRAEngine with CLIP's ModifiedResNet as the image tower."""
+
+    # ------------------------------------------------------------------ setup --
+    def _init_vision(self, max_images: int) -> None:
+        cfg, v, dt, dev = self.cfg, self.cfg.vision, self.dtype, self.device
+        if cfg.dim_per_3d_slice:
+            raise ValueError("the 3D OCT front end is built for the ViT tower only")
+        if v.image_size % 32:
+            raise ValueError("ModifiedResNet needs an image size divisible by 32")
+        self.is3d = False
+        self.vis = None
+        self.kq = 64 if dt == torch.bfloat16 else 32             # GEMM K granularity (128 bytes)
+        self.rnw: Dict[str, Tensor] = {}
+        self.bns: List[_BN] = []
+        self.bn_scratch = self.bn_cmax = self.cols_elems = 0
+        self.bn_training = False
+        self.bn_steps = 0
+        self.nbt0: Dict[str, int] = {}
+        e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)
+        w, H1 = v.width, v.image_size // 2
+        R1 = max_images * H1 * H1
+        self.H1, self.H2 = H1, H1 // 2
+        self.ones_s = torch.ones(1, cfg.lora.rank, device=dev, dtype=torch.float32)
+        # stem: conv1 (stride 2) .. conv3, three BatchNorms, 2x2 average pool
+        self.Kp1, self.Kp2 = _round_up(27, self.kq), _round_up(9 * (w // 2), self.kq)
+        self.Kc = _round_up(w // 2, self.kq)                      # K of the dX product of stem conv2
+        self.cols1 = e(R1, self.Kp1)
+        self.cols_elems = R1 * self.Kp2
+        self.sbn = [_BN(self, f"image_encoder.bn{i}.", c, R1) for i, c in ((1, w // 2), (2, w // 2), (3, w))]
+        self.sz = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
+        self.sa = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
+        self.dsa = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
+        self.dsz = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
+        self.dsz2p = e(R1, self.Kc) if self.Kc != w // 2 else None
+        self.p0 = e(max_images * self.H2 * self.H2, w)
+        # residual stages
+        self.blocks: List[_Bneck] = []
+        inpl, H = w, self.H2
+        for li, nblk in enumerate(v.layers):
+            planes = w * (2 ** li)
+            for j in range(nblk):
+                stride = 2 if (li > 0 and j == 0) else 1
+                blk = _Bneck(self, f"image_encoder.layer{li + 1}.{j}.", inpl, planes, stride, H, max_images)
+                self.blocks.append(blk)
+                inpl, H = planes * 4, H // stride
+        assert inpl == v.embed_dim and H == v.spacial
+        # attention pool
+        E, L = v.embed_dim, v.tokens
+        T = max_images * L
+        ap = "image_encoder.attnpool."
+        self.ap = {n: _Lora(self, f"{ap}{n}_proj.", E, v.out_dim if n == "c" else E, T, False) for n in "qkvc"}
+        self.tok, self.qkv, self.att_o = e(T, E), e(T, 3 * E), e(T, E)
+        self.lse = torch.zeros(max_images * v.heads * L, device=dev, dtype=torch.float32)
+        self.delta = torch.zeros_like(self.lse)
+        self.d_o, self.dqkv, self.dtok = e(T, E), e(T, 3 * E), [e(T, E), e(T, E)]
+        self.dx4 = e(max_images * v.spacial * v.spacial, E)
+        self.cols_flat = torch.zeros(self.cols_elems, device=dev, dtype=dt)
+        self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
+        self.bn_k12 = torch.zeros(2 * self.bn_cmax, device=dev, dtype=torch.float32)
+        self.rn_plans: Dict[int, ops.ReducePlan] = {}
+
+    def _init_vision_late(self) -> None:
+        self.fused_rank = False
+
+    def _n_layer_events(self) -> int:
+        return 1
+
+    def cols_view(self, rows: int, Kp: int) -> Tensor:
+        return self.cols_flat[:rows * Kp].view(rows, Kp)
+
+    def conv3x3_rows(self, w: Tensor, Kp: int) -> Tensor:
+        """[Cout, Cin, 3, 3] -> [Cout, Kp] with k = (ky*3 + kx)*Cin + c, zero padded (the order ffm_im2col3x3 writes)."""
+        co = w.shape[0]
+        rows = w.float().permute(0, 2, 3, 1).reshape(co, -1)
+        out = torch.zeros(co, Kp, dtype=torch.float32)
+        out[:, :rows.shape[1]] = rows
+        return out
+
+    def _load_vision_frozen(self, sd: Dict[str, Tensor], put) -> None:
+        v, ie = self.cfg.vision, "image_encoder."
+
+        def putw(name: str, val: Tensor) -> None:                # stable addresses across reloads
+            if name in self.rnw:
+                self.rnw[name].copy_(val)
+            else:
+                self.rnw[name] = val
+
+        w = v.width
+        putw("s1", self._w(self.conv3x3_rows(sd[ie + "conv1.weight"], self.Kp1)))
+        s2 = self.conv3x3_rows(sd[ie + "conv2.weight"], self.Kp2)
+        putw("s2", self._w(s2))
+        s2t = torch.zeros(self.Kp2, self.Kc)                      # dX operand, K padded to the GEMM granularity
+        s2t[:, :w // 2] = s2.t()
+        putw("s2t", self._w(s2t))
+        s3 = self.conv3x3_rows(sd[ie + "conv3.weight"], self.Kp2)
+        putw("s3", self._w(s3)); putw("s3t", self._wt(s3))
+        for blk in self.blocks:
+            blk.load(sd, putw)
+        ap = ie + "attnpool."
+        putw("pos", self._w(sd[ap + "positional_embedding"]))
+        for n in "qkvc":
+            wt = sd[f"{ap}{n}_proj.original_linear.weight"]
+            putw(f"ap_{n}", self._w(wt)); putw(f"ap_{n}t", self._wt(wt))
+            putw(f"ap_{n}b", self._f(sd[f"{ap}{n}_proj.original_linear.bias"]))
+        self.load_buffers(sd)
+
+    # ------------------------------------------------------ BatchNorm buffers --
+    def load_buffers(self, sd: Dict[str, Tensor]) -> None:
+        """running_mean / running_var / num_batches_tracked of every BatchNorm2d (clip/model.py:17-36, 237-244)."""
+        for bn in self.bns:
+            bn.run_mean.copy_(sd[bn.prefix + "running_mean"].to(self.device, torch.float32))
+            bn.run_var.copy_(sd[bn.prefix + "running_var"].to(self.device, torch.float32))
+            self.nbt0[bn.prefix] = int(sd[bn.prefix + "num_batches_tracked"])
+        self.bn_steps = 0
+
+    def buffer_state(self) -> Dict[str, Tensor]:
+        out = {}
+        by_prefix = {bn.prefix: bn for bn in self.bns}
+        for k in buffer_keys(self.cfg):
+            p, name = k.rsplit(".", 1)
+            bn = by_prefix[p + "."]
+            if name == "num_batches_tracked":
+                out[k] = torch.tensor(self.nbt0[bn.prefix] + self.bn_steps, dtype=torch.int64)
+            else:
+                out[k] = (bn.run_mean if name == "running_mean" else bn.run_var).clone()
+        return out
+
+    # ----------------------------------------------------------------- inputs --
+    def _check_batch(self, image: Tensor) -> Tuple[int, int]:
+        v = self.cfg.vision
+        if not image.is_cuda or image.dtype != torch.float32:
+            raise TypeError("image must be a float32 CUDA tensor of raw 0..255 values")
+        b, c, h, w = image.shape
+        if c != 3 or h != v.image_size or w != v.image_size:
+            raise ValueError(f"expected [B,3,{v.image_size},{v.image_size}], got {tuple(image.shape)}")
+        if b > self.max_images:
+            raise ValueError(f"{b} images exceed the engine's max_images={self.max_images}")
+        return b, 1
+
+    def _load_inputs(self, image: Tensor, attr: Optional[Tensor], label: Optional[Tensor]):
+        cfg = self.cfg
+        b, S = self._check_batch(image)
+        ops.stem_im2col(image.contiguous(), self.cols1[:b * self.H1 * self.H1], 2, cfg.pixel_mean, cfg.pixel_std)
+        if attr is not None:
+            self.attr_i32[:b].copy_(attr)
+        if label is not None:
+            self.label_buf[:b].copy_(label)
+        return b, S
+
+    # ---------------------------------------------------------------- forward --
+    def _vision_forward(self, b: int, S: int, has_attr: bool, wait=None) -> None:
+        cfg, v, W = self.cfg, self.cfg.vision, self.rnw
+        H1, H2 = self.H1, self.H2
+        r1 = b * H1 * H1
+        a32 = self.attr_i32[:b] if has_attr else None
+        sz, sa = [t[:r1] for t in self.sz], [t[:r1] for t in self.sa]
+        ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0])
+        self.sbn[0].fwd(sz[0], sa[0], True)
+        for i, wn in ((1, "s2"), (2, "s3")):
+            cols = self.cols_view(r1, self.Kp2)
+            ops.im2col3x3(sa[i - 1], cols, b, H1, H1, 1)
+            ops.gemm_nt(cols, W[wn], sz[i])
+            self.sbn[i].fwd(sz[i], sa[i], True)
+        x = self.p0[:b * H2 * H2]
+        ops.avgpool2(sa[2], x, b, H1, H1)
+        for blk in self.blocks:
+            x = blk.forward(x, b, a32)
+        # attention pool (clip/model.py:75-118): all HW + 1 tokens come back
+        HW, L, E = v.spacial * v.spacial, v.tokens, v.embed_dim
+        rows = b * L
+        tok, qkv = self.tok[:rows], self.qkv[:rows]
+        ops.attnpool_tokens(x, W["pos"], tok, b, HW)
+        for i, n in enumerate("qkv"):
+            self.ap[n].fwd(tok, W[f"ap_{n}"], qkv[:, i * E:(i + 1) * E], None, L, bias=W[f"ap_{n}b"])
+        ops.attention_fwd(qkv, self.att_o[:rows], self.lse, b, L, v.heads, False)
+        self.ap["c"].fwd(self.att_o[:rows], W["ap_c"], self.feat[:rows], None, L, bias=W["ap_cb"])
+        if wait is not None:
+            self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
+        ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
+                     b, L, cfg.n_cls)
+
+    # --------------------------------------------------------------- backward --
+    def _vision_backward(self, b: int, S: int, has_attr: bool) -> None:
+        cfg, v, W = self.cfg, self.cfg.vision, self.rnw
+        HW, L, E = v.spacial * v.spacial, v.tokens, v.embed_dim
+        rows = b * L
+        a32 = self.attr_i32[:b] if has_attr else None
+        tok, qkv, dqkv = self.tok[:rows], self.qkv[:rows], self.dqkv[:rows]
+        self.ap["c"].bwd(self.dfeat[:rows], W["ap_ct"], self.d_o[:rows], self.att_o[:rows], None, L)
+        ops.attention_bwd(qkv, self.att_o[:rows], self.d_o[:rows], self.lse, self.delta, dqkv, b, L, v.heads, False)
+        acc = None
+        for i, n in enumerate("qkv"):
+            dst = self.dtok[i & 1][:rows]
+            self.ap[n].bwd(dqkv[:, i * E:(i + 1) * E], W[f"ap_{n}t"], dst, tok, None, L, res=acc)
+            acc = dst
+        g = self.dx4[:b * HW]
+        ops.attnpool_tokens(acc, None, g, b, HW, backward=True)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            x = self.blocks[i - 1].out[:b * self.blocks[i].Hin ** 2] if i > 0 else self.p0[:b * self.H2 * self.H2]
+            g = self.blocks[i].backward(g, x, b, a32)
+        # stem: only the BatchNorm weights / biases train, but their gradients need dX through conv3 and conv2
+        H1 = self.H1
+        r1 = b * H1 * H1
+        sz, sa = [t[:r1] for t in self.sz], [t[:r1] for t in self.sa]
+        dsa, dsz = [t[:r1] for t in self.dsa], [t[:r1] for t in self.dsz]
+        ops.avgpool2(g, dsa[2], b, H1, H1, backward=True)
+        self.sbn[2].bwd(dsa[2], sa[2], sz[2], dsz[2])
+        dcols = self.cols_view(r1, self.Kp2)
+        ops.gemm_nt(dsz[2], W["s3t"], dcols)
+        ops.col2im3x3(dcols, dsa[1], b, H1, H1, 1)
+        self.sbn[1].bwd(dsa[1], sa[1], sz[1], dsz[1])
+        gz = dsz[1]
+        if self.dsz2p is not None:
+            gz = self.dsz2p[:r1]
+            c = dsz[1].shape[1]
+            self._glue(lambda gz=gz, src=dsz[1], c=c: gz[:, :c].copy_(src))
+        ops.gemm_nt(gz, W["s2t"], dcols)
+        ops.col2im3x3(dcols, dsa[0], b, H1, H1, 1)
+        self.sbn[0].bwd(dsa[0], sa[0], sz[0], dsz[0])
+        self._reduce(b).run()
+
+    def _reduce(self, b: int) -> "ops.ReducePlan":
+        if b not in self.rn_plans:
+            v = self.cfg.vision
+            ent = []
+            for blk in self.blocks:
+                for site, H in blk.loras():
+                    ent += site.reduce_entries(b * H * H)
+            for n in "qkvc":
+                ent += self.ap[n].reduce_entries(b * v.tokens)
+            self.rn_plans[b] = ops.ReducePlan(ent, self.device)
+        return self.rn_plans[b]
+
+    # -------------------------------------------------------------------- API --
+    def _step_body(self, b: int, S: int, has_attr: bool) -> None:
+        self.bn_training = True                                   # model.train(): batch statistics, running stats move
+        try:
+            super()._step_body(b, S, has_attr)
+        finally:
+            self.bn_training = False
+
+    def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:
+        out = super().forward_backward(image, attr, label)
+        self.bn_steps += 1
+        return out
+
+
+def create_engine(cfg, state_dict, **kw) -> FairLoRAEngine:
+    """The engine class for cfg's image tower (MODEL.BACKBONE.NAME: ViT-B/16 or RN50)."""
+    cls = RN50Engine if hasattr(cfg.vision, "embed_dim") else FairLoRAEngine
+    return cls(cfg, state_dict, **kw)
