@@ -220,8 +220,6 @@ class RN50Engine(FairLoRAEngine):
         self.bns: List[_BN] = []
         self.bn_scratch = self.bn_cmax = self.cols_elems = 0
         self.bn_training = False
-        self.bn_steps = 0
-        self.nbt0: Dict[str, int] = {}
         e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)
         w, H1 = v.width, v.image_size // 2
         R1 = max_images * H1 * H1
@@ -264,6 +262,8 @@ class RN50Engine(FairLoRAEngine):
         self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
         self.bn_k12 = torch.zeros(2 * self.bn_cmax, device=dev, dtype=torch.float32)
         self.rn_plans: Dict[int, ops.ReducePlan] = {}
+        # num_batches_tracked of every BatchNorm2d, in self.bns order (one add per training step for all of them)
+        self.nbt = torch.zeros(len(self.bns), device=dev, dtype=torch.int64)
 
     def _init_vision_late(self) -> None:
         self.fused_rank = False
@@ -316,20 +316,34 @@ class RN50Engine(FairLoRAEngine):
         for bn in self.bns:
             bn.run_mean.copy_(sd[bn.prefix + "running_mean"].to(self.device, torch.float32))
             bn.run_var.copy_(sd[bn.prefix + "running_var"].to(self.device, torch.float32))
-            self.nbt0[bn.prefix] = int(sd[bn.prefix + "num_batches_tracked"])
-        self.bn_steps = 0
+        self.nbt.copy_(torch.stack([sd[bn.prefix + "num_batches_tracked"].reshape(()).to(torch.int64).cpu()
+                                    for bn in self.bns]))
 
-    def buffer_state(self) -> Dict[str, Tensor]:
+    def buffer_views(self) -> Dict[str, Tensor]:
+        """state_dict key -> the live device tensor (CustomCLIP registers these as its buffers)."""
         out = {}
-        by_prefix = {bn.prefix: bn for bn in self.bns}
+        index = {bn.prefix: i for i, bn in enumerate(self.bns)}
         for k in buffer_keys(self.cfg):
             p, name = k.rsplit(".", 1)
-            bn = by_prefix[p + "."]
-            if name == "num_batches_tracked":
-                out[k] = torch.tensor(self.nbt0[bn.prefix] + self.bn_steps, dtype=torch.int64)
-            else:
-                out[k] = (bn.run_mean if name == "running_mean" else bn.run_var).clone()
+            i = index[p + "."]
+            out[k] = self.nbt[i] if name == "num_batches_tracked" else \
+                (self.bns[i].run_mean if name == "running_mean" else self.bns[i].run_var)
         return out
+
+    def buffers_flat(self) -> Tensor:
+        """All BatchNorm buffers as one fp32 vector (means | variances | counters): the FedAvg exchange unit."""
+        return torch.cat([bn.run_mean for bn in self.bns] + [bn.run_var for bn in self.bns] + [self.nbt.float()])
+
+    def load_buffers_flat(self, t: Tensor) -> None:
+        off = 0
+        for which in ("run_mean", "run_var"):
+            for bn in self.bns:
+                getattr(bn, which).copy_(t[off:off + bn.C])
+                off += bn.C
+        self.nbt.copy_(t[off:off + len(self.bns)])                 # float -> int64 truncates, as load_state_dict does
+
+    def buffer_state(self) -> Dict[str, Tensor]:
+        return {k: v.clone() for k, v in self.buffer_views().items()}
 
     # ----------------------------------------------------------------- inputs --
     def _check_batch(self, image: Tensor) -> Tuple[int, int]:
@@ -447,7 +461,7 @@ class RN50Engine(FairLoRAEngine):
 
     def forward_backward(self, image: Tensor, attr: Optional[Tensor], label: Tensor) -> Dict[str, Tensor]:
         out = super().forward_backward(image, attr, label)
-        self.bn_steps += 1
+        self.nbt.add_(1)
         return out
 
 

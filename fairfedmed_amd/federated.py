@@ -116,7 +116,10 @@ def run_fedotplora(trainer, args: FedArgs, attribute: Optional[str] = None, log=
     # Only the trainable tensors travel: the reference averages the whole state_dict, but frozen tensors are
     # identical on every client, so their weighted mean is the tensor itself up to one rounding per round
     # (SURVEY §5 quirk 10); leaving them out also keeps the engine's packed copies of the frozen weights valid.
+    # RN50: the BatchNorm running statistics do differ between clients and are averaged with everything else.
     keys = set(trainer.engine.params.keys) if hasattr(trainer, "engine") else None
+    if keys is not None and hasattr(trainer.engine, "buffer_views"):
+        keys |= set(trainer.engine.buffer_views())
     snap = lambda: copy.deepcopy({k: v for k, v in trainer.model.state_dict().items() if keys is None or k in keys})
     global_weights = snap()
     local_weights: Dict[int, Dict[str, Tensor]] = {}
@@ -181,19 +184,33 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     lo_a, lo_b = ctx_off + args.avg_prompt * n_ctx_row, ctx_off + args.num_prompt * n_ctx_row
     s_slices = [(off, off + int(np.prod(shp))) for k, (off, shp) in offsets.items() if "lora_S" in k]
     hist = {"acc": [], "err": [], "f1": [], "auc": [], "epoch": []}
+    # RN50: the BatchNorm running statistics (buffers, not parameters) are averaged like every other state_dict
+    # entry, with the plain n_k / sum n weights; they ride in a second, small all-reduce
+    eng = trainer.engine
+    has_buf = hasattr(eng, "buffers_flat")
+    global_buf = eng.buffers_flat() if has_buf else None
+    per_client_buf = {i: global_buf.clone() for i in range(users)} if has_buf else None
     for epoch in range(args.round):
         idxs_users = select_clients(epoch, args, users)
         acc = torch.zeros_like(flat)
+        acc_buf = torch.zeros_like(global_buf) if has_buf else None
+        total = sum(n_client[int(u)] for u in idxs_users)
         local_after: Dict[int, Tensor] = {}
         for j, idx in enumerate(idxs_users):
             if j % world != rank:
                 continue
             flat.copy_(global_flat if epoch == 0 else per_client[idx])
+            if has_buf:
+                eng.load_buffers_flat(global_buf if epoch == 0 else per_client_buf[idx])
             trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
             local_after[idx] = flat.detach().clone()
             w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
             acc += w * flat
+            if has_buf:
+                acc_buf += eng.buffers_flat() * (n_client[int(idx)] / total)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        if has_buf:
+            dist.all_reduce(acc_buf, op=dist.ReduceOp.SUM)
         if args.shared_half_s:
             G, r = lo.num_groups, lo.rank
             for k, (off, shp) in offsets.items():
@@ -202,6 +219,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
                     blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
         beta_decay = 0.999 * (epoch / max(args.round, 1))
         global_flat = (1 - beta_decay) * acc + beta_decay * global_flat
+        if has_buf:
+            global_buf = (1 - beta_decay) * acc_buf + beta_decay * global_buf
         # personalisation needs every trained client's local prompts / lora_S on every rank that may test it:
         # exchange them (a few KB) with one more all-reduce of a zero-padded buffer
         keep = torch.zeros(users, flat.numel(), device=flat.device) if args.idxs_users_train else None
@@ -213,6 +232,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         results = []
         for idx in all_users:
             per_client[idx] = global_flat.clone()
+            if has_buf:
+                per_client_buf[idx] = global_buf
             if idx in args.idxs_users_train and keep is not None:
                 per_client[idx][lo_a:lo_b] = keep[idx][lo_a:lo_b]
                 if args.local_s:
@@ -222,6 +243,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
             if j % world != rank:
                 continue
             flat.copy_(per_client[idx])
+            if has_buf:
+                eng.load_buffers_flat(per_client_buf[idx])
             results.append((idx, trainer.test(idx=idx, current_epoch=epoch)))
         gathered = [None] * world
         dist.all_gather_object(gathered, results)
@@ -235,6 +258,9 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
             log(f"round {epoch}: acc {hist['acc'][-1]:.3f} f1 {hist['f1'][-1]:.3f}"
                 + (f" auc {hist['auc'][-1]:.4f}" if hist["auc"] else ""))
     flat.copy_(global_flat)
+    if has_buf:
+        eng.load_buffers_flat(global_buf)
+        hist["global_buffers"] = global_buf
     trainer.fed_after_train()
     hist["global_flat"] = global_flat
     return hist

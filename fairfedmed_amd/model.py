@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import ops
 from .config import ModelCfg
 from .engine import FairLoRAEngine
-from .synth import lora_s_init, manifest, trainable_keys
+from .synth import buffer_keys, lora_s_init, manifest, trainable_keys
 
 Tensor = torch.Tensor
 
@@ -52,15 +52,20 @@ class CustomCLIP(nn.Module):
                  device: str = "cuda:0"):
         super().__init__()
         self.cfg = cfg
-        self.engine = FairLoRAEngine(cfg, state_dict, dtype=dtype, max_images=max_images, device=device)
+        from .engine_rn import create_engine
+        self.engine = create_engine(cfg, state_dict, dtype=dtype, max_images=max_images, device=device)
         train = set(trainable_keys(cfg))
         dev = self.engine.device
+        # RN50: BatchNorm running statistics are buffers that training changes; they alias the engine's tensors
+        live = self.engine.buffer_views() if hasattr(self.engine, "buffer_views") else {}
         for key, shape in manifest(cfg).items():
             if key in train:
                 t = self.engine.params.view(key)                   # view of the flat fp32 buffer
+            elif key in live:
+                t = live[key]
             else:
                 t = state_dict[key].detach().to(dev, torch.float32).reshape(shape).clone()
-            _register(self, key, t, key in train, buffer=key.startswith("prompt_learner.token_"))
+            _register(self, key, t, key in train, buffer=key.startswith("prompt_learner.token_") or key in live)
         for key in train:                                          # .grad = view of the flat grad buffer
             self.get_parameter(key).grad = self.engine.params.view(key, "grad")
 
@@ -74,7 +79,7 @@ class CustomCLIP(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         res = super().load_state_dict(state_dict, strict=strict, assign=False)
-        train = set(self.engine.params.keys)
+        train = set(self.engine.params.keys) | set(buffer_keys(self.cfg))   # live tensors: nothing to rebuild
         if any(k not in train for k in state_dict):
             # frozen tensors may have changed: rebuild their compute-dtype copies (W and W^T)
             self.engine.load_frozen(self.state_dict())
@@ -247,16 +252,28 @@ class LoRALinear(nn.Module):
 
 def apply_lora_to_model(model: nn.Module, unfreeze_image_encoder: bool, rank: int = 4, alpha: float = 0.04,
                         lora_type: str = "FairLoRA", global_s: bool = False, num_attrs: int = 1) -> None:
-    """ViT rule of the reference (trainers/GLP_OT_SVLoRA.py:512-540): wrap every nn.Linear whose
-    qualified name starts with 'image_encoder.' and contains '.mlp.'."""
+    """The reference's injection rules (trainers/GLP_OT_SVLoRA.py:503-573) for modules under 'image_encoder.':
+    ViT - every nn.Linear whose name contains '.mlp.' becomes a FairLoRALinear; ResNet - every 1x1 nn.Conv2d named
+    '*conv*' under 'layer*' becomes a FairLoRALinear (downsample.0 is not named conv and stays), every nn.Linear
+    of 'attnpool' a plain LoRALinear."""
     if lora_type != "FairLoRA":
         raise NotImplementedError(lora_type)
     for name, module in dict(model.named_modules()).items():
-        if unfreeze_image_encoder and name.startswith("image_encoder.") and isinstance(module, nn.Linear) \
-                and ".mlp." in name:
-            parent = model
-            parts = name.split(".")
-            for p in parts[:-1]:
-                parent = getattr(parent, p)
-            setattr(parent, parts[-1], FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s,
-                                                      num_attrs=num_attrs))
+        if not (unfreeze_image_encoder and name.startswith("image_encoder.")):
+            continue
+        if isinstance(module, nn.Linear) and ".mlp." in name:
+            new = FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s, num_attrs=num_attrs)
+        elif name.startswith("image_encoder.layer") or name.startswith("image_encoder.attnpool"):
+            if "attnpool" in name and isinstance(module, nn.Linear):
+                new = LoRALinear(module, rank=rank, alpha=alpha)
+            elif isinstance(module, nn.Conv2d) and "conv" in name and tuple(module.weight.shape[-2:]) == (1, 1):
+                new = FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s, num_attrs=num_attrs)
+            else:
+                continue
+        else:
+            continue
+        parent = model
+        parts = name.split(".")
+        for p in parts[:-1]:
+            parent = getattr(parent, p)
+        setattr(parent, parts[-1], new)

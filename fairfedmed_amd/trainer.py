@@ -138,7 +138,9 @@ class GLP_OT_SVLoRA:
             eot = tuple(KNOWN_EOT[n.replace("_", " ")] for n in names)
         except KeyError as e:
             raise NotImplementedError(f"EOT position of class prompt {e} is not pinned (tokenizer is out of scope)")
-        base = C.vit_b16() if cfg.MODEL.BACKBONE.NAME in ("ViT-B/16", "vit_b16") else getattr(cfg.MODEL, "GEOMETRY")
+        name = cfg.MODEL.BACKBONE.NAME
+        base = C.vit_b16() if name in ("ViT-B/16", "vit_b16") else C.rn50() if name in ("RN50", "rn50") \
+            else getattr(cfg.MODEL, "GEOMETRY")
         # 3D modalities go through the trainable per-slice conv (trainers/GLP_OT_SVLoRA.py:584-586)
         is_3d = getattr(cfg.DATASET, "MODALITY_TYPE", "slo_fundus") in MODALITIES_3D
         return C.ModelCfg(vision=base.vision, text=base.text,

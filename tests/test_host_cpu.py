@@ -114,3 +114,54 @@ def test_fairness_scores_vs_reference(golden_dir):
     assert abs(Mx.demographic_parity_difference(lab, pred, att) - (0.5 - 0.25)) < 1e-12
     # TPR: g0 1/2, g1 1/2 -> gap 0; FPR: g0 1/2, g1 0 -> gap 0.5
     assert abs(Mx.equalized_odds_difference(lab, pred, att) - 0.5) < 1e-12
+
+
+def test_apply_lora_resnet_rule():
+    """ResNet branch of apply_lora_to_model (trainers/GLP_OT_SVLoRA.py:541-573): 1x1 convolutions named conv* under
+    image_encoder.layer* become FairLoRALinear, attnpool's nn.Linear plain LoRALinear; 3x3 convolutions, downsample.0
+    and everything outside image_encoder stay."""
+    import torch.nn as nn
+    from fairfedmed_amd.model import FairLoRALinear, LoRALinear, apply_lora_to_model
+
+    class Neck(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.conv2, self.conv3 = nn.Conv2d(64, 64, 1, bias=False), nn.Conv2d(64, 64, 3, bias=False), \
+                nn.Conv2d(64, 256, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.downsample = nn.Sequential(nn.AvgPool2d(1), nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+
+    class Pool(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.k_proj, self.q_proj, self.v_proj, self.c_proj = (nn.Linear(128, 128), nn.Linear(128, 128),
+                                                                  nn.Linear(128, 128), nn.Linear(128, 64))
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 32, 3, bias=False)
+            self.layer1 = nn.Sequential(Neck())
+            self.attnpool = Pool()
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.image_encoder = Enc()
+            self.text_encoder = nn.Sequential(nn.Linear(8, 8))
+
+    m = Model()
+    apply_lora_to_model(m, True, rank=4, alpha=2.0, lora_type="FairLoRA", num_attrs=2)
+    neck = m.image_encoder.layer1[0]
+    assert isinstance(neck.conv1, FairLoRALinear) and isinstance(neck.conv3, FairLoRALinear)
+    assert tuple(neck.conv1.lora_S.weight.shape) == (2, 4) and tuple(neck.conv3.lora_B.weight.shape) == (4, 256)
+    assert isinstance(neck.conv2, nn.Conv2d) and isinstance(neck.downsample[1], nn.Conv2d)
+    assert isinstance(m.image_encoder.conv1, nn.Conv2d)
+    for n in "kqvc":
+        assert isinstance(getattr(m.image_encoder.attnpool, n + "_proj"), LoRALinear)
+    assert isinstance(m.text_encoder[0], nn.Linear)
+    names = {k for k, p in m.named_parameters() if "lora_" in k}
+    assert len(names) == 2 * 3 + 4 * 2
+    m2 = Model()
+    apply_lora_to_model(m2, False, rank=4, alpha=2.0, lora_type="FairLoRA", num_attrs=2)
+    assert not any("lora_" in k for k, _ in m2.named_parameters())

@@ -249,3 +249,101 @@ def test_federated_round_loop_single_process_and_ranks_agree():
         got = hist2["global_flat"][off:off + v.numel()].view(shp).cpu()
         assert rel(got, v.cpu()) < 1e-5, k
     assert abs(hist["acc"][-1] - hist2["acc"][-1]) < 1e-6
+
+
+# ----------------------------------------------------------------------------- RN50 backbone
+def rn_cfg(bs=6):
+    cfg = make_cfg(bs=bs)
+    cfg.DATASET.ATTRIBUTES, cfg.DATASET.ATTRIBUTE_TYPE = ["gender"], "gender"        # two groups, as the golden model
+    cfg.MODEL.GEOMETRY = C.rn_tiny(rank=4, num_groups=2)
+    return cfg
+
+
+def test_trainer_rn_backbone_trajectory(golden_dir):
+    """The registry-built trainer picks the RN50 engine for a ResNet geometry; its steps follow the reference's
+    forward_backward trajectory and state_dict() carries the live BatchNorm buffers."""
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.engine_rn import RN50Engine
+    from fairfedmed_amd.trainer import SyntheticFedData, _ListDataset, _Loader
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    gold = np.load(os.path.join(golden_dir, "rn_tiny.npz"))
+    mcfg = C.rn_tiny(rank=4, num_groups=2)
+    cfg = rn_cfg()
+    data = SyntheticFedData(mcfg, 1, 1, 1, 6)
+    batch = synth.make_batch(mcfg, 6, seed=1234)
+    data.fed_train_loader_x_dict[0] = _Loader(_ListDataset([batch], ["gender"], {"gender": 2}))
+    cfg.DATA = data
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    tr = build_trainer(cfg)
+    assert isinstance(tr.engine, RN50Engine)
+    image, label, _, attr = tr.parse_batch_train(batch)
+    tr.engine.forward_backward(image, attr, label)        # the golden script's gradient pass: one BatchNorm update
+    tr.num_batches = 10 ** 9
+    for i, ref in enumerate(meta["rn_tiny_r4g2.traj"]):
+        tr.batch_idx = i
+        s = tr.forward_backward(batch)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (s, ref)
+        assert abs(s["acc"] - ref["acc"]) < 1e-3 and abs(s["auc"] - ref["auc"]) < 1e-9
+    sd = tr.model.state_dict()
+    for k in synth.buffer_keys(mcfg):
+        ref = torch.from_numpy(gold[f"rn_tiny_r4g2.post.{k}"]).double()
+        assert float((sd[k].cpu().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, k
+    # buffers round-trip through load_state_dict without rebuilding the frozen weights
+    before = tr.engine.rnw["s1"].data_ptr()
+    zero = {k: torch.zeros_like(v) for k, v in sd.items() if k.endswith(("running_mean", "num_batches_tracked"))}
+    tr.model.load_state_dict(zero, strict=False)
+    assert float(tr.engine.bns[0].run_mean.abs().max()) == 0.0 and int(tr.engine.nbt.sum()) == 0
+    assert tr.engine.rnw["s1"].data_ptr() == before
+
+
+def test_federated_rn_backbone_averages_batchnorm_buffers():
+    """Two clients, two rounds on the RN backbone: the BatchNorm running statistics travel with the trainable
+    tensors (the reference averages the whole state_dict), one-process and torch.distributed drivers agree."""
+    import torch.distributed as dist
+    from fairfedmed_amd import federated as F
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData
+    mcfg = C.rn_tiny(rank=4, num_groups=2)
+
+    def setup():
+        cfg = rn_cfg()
+        cfg.DATASET.USERS = 2
+        cfg.TEST.NO_TEST = True
+        cfg.TRAIN.METRICS_EVERY = 0
+        cfg.DATA = SyntheticFedData(mcfg, 2, 2, 1, 6, attribute="gender", signal=0.3)
+        cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+        return build_trainer(cfg)
+
+    args = F.FedArgs(num_users=2, frac=1.0, round=2, shared_half_s=True, seed=0)
+    tr = setup()
+    hist = F.run_fedotplora(tr, args, log=lambda *_: None)
+    gw = hist["global_weights"]
+    bkeys = synth.buffer_keys(mcfg)
+    assert all(k in gw for k in bkeys)
+    k0 = "image_encoder.bn1.running_mean"
+    assert float(gw[k0].abs().max()) > 0                          # synthetic init is 0 mean / 1 var: it moved
+    # counters too (as floats, as in the reference): round 0 averages 2 and 2, round 1 averages 4 and 4 and mixes the
+    # previous global 2 back in with beta = 0.999 * 1/2
+    assert abs(float(gw["image_encoder.bn1.num_batches_tracked"]) - (4 * (1 - 0.4995) + 2 * 0.4995)) < 1e-5
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        tr2 = setup()
+        hist2 = F.run_fedotplora_ranks(tr2, args, log=lambda *_: None)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    params = tr2.engine.params
+    for k, v in gw.items():
+        if k in params.offsets:
+            off, shp = params.offsets[k]
+            got = hist2["global_flat"][off:off + v.numel()].view(shp).cpu()
+            assert rel(got, v.cpu()) < 1e-5, k
+    live = tr2.engine.buffer_state()                               # loaded from hist2["global_buffers"] at the end
+    for k in bkeys:
+        if not k.endswith("num_batches_tracked"):
+            assert rel(live[k].cpu(), gw[k].cpu()) < 1e-5, k
+    assert abs(hist["acc"][-1] - hist2["acc"][-1]) < 1e-6
