@@ -117,43 +117,88 @@ __global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dc
     }
 }
 
-// ---- column sums over the rows: part[blk][0][c] = sum a, part[blk][1][c] = sum a*b   (block = 64 channels x 4 row lanes)
+// ---- column sums over the rows: part[blk][0][c] = sum a, part[blk][1][c] = sum a*b
 //  MODE 0: a = x, b = x                                (BatchNorm statistics)
 //  MODE 1: a = g, b = g * xhat, g = dy * (y > 0 if mask) (BatchNorm backward)
-constexpr int CS_ROWS = 512;     // rows per block
+// A block owns rows [blk*rpb, (blk+1)*rpb) and up to 256 16-byte channel chunks: min(C/VN, 256) threads lie along a
+// row (coalesced 16-byte loads), the remaining threads are row lanes; the row lanes are combined through LDS.
+constexpr int CS_MAXBLK = 1024;  // upper bound of the partial rows (the finalize kernels sum them 8 lanes per channel)
+constexpr int CS_MINROWS = 64;
+inline int cs_blocks(int rows) {
+    const int n = (rows + CS_MINROWS - 1) / CS_MINROWS;
+    return n < 1 ? 1 : (n > CS_MAXBLK ? CS_MAXBLK : n);
+}
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, const T* __restrict__ p1,
                                                      const T* __restrict__ mask, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ part, int rows,
-                                                     int C) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + cl;
-    const int r0 = blockIdx.x * CS_ROWS, r1 = (r0 + CS_ROWS) < rows ? (r0 + CS_ROWS) : rows;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-        const float mu = MODE == 1 ? mean[c] : 0.f, rs = MODE == 1 ? rstd[c] : 0.f;
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const size_t o = (size_t)r * C + c;
+                                                     int C, int rpb) {
+    constexpr int VN = VecC<T>::N;
+    __shared__ float red[2][256][VN + 1];
+    const int cc = C / VN;
+    const int tpr = cc < 256 ? cc : 256, nrl = 256 / tpr;
+    const int chl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+    const int ch = blockIdx.y * 256 + chl;
+    const int r0 = blockIdx.x * rpb, r1 = (r0 + rpb) < rows ? (r0 + rpb) : rows;
+    float s0[VN], s1[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) s0[e] = s1[e] = 0.f;
+    if (rl < nrl && ch < cc) {
+        float mu[VN], rs[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            mu[e] = MODE == 1 ? mean[ch * VN + e] : 0.f;
+            rs[e] = MODE == 1 ? rstd[ch * VN + e] : 0.f;
+        }
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += nrl) {
+            const size_t o = (size_t)r * C + (size_t)ch * VN;
+            float a[VN];
+            VecC<T>::load(p0 + o, a);
             if (MODE == 0) {
-                const float v = Elem<T>::to_f(p0[o]);
-                s0 += v;
-                s1 += v * v;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) { s0[e] += a[e]; s1[e] += a[e] * a[e]; }
             } else {
-                float g = Elem<T>::to_f(p0[o]);
-                if (mask && !(Elem<T>::to_f(mask[o]) > 0.f)) g = 0.f;
-                s0 += g;
-                s1 += g * (Elem<T>::to_f(p1[o]) - mu) * rs;
+                float xv[VN], m[VN];
+                VecC<T>::load(p1 + o, xv);
+                if (mask) VecC<T>::load(mask + o, m);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    const float g = (mask && !(m[e] > 0.f)) ? 0.f : a[e];
+                    s0[e] += g;
+                    s1[e] += g * (xv[e] - mu[e]) * rs[e];
+                }
             }
         }
     }
-    red[0][rl][cl] = s0;
-    red[1][rl][cl] = s1;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        part[((size_t)blockIdx.x * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        part[((size_t)blockIdx.x * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    for (int i = threadIdx.x; i < tpr * VN; i += 256) {
+        const int cl = i / VN, e = i % VN;
+        if (blockIdx.y * 256 + cl >= cc) continue;
+        float t0 = 0.f, t1 = 0.f;
+        for (int l = 0; l < nrl; ++l) { t0 += red[0][l * tpr + cl][e]; t1 += red[1][l * tpr + cl][e]; }
+        const int c = (blockIdx.y * 256 + cl) * VN + e;
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = t0;
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = t1;
     }
+}
+
+// sum of the nblk partial rows of channel c, CS_FL adjacent lanes per channel (block = 256 / CS_FL channels)
+constexpr int CS_FL = 16;
+__device__ __forceinline__ void cs_total(const float* __restrict__ part, int nblk, int C, int c, double& s, double& q) {
+    const int lane = threadIdx.x & (CS_FL - 1);
+    s = q = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = lane; b < nblk; b += CS_FL) {
+            s += part[((size_t)b * 2) * C + c];
+            q += part[((size_t)b * 2 + 1) * C + c];
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < CS_FL; d <<= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
 }
 
 // mean / rstd of the batch (biased variance, eps 1e-5) + running statistics update (unbiased variance, momentum)
@@ -161,10 +206,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    const int c = blockIdx.x * (256 / CS_FL) + threadIdx.x / CS_FL;
+    double s, q;
+    cs_total(part, nblk, C, c, s, q);
+    if (c >= C || (threadIdx.x & (CS_FL - 1))) return;
     const double mu = s / rows;
     double var = q / rows - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -214,10 +259,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int C,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ k12) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    const int c = blockIdx.x * (256 / CS_FL) + threadIdx.x / CS_FL;
+    double s, q;
+    cs_total(part, nblk, C, c, s, q);
+    if (c >= C || (threadIdx.x & (CS_FL - 1))) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     k12[c] = (float)(s / rows);
@@ -418,7 +463,7 @@ extern "C" int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, i
     return FFM_OK;
 }
 
-extern "C" int ffm_bn_blocks(int rows) { return (rows + CS_ROWS - 1) / CS_ROWS; }
+extern "C" int ffm_bn_blocks(int rows) { return cs_blocks(rows); }
 
 extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
                           float* mean, float* rstd, float* part, const void* res, void* y, int rows, int C, int training,
@@ -427,13 +472,13 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
     if (C % (dtype == FFM_BF16 ? 8 : 4) || (training && !part)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (training) {
-        const int nblk = ffm_bn_blocks(rows);
-        dim3 g(nblk, (C + 63) / 64);
+        const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
+        dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
         DISPATCH_T(dtype,
-                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C),
-                   hipLaunchKernelGGL((colsum_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C))
+                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb),
+                   hipLaunchKernelGGL((colsum_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb))
         FFM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
                            run_var, 0.1f, 1e-5f);
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, run_var, mean, rstd, C, 1e-5f);
@@ -454,13 +499,13 @@ extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, c
         return FFM_EINVAL;
     if (C % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = ffm_bn_blocks(rows);
-    dim3 g(nblk, (C + 63) / 64);
+    const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
+    dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C),
-               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C))
+               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb),
+               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb))
     FFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();
     const int g2 = grid1d((size_t)rows * C / 4);
     DISPATCH_T(dtype,

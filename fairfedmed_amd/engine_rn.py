@@ -39,7 +39,22 @@ class _Lora:
         self.t, self.ts, self.u, self.us = f(max_rows, r), f(max_rows, r), f(max_rows, r), f(max_rows, r)
         ns = ops.lora_grad_splits(max_rows)
         self.pA, self.pB = f(ns * K * r), f(ns * N * r)
-        self.pS = f(ops.lora_down_blocks(max_rows, N, r, dt) * lo.num_groups * r) if fair else None
+        # rank <= 16: the down projections ride inside the GEMMs (FFM_EPI_RANKOP); their operands are the LoRA
+        # matrices re-packed to [16, K] in the compute dtype once per step (one launch for all sites)
+        self.fused = 0 < r <= 16
+        nb = ops.lora_down_blocks(max_rows, N, r, dt)
+        if self.fused:
+            nb = max(nb, self._tiles(max_rows))
+            self.rkA = torch.zeros(16, K, device=eng.device, dtype=dt)
+            self.rkB = torch.zeros(16, N, device=eng.device, dtype=dt)
+            eng.pack_entries += [(eng.params.view(self.kA), False, self.rkA), (eng.params.view(self.kB), True, self.rkB)]
+        self.pS = f(nb * lo.num_groups * r) if fair else None
+
+    def _tiles(self, rows: int) -> int:
+        """dS partial rows the dX GEMM (M = rows, N = in features, K = out features) writes."""
+        from . import _lib as L
+        return ops.gemm_tiles_m(rows, self.K, self.N, L.EPI_LORA | L.EPI_LORA_KR | L.EPI_RANKOP, self.eng.cfg.lora.rank,
+                                self.eng.dtype, False)
 
     def _s(self) -> Tuple[Tensor, int]:
         e = self.eng
@@ -49,7 +64,12 @@ class _Lora:
         e, lo = self.eng, self.eng.cfg.lora
         rows = x.shape[0]
         S, G = self._s()
-        ops.lora_down(x, e.params.view(self.kA), False, S, attr if self.fair else None, lo.rank, G, rps, lo.scaling,
+        attr = attr if self.fair else None
+        if self.fused:
+            ro = ops.RankOp(self.rkA, S, attr, rps, lo.scaling, lo.lambda_group, t_out=self.t[:rows], ts_out=self.ts[:rows])
+            ops.gemm_nt(x, W, out, bias=bias, lw=e.params.view(self.kB), res=res, rankop=ro)
+            return
+        ops.lora_down(x, e.params.view(self.kA), False, S, attr, lo.rank, G, rps, lo.scaling,
                       lo.lambda_group, self.t[:rows], self.ts[:rows])
         ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res)
 
@@ -58,9 +78,15 @@ class _Lora:
         e, lo = self.eng, self.eng.cfg.lora
         rows = g.shape[0]
         S, G = self._s()
-        ops.lora_down(g, e.params.view(self.kB), True, S, attr if self.fair else None, lo.rank, G, rps, lo.scaling,
-                      lo.lambda_group, self.u[:rows], self.us[:rows], self.t[:rows] if self.fair else None, self.pS)
-        ops.gemm_nt(g, Wt, dx, ts=self.us[:rows], lw=e.params.view(self.kA), lw_is_kr=True, res=res)
+        attr = attr if self.fair else None
+        if self.fused:
+            ro = ops.RankOp(self.rkB, S, attr, rps, lo.scaling, lo.lambda_group, ts_out=self.us[:rows],
+                            t_fwd=self.t[:rows] if self.fair else None, ds_part=self.pS)
+            ops.gemm_nt(g, Wt, dx, lw=e.params.view(self.kA), lw_is_kr=True, res=res, rankop=ro)
+        else:
+            ops.lora_down(g, e.params.view(self.kB), True, S, attr, lo.rank, G, rps, lo.scaling,
+                          lo.lambda_group, self.u[:rows], self.us[:rows], self.t[:rows] if self.fair else None, self.pS)
+            ops.gemm_nt(g, Wt, dx, ts=self.us[:rows], lw=e.params.view(self.kA), lw_is_kr=True, res=res)
         ops.lora_grad_partial(g, self.ts[:rows], lo.rank, self.pB)
         ops.lora_grad_partial(x, self.us[:rows], lo.rank, self.pA)
 
@@ -70,7 +96,8 @@ class _Lora:
         gv = lambda k: e.params.view(k, "grad")
         ent = [(self.pB, nsp, self.N * r, gv(self.kB), self.N, r), (self.pA, nsp, self.K * r, gv(self.kA), 0, 0)]
         if self.fair:
-            ent.append((self.pS, ops.lora_down_blocks(rows, self.N, r, e.dtype), lo.num_groups * r, gv(self.kS), 0, 0))
+            nb = self._tiles(rows) if self.fused else ops.lora_down_blocks(rows, self.N, r, e.dtype)
+            ent.append((self.pS, nb, lo.num_groups * r, gv(self.kS), 0, 0))
         return ent
 
 
@@ -220,6 +247,7 @@ class RN50Engine(FairLoRAEngine):
         self.bns: List[_BN] = []
         self.bn_scratch = self.bn_cmax = self.cols_elems = 0
         self.bn_training = False
+        self.pack_entries: list = []
         e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)
         w, H1 = v.width, v.image_size // 2
         R1 = max_images * H1 * H1
@@ -266,7 +294,8 @@ class RN50Engine(FairLoRAEngine):
         self.nbt = torch.zeros(len(self.bns), device=dev, dtype=torch.int64)
 
     def _init_vision_late(self) -> None:
-        self.fused_rank = False
+        self.fused_rank = 0 < self.cfg.lora.rank <= 16
+        self.pack_plan = ops.PackPlan(self.pack_entries, self.dtype, self.device) if self.fused_rank else None
 
     def _n_layer_events(self) -> int:
         return 1
@@ -374,6 +403,8 @@ class RN50Engine(FairLoRAEngine):
         r1 = b * H1 * H1
         a32 = self.attr_i32[:b] if has_attr else None
         sz, sa = [t[:r1] for t in self.sz], [t[:r1] for t in self.sa]
+        if self.pack_plan is not None:
+            self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
         ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0])
         self.sbn[0].fwd(sz[0], sa[0], True)
         for i, wn in ((1, "s2"), (2, "s3")):

@@ -56,13 +56,13 @@ def test_rn_step_vs_oracle_and_golden(golden_dir, dtype):
     out = eng.forward_backward(img, attr, label)
     torch.cuda.synchronize()
     f32 = dtype == torch.float32
-    assert rel(out["logits"], gold[f"{TAG}.logits"]) < (1e-5 if f32 else 0.15)
+    assert rel(out["logits"], gold[f"{TAG}.logits"]) < (3e-5 if f32 else 0.15)
     l0 = meta[f"{TAG}.loss0"]
     assert abs(float(out["loss"]) - l0) <= (1e-5 if f32 else 5e-2) * abs(l0)
     assert int(out["finite"]) == 1
     ref_sd = copy.deepcopy(sd)
     loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
-    assert rel(out["logits"], logits) < (1e-5 if f32 else 0.15)
+    assert rel(out["logits"], logits) < (3e-5 if f32 else 0.15)
     worst, wcos = 0.0, 1.0
     for k in keys:
         g, ref = eng.params.view(k, "grad"), grads[k]

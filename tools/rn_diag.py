@@ -1,7 +1,7 @@
 """Per-tensor gradient error of the RN engine against the oracle (diagnostic)."""
 import copy, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from fairfedmed_amd import config as C, synth
 from fairfedmed_amd.engine_rn import create_engine
 from oracle import fairlora_oracle as O

@@ -1,7 +1,7 @@
 """bf16 RN engine against the fp32 RN engine at a chosen image size / batch (conditioning of BatchNorm statistics)."""
 import dataclasses, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from fairfedmed_amd import config as C, synth
 from fairfedmed_amd.engine_rn import create_engine
 
