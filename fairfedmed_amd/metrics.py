@@ -126,3 +126,64 @@ def comprehensive_scores(prob: np.ndarray, label: np.ndarray, attrs: np.ndarray)
         out["dpds"].append(demographic_parity_difference(label, pred, a))
         out["eods"].append(equalized_odds_difference(label, pred, a))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The same scores from the integer counts of ffm_eval_counts (include/ffm_hip.h): rows = groups 0..G-1, unknown
+# (attribute -1), all samples; columns n_pos n_neg win1 tie1 win0 tie0 TP FP TN FN.  Host arithmetic on ~100
+# integers; the pass over the samples ran on the GPU.
+# ------------------------------------------------------------------------------------------------------------
+N_POS, N_NEG, WIN1, TIE1, WIN0, TIE0, TP, FP, TN, FN = range(10)
+
+
+def _auc_from_row(r) -> float:
+    """auc_macro_ovr of the samples behind one count row (1.0 for a single-class set, as above)."""
+    n1, n0 = int(r[N_POS]), int(r[N_NEG])
+    if n1 == 0 or n0 == 0:
+        return 1.0
+    a1 = (int(r[WIN1]) + 0.5 * int(r[TIE1])) / (n1 * n0)
+    a0 = (int(r[WIN0]) + 0.5 * int(r[TIE0])) / (n1 * n0)
+    return float(np.mean([a0, a1]))
+
+
+def _rates_from_row(r):
+    tp, fp, tn, fn = (int(r[k]) for k in (TP, FP, TN, FN))
+    n = tp + fp + tn + fn
+    sel = (tp + fp) / n if n else 0.0
+    tpr = tp / (tp + fn) if (tp + fn) else 0.0
+    fpr = fp / (fp + tn) if (fp + tn) else 0.0
+    return sel, tpr, fpr
+
+
+def basic_from_counts(counts: np.ndarray):
+    """[accuracy %, error %, macro-F1 %, AUC] of SimpleTrainer.test from the 'all' row."""
+    r = np.asarray(counts)[-1]
+    tp, fp, tn, fn = (int(r[k]) for k in (TP, FP, TN, FN))
+    n = tp + fp + tn + fn
+    acc = 100.0 * (tp + tn) / n
+    f = []
+    for a, b, c in ((tn, fn, fp), (tp, fp, fn)):                  # class 0: tp' = TN, fp' = FN, fn' = FP; class 1
+        d = 2 * a + b + c
+        f.append(0.0 if d == 0 else 2 * a / d)
+    return [acc, 100.0 - acc, 100.0 * float(np.mean(f)), _auc_from_row(r)]
+
+
+def comprehensive_scores_from_counts(counts_by_attr) -> dict:
+    """comprehensive_scores() from one count table per attribute column."""
+    tables = [np.asarray(c) for c in counts_by_attr]
+    overall = _auc_from_row(tables[0][-1])
+    out = {"overall_auc": overall, "esaucs_by_attrs": [], "aucs_by_attrs": [], "dpds": [], "eods": [],
+           "between_group_disparity": []}
+    for t in tables:
+        groups, unknown = t[:-2], t[-2]
+        present = [g for g in groups if int(g[N_POS]) + int(g[N_NEG]) > 0]
+        ga = np.array([_auc_from_row(g) for g in present])
+        out["aucs_by_attrs"].append(ga)
+        out["esaucs_by_attrs"].append(float(overall / (np.abs(ga - overall).sum() + 1.0)))
+        out["between_group_disparity"].append(between_group_disparity(ga, overall))
+        rows = ([unknown] if int(unknown[N_POS]) + int(unknown[N_NEG]) > 0 else []) + present   # -1 is a group here
+        r = [_rates_from_row(g) for g in rows]
+        sel, tpr, fpr = [x[0] for x in r], [x[1] for x in r], [x[2] for x in r]
+        out["dpds"].append(float(max(sel) - min(sel)))
+        out["eods"].append(float(max(max(tpr) - min(tpr), max(fpr) - min(fpr))))
+    return out

@@ -328,6 +328,22 @@ def attnpool_tokens(inp: Tensor, pos: Optional[Tensor], out: Tensor, B: int, HW:
           L.dtype_code(inp.dtype), L.stream_ptr())
 
 
+EVAL_SLOTS = 10
+
+
+def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups: int) -> Tensor:
+    """Integer counts behind every score of the binary-task evaluator (ffm_eval_counts): int64 [(G + 2), 10] on the
+    device (rows: groups 0..G-1, unknown, all)."""
+    _dev(prob, label, attr)
+    N = prob.shape[0]
+    assert prob.dtype == torch.float32 and prob.dim() == 2 and prob.shape[1] == 2 and prob.is_contiguous()
+    assert label.dtype == torch.int64 and label.is_contiguous() and label.numel() == N
+    assert attr is None or (attr.dtype == torch.int64 and attr.is_contiguous() and attr.numel() == N)
+    out = torch.empty(num_groups + 2, EVAL_SLOTS, device=prob.device, dtype=torch.int64)
+    _call("ffm_eval_counts", L.ptr(prob), L.ptr(label), L.ptr(attr), N, num_groups, L.ptr(out), L.stream_ptr())
+    return out
+
+
 def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok: int, heads: int,
                   causal: bool = False) -> Tensor:
     _dev(qkv, out, lse)

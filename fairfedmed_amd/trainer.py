@@ -23,7 +23,9 @@ import torch
 
 from . import config as C
 from . import synth
-from .metrics import comprehensive_scores, auc_macro_ovr, macro_f1
+from . import ops
+from .metrics import (auc_macro_ovr, basic_from_counts, comprehensive_scores, comprehensive_scores_from_counts,
+                      macro_f1)
 from .model import CustomCLIP
 from .registry import TRAINER_REGISTRY
 
@@ -298,12 +300,25 @@ class GLP_OT_SVLoRA:
             probs.append(torch.softmax(logits, -1))
             labels.append(label)
             attrs_all.append(attrs)
-        prob = torch.cat(probs).cpu().numpy()
-        y = torch.cat(labels).cpu().numpy()
+        prob_d, y_d = torch.cat(probs).float().contiguous(), torch.cat(labels).contiguous()
+        attrs_d = torch.cat(attrs_all, dim=1)                                  # [n_attr, N]
+        if prob_d.shape[1] == 2 and not getattr(self.cfg.TEST, "HOST_METRICS", False):
+            # binary task: one pass over the scores on the GPU yields the integer counts every reported score is a
+            # ratio of (csrc/evalmetrics.hip); one small D2H copy per test() instead of the whole score matrix
+            G = 8                                                              # FFM_MAX_GROUPS: absent groups are skipped
+            tables = torch.stack([ops.eval_counts(prob_d, y_d, attrs_d[a].contiguous(), G)
+                                  for a in range(attrs_d.shape[0])]).cpu().numpy()
+            res = basic_from_counts(tables[0])
+            self.last_results = {"accuracy": res[0], "error_rate": res[1]}
+            if tables[0][-1][0] > 0 and tables[0][-1][1] > 0:
+                self.last_results.update(comprehensive_scores_from_counts(tables))
+            return res
+        prob = prob_d.cpu().numpy()
+        y = y_d.cpu().numpy()
         pred = prob.argmax(-1)
         acc = 100.0 * float((pred == y).mean())
         # the fairness block of Classification_oph.evaluate (evaluation/evaluator_oph.py:69-113), binary tasks
         self.last_results = {"accuracy": acc, "error_rate": 100.0 - acc}
         if prob.shape[1] == 2 and y.min() != y.max():
-            self.last_results.update(comprehensive_scores(prob, y, torch.cat(attrs_all, dim=1).cpu().numpy()))
+            self.last_results.update(comprehensive_scores(prob, y, attrs_d.cpu().numpy()))
         return [acc, 100.0 - acc, 100.0 * macro_f1(pred, y, prob.shape[1]), auc_macro_ovr(prob, y)]

@@ -301,6 +301,20 @@ int ffm_head_bwd(const void* f, const float* tbar, const float* logit_scale, con
                  int L, int D, int n_cls, int dtype, void* stream);
 
 /*
+ * Evaluator counts for binary tasks (evaluation/evaluator_oph.py:37-150; evaluation/metrics.py:197-311, 513-552;
+ * Dassl/dassl/engine/trainer.py:523-569).  prob: fp32 [N, 2] softmax scores, label: int64 [N] in {0, 1},
+ * attr: int64 [N] group ids (values outside [0, G) are "unknown"), or NULL.
+ * out: uint64 [(G + 2)][FFM_EVAL_SLOTS], zeroed by the call; row g < G = group g, row G = unknown, row G + 1 = all:
+ *   0 n_pos   1 n_neg   2 win1  3 tie1   (label-1 sample i vs label-0 sample j: p1_i > p1_j, p1_i == p1_j)
+ *   4 win0  5 tie0   (class-0 column: p0_j > p0_i, p0_j == p0_i)   6 TP  7 FP  8 TN  9 FN  (pred = p1 > p0)
+ * one-vs-rest AUC of class c = (win_c + tie_c / 2) / (n_pos * n_neg)  (== sklearn.metrics.roc_auc_score), pairs of a
+ * group row are counted among that group's samples only.  All counts are exact integers.
+ */
+#define FFM_EVAL_SLOTS 10
+int ffm_eval_counts(const float* prob, const int64_t* label, const int64_t* attr, int N, int G, uint64_t* out,
+                    void* stream);
+
+/*
  * torch.optim.SGD(momentum, weight_decay, dampening=0) over one flat fp32
  * buffer (Dassl/dassl/optim/optimizer.py:105-113): d = g + wd*p;
  * buf = first_step ? d : mu*buf + d; p -= lr*buf.

@@ -165,3 +165,53 @@ def test_apply_lora_resnet_rule():
     m2 = Model()
     apply_lora_to_model(m2, False, rank=4, alpha=2.0, lora_type="FairLoRA", num_attrs=2)
     assert not any("lora_" in k for k, _ in m2.named_parameters())
+
+
+def _brute_counts(prob, y, attr, G):
+    """The table ffm_eval_counts produces (include/ffm_hip.h), by brute force in numpy."""
+    t = np.zeros((G + 2, 10), dtype=np.int64)
+    slot = np.where((attr >= 0) & (attr < G), attr, G)
+    pred = prob[:, 1] > prob[:, 0]
+    for rows, sel in [(g, slot == g) for g in range(G + 1)] + [(G + 1, np.ones(len(y), bool))]:
+        p, yy, pr = prob[sel], y[sel], pred[sel]
+        pos, neg = p[yy == 1], p[yy == 0]
+        t[rows, 0], t[rows, 1] = len(pos), len(neg)
+        t[rows, 2] = (pos[:, None, 1] > neg[None, :, 1]).sum()
+        t[rows, 3] = (pos[:, None, 1] == neg[None, :, 1]).sum()
+        t[rows, 4] = (neg[None, :, 0] > pos[:, None, 0]).sum()
+        t[rows, 5] = (neg[None, :, 0] == pos[:, None, 0]).sum()
+        t[rows, 6], t[rows, 7] = (pr & (yy == 1)).sum(), (pr & (yy == 0)).sum()
+        t[rows, 8], t[rows, 9] = (~pr & (yy == 0)).sum(), (~pr & (yy == 1)).sum()
+    return t
+
+
+def test_scores_from_counts_equal_the_sort_based_scores():
+    """metrics.*_from_counts (fed by the on-device count kernel) == the sort / mid-rank implementations pinned against
+    the reference's evaluator, including tied scores, an unknown (-1) attribute value and an absent group."""
+    from fairfedmed_amd import metrics as M
+    rng = np.random.default_rng(5)
+    N = 400
+    logits = np.round(rng.normal(size=(N, 2)) * 2, 1)              # coarse grid: many exact ties
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    y = rng.integers(0, 2, N)
+    a0 = rng.integers(0, 3, N)
+    a1 = rng.integers(0, 2, N) * 2                                   # groups 0 and 2 only
+    a1[:7] = -1
+    attrs = np.stack([a0, a1])
+    tables = [_brute_counts(prob, y, a, 8) for a in attrs]
+    ref = M.comprehensive_scores(prob, y, attrs)
+    got = M.comprehensive_scores_from_counts(tables)
+    assert abs(got["overall_auc"] - ref["overall_auc"]) < 1e-12
+    for k in ("esaucs_by_attrs", "dpds", "eods"):
+        assert np.allclose(got[k], ref[k], rtol=0, atol=1e-12), k
+    for a, b in zip(got["aucs_by_attrs"], ref["aucs_by_attrs"]):
+        assert a.shape == b.shape and np.allclose(a, b, rtol=0, atol=1e-12)
+    assert np.allclose(got["between_group_disparity"], ref["between_group_disparity"], rtol=0, atol=1e-12)
+    pred = prob.argmax(-1)
+    acc, err, f1, auc = M.basic_from_counts(tables[0])
+    assert abs(acc - 100.0 * (pred == y).mean()) < 1e-12 and abs(err - (100 - acc)) < 1e-12
+    assert abs(f1 - 100.0 * M.macro_f1(pred, y, 2)) < 1e-12 and abs(auc - M.auc_macro_ovr(prob, y)) < 1e-12
+    # a single-class set reports AUC 1 (trainers/GLP_OT_SVLoRA.py:965-967)
+    one = _brute_counts(prob, np.ones(N, np.int64), a0, 8)
+    assert M.basic_from_counts(one)[3] == 1.0
