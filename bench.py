@@ -240,7 +240,7 @@ def main():
                 "gemm_ms_per_step": ms / args.steps,
                 "all_gemm_launches": {"launches_per_step": n_all // args.steps, "achieved": fl_all / (ms_all * 1e-3) / 1e12,
                                       "gemm_ms_per_step": ms_all / args.steps,
-                                      "note": "includes the text tower's 96 latency-bound launches on 308 rows"},
+                                      "note": "includes the text tower's 96 latency-bound launches on 40 rows (4 prompts x 10 tokens)"},
                 "measured": "HIP events around every ffm_gemm_nt launch, second pass over the same K steps with the "
                             "side streams folded into the main stream (one kernel at a time); value comes from the "
                             "un-instrumented overlapped pass"}
