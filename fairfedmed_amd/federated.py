@@ -39,6 +39,12 @@ class FedArgs:
     shared_half_s: bool = False
     local_s: bool = False                 # cfg.TRAINER.GLP_OT_LORA.LOCAL_S
     seed: Optional[int] = None            # seeds numpy's global generator like the reference's set_random_seed
+    # run_fedotplora_ranks only.  The reference trains its clients one after the other with ONE optimizer and ONE
+    # LR scheduler (federated_main.py:183): momentum buffers and the StepLR counter leak from
+    # client to client.  True reproduces that across ranks (clients of a round train in reference order, the
+    # optimizer state is handed on after each: no concurrency, for parity runs); False gives every rank its own
+    # optimizer state (clients of a round train concurrently: the throughput mode).
+    compat_sequential_optimizer: bool = False
 
 
 def average_weights_ema(w_g: Dict[str, Tensor], w: Dict[int, Dict[str, Tensor]], idxs_users: Sequence[int],
@@ -197,17 +203,25 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         total = sum(n_client[int(u)] for u in idxs_users)
         local_after: Dict[int, Tensor] = {}
         for j, idx in enumerate(idxs_users):
-            if j % world != rank:
-                continue
-            flat.copy_(global_flat if epoch == 0 else per_client[idx])
-            if has_buf:
-                eng.load_buffers_flat(global_buf if epoch == 0 else per_client_buf[idx])
-            trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
-            local_after[idx] = flat.detach().clone()
-            w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
-            acc += w * flat
-            if has_buf:
-                acc_buf += eng.buffers_flat() * (n_client[int(idx)] / total)
+            mine = j % world == rank
+            if mine:
+                flat.copy_(global_flat if epoch == 0 else per_client[idx])
+                if has_buf:
+                    eng.load_buffers_flat(global_buf if epoch == 0 else per_client_buf[idx])
+                trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
+                local_after[idx] = flat.detach().clone()
+                w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
+                acc += w * flat
+                if has_buf:
+                    acc_buf += eng.buffers_flat() * (n_client[int(idx)] / total)
+            if args.compat_sequential_optimizer and world > 1:
+                # hand the shared optimizer on: the next client (on whichever rank) starts from this one's momentum
+                # buffers, first-step flag, StepLR counter and learning rate
+                mom, scal = trainer.optimizer_state()
+                dist.broadcast(mom, src=j % world)
+                dist.broadcast(scal, src=j % world)
+                if not mine:
+                    trainer.load_optimizer_state(mom, scal)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         if has_buf:
             dist.all_reduce(acc_buf, op=dist.ReduceOp.SUM)

@@ -196,6 +196,22 @@ class GLP_OT_SVLoRA:
         s.last_epoch += 1
         self.optim.param_groups[0]["lr"] = self.optim.lr0 * s.gamma ** (s.last_epoch // s.step_size)
 
+    def optimizer_state(self):
+        """(momentum buffers fp32 [numel] on the device, [SGD steps taken, StepLR.last_epoch, lr] float64 on the same
+        device): what the reference's single shared optimizer / scheduler carries from one client to the next."""
+        p = self.engine.params
+        scal = torch.tensor([p.steps, self.sched.last_epoch, self.optim.param_groups[0]["lr"]], dtype=torch.float64,
+                            device=p.momentum.device)
+        return p.momentum, scal
+
+    def load_optimizer_state(self, momentum: torch.Tensor, scal: torch.Tensor) -> None:
+        p = self.engine.params
+        if momentum.data_ptr() != p.momentum.data_ptr():
+            p.momentum.copy_(momentum)
+        steps, last_epoch, lr = scal.cpu().tolist()
+        p.steps, self.sched.last_epoch = int(steps), int(last_epoch)
+        self.optim.param_groups[0]["lr"] = lr
+
     # ------------------------------------------------------------- batch --
     def _parse(self, batch):
         cfg = self.cfg

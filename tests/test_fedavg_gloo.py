@@ -127,6 +127,7 @@ class _FlatTrainer:
         offsets, numel = _layout(mcfg)
         flat = _flatten(_client_state(mcfg, 99, 0), offsets, numel)
         self.engine = NS(params=NS(flat=flat, offsets=offsets, keys=list(offsets)), cfg=mcfg)
+        self.mom, self.steps = torch.zeros_like(flat), 0
         self.cfg = NS(DATASET=NS(USERS=users, ATTRIBUTE_TYPE="race"))
         self.fed_train_loader_x_dict = {
             i: NS(dataset=type("D", (), {"__len__": lambda s, n=40 * (i + 1): n,
@@ -152,6 +153,21 @@ class _FlatTrainer:
     def train(self, idx, global_epoch, is_fed, is_last_client):
         f = self.engine.params.flat
         f.mul_(1.0 + 0.01 * (idx + 1)).add_(0.001 * (global_epoch + 1) * (idx + 1))
+        if self.shared_opt:
+            # a momentum-like state that outlives the client, as the reference's single optimizer does (quirk 8)
+            self.mom.mul_(0.9).add_(0.01 * (idx + 1))
+            self.steps += 1
+            f.add_(self.mom * (0.5 ** (self.steps // 4)))
+
+    shared_opt = False
+
+    def optimizer_state(self):
+        return self.mom, torch.tensor([self.steps], dtype=torch.float64)
+
+    def load_optimizer_state(self, mom, scal):
+        if mom.data_ptr() != self.mom.data_ptr():
+            self.mom.copy_(mom)
+        self.steps = int(scal[0])
 
     def test(self, idx, current_epoch):
         return [float(self.engine.params.flat.mean()), 0.0, 0.0, 0.5]
@@ -181,3 +197,39 @@ def test_round_loop_over_two_ranks_equals_the_single_process_driver():
         ref = v.reshape(-1)
         assert torch.allclose(got[0]["flat"][o:o + ref.numel()], ref, rtol=1e-5, atol=1e-7), k
     assert all(abs(a - b) < 1e-6 for a, b in zip(got[0]["acc"], hist["acc"]))
+
+
+def _compat_worker(rank, world, port, outdir, compat):
+    from fairfedmed_amd import federated as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = F.FedArgs(num_users=3, frac=0.7, round=3, shared_half_s=True, seed=5, compat_sequential_optimizer=compat)
+    tr = _FlatTrainer(3)
+    tr.shared_opt = True
+    hist = F.run_fedotplora_ranks(tr, args, log=lambda *_: None)
+    torch.save({"flat": hist["global_flat"]}, os.path.join(outdir, f"c{int(compat)}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_compat_sequential_optimizer_reproduces_the_shared_optimizer_across_ranks():
+    """with compat_sequential_optimizer the two-rank run hands the optimizer state from client
+    to client in reference order and equals the one-process (one shared optimizer) run; without it the ranks keep
+    their own optimizer state and the result differs."""
+    from fairfedmed_amd import federated as F
+    tr = _FlatTrainer(3)
+    tr.shared_opt = True
+    hist = F.run_fedotplora(tr, F.FedArgs(num_users=3, frac=0.7, round=3, shared_half_s=True, seed=5), log=lambda *_: None)
+    p = tr.engine.params
+    ref = torch.zeros_like(p.flat)
+    for k, v in hist["global_weights"].items():
+        o, s = p.offsets[k]
+        ref[o:o + v.numel()] = v.reshape(-1)
+    with tempfile.TemporaryDirectory() as d:
+        for compat in (True, False):
+            mp.spawn(_compat_worker, args=(2, _free_port(), d, compat), nprocs=2, join=True)
+        on = [torch.load(os.path.join(d, f"c1_{r}.pt"))["flat"] for r in range(2)]
+        off = [torch.load(os.path.join(d, f"c0_{r}.pt"))["flat"] for r in range(2)]
+    assert torch.equal(on[0], on[1]) and torch.equal(off[0], off[1])
+    used = ref != 0
+    assert torch.allclose(on[0][used], ref[used], rtol=1e-5, atol=1e-7)
+    assert not torch.allclose(off[0][used], ref[used], rtol=1e-3, atol=1e-5)
