@@ -205,6 +205,21 @@ def main():
         dt = float(t)
     finite = int(eng.finite)
     loss = float(eng.loss)
+    # round-boundary exchange on its own: pre-scale, ONE all-reduce of the flat trainable buffer,
+    # shared_half_s + EMA; median of 5 after the timed region, max over ranks
+    fedavg_us = None
+    if agg is not None:
+        samples = []
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            round_boundary()
+            torch.cuda.synchronize()
+            samples.append(time.perf_counter() - t1)
+        t = torch.tensor([sorted(samples)[2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fedavg_us = float(t) * 1e6
 
     roof = None
     if not args.no_roofline and rank == 0:
@@ -264,6 +279,9 @@ def main():
                        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
                        "launch": args.launch},
         }
+        if fedavg_us is not None:
+            res["config"]["fedavg_round_boundary_us"] = fedavg_us
+            res["config"]["fedavg_payload_bytes"] = eng.params.numel * 4
         if roof:
             res["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
