@@ -579,6 +579,21 @@ class FairLoRAEngine:
         self._glue(self._text_glue_back_out, stream)
 
     # ------------------------------------------------------------- vision --
+    def _as_f32(self, image: Tensor) -> Tensor:
+        """uint8 transport (fairfedmed_amd.data, transport="uint8"): expand on the GPU to the float32 batch the
+        reference's loader ships - a single SLO / X-ray channel is repeated to 3 (utils/data_utils.py:676-679)."""
+        if image.dtype != torch.uint8:
+            return image
+        if not image.is_cuda or image.dim() != 4:
+            raise TypeError("uint8 images must be CUDA tensors [B, C, H, W]")
+        b, c1 = image.shape[:2]
+        rep = 1 if self.cfg.dim_per_3d_slice else (3 // c1 if c1 in (1, 3) else 1)
+        stage = getattr(self, "_u8_stage", None)
+        shape = (b, c1 * rep) + tuple(image.shape[2:])
+        if stage is None or stage.shape[0] < b or tuple(stage.shape[1:]) != shape[1:]:
+            stage = self._u8_stage = torch.empty(shape, device=self.device, dtype=torch.float32)
+        return ops.expand_u8(image.contiguous(), stage[:b], rep)
+
     def _check_batch(self, image: Tensor) -> Tuple[int, int]:
         cfg, v = self.cfg, self.cfg.vision
         if not image.is_cuda or image.dtype != torch.float32:
@@ -596,6 +611,7 @@ class FairLoRAEngine:
     def _load_inputs(self, image: Tensor, attr: Optional[Tensor], label: Optional[Tensor]):
         """Per-step inputs -> static buffers (these three launches are the only ones not replayed)."""
         cfg, v = self.cfg, self.cfg.vision
+        image = self._as_f32(image)
         b, S = self._check_batch(image)
         images = b * S
         P = v.grid * v.grid

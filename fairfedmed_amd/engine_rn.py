@@ -388,6 +388,7 @@ class RN50Engine(FairLoRAEngine):
 
     def _load_inputs(self, image: Tensor, attr: Optional[Tensor], label: Optional[Tensor]):
         cfg = self.cfg
+        image = self._as_f32(image)
         b, S = self._check_batch(image)
         ops.stem_im2col(image.contiguous(), self.cols1[:b * self.H1 * self.H1], 2, cfg.pixel_mean, cfg.pixel_std)
         if attr is not None:

@@ -328,6 +328,16 @@ def attnpool_tokens(inp: Tensor, pos: Optional[Tensor], out: Tensor, B: int, HW:
           L.dtype_code(inp.dtype), L.stream_ptr())
 
 
+def expand_u8(src: Tensor, dst: Tensor, rep: int) -> Tensor:
+    """uint8 [B, C1, H, W] -> fp32 [B, C1*rep, H, W] with each channel repeated rep times (ffm_expand_u8)."""
+    _dev(src, dst)
+    B, C1, H, W = src.shape
+    assert src.dtype == torch.uint8 and src.is_contiguous() and dst.dtype == torch.float32 and dst.is_contiguous()
+    assert tuple(dst.shape) == (B, C1 * rep, H, W)
+    _call("ffm_expand_u8", L.ptr(src), L.ptr(dst), B, C1, H * W, rep, L.stream_ptr())
+    return dst
+
+
 EVAL_SLOTS = 10
 
 

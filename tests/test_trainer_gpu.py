@@ -347,3 +347,33 @@ def test_federated_rn_backbone_averages_batchnorm_buffers():
         if not k.endswith("num_batches_tracked"):
             assert rel(live[k].cpu(), gw[k].cpu()) < 1e-5, k
     assert abs(hist["acc"][-1] - hist2["acc"][-1]) < 1e-6
+
+
+# ----------------------------------------------------------------------------- on-disk data path
+def test_trainer_on_fairfedmed_files_uint8_equals_float32_transport(tmp_path):
+    """Two clients read from a FairFedMed tree on disk; shipping uint8 samples (expanded on the GPU) trains to exactly
+    the weights that shipping the reference's float32 batches does."""
+    from fairfedmed_amd import data as D
+    from fairfedmed_amd import federated as F
+    from fairfedmed_amd.registry import build_trainer
+    import fairfedmed_amd.trainer  # noqa: F401  (registers GLP_OT_SVLoRA)
+    D.write_synthetic_fairfedmed(str(tmp_path), sites=2, n_train=16, n_test=8, size=64, seed=4)
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+    hist = {}
+    for transport in ("float32", "uint8"):
+        cfg = make_cfg(bs=8)
+        cfg.DATASET = NS(NAME="FairFedMed", ROOT=str(tmp_path), USERS=2, ATTRIBUTE_TYPE="race",
+                         ATTRIBUTES=["race", "gender"], MODALITY_TYPE="slo_fundus")
+        cfg.TEST.NO_TEST = True
+        cfg.DATA = D.FedData(cfg, transport=transport)
+        cfg.MODEL.STATE_DICT = sd
+        tr = build_trainer(cfg)
+        first = next(iter(tr.fed_train_loader_x_dict[0]))
+        assert first["img"].dtype == (torch.uint8 if transport == "uint8" else torch.float32)
+        hist[transport] = F.run_fedotplora(tr, F.FedArgs(num_users=2, frac=1.0, round=2, shared_half_s=True, seed=0),
+                                           log=lambda *_: None)
+    a, b = hist["float32"], hist["uint8"]
+    for k, v in a["global_weights"].items():
+        assert torch.equal(v, b["global_weights"][k]), k
+    assert a["acc"] == b["acc"] and a["auc"] == b["auc"]
