@@ -215,3 +215,34 @@ def test_scores_from_counts_equal_the_sort_based_scores():
     # a single-class set reports AUC 1 (trainers/GLP_OT_SVLoRA.py:965-967)
     one = _brute_counts(prob, np.ones(N, np.int64), a0, 8)
     assert M.basic_from_counts(one)[3] == 1.0
+
+
+def test_cli_flags_config_tree_and_scope(tmp_path):
+    """fairfedmed_amd.federated_main: the reference's flag names (federated_main.py:791-881), its type=bool quirk
+    (any non-empty value is True), config-file merge order, and the scope guard."""
+    from fairfedmed_amd import federated_main as FM
+    (tmp_path / "ds.yaml").write_text('DATASET:\n  NAME: "FairFedMed"\n')
+    (tmp_path / "tr.yaml").write_text('DATALOADER:\n  TRAIN_X:\n    BATCH_SIZE: 32\n  TEST:\n    BATCH_SIZE: 100\n'
+                                      'INPUT:\n  SIZE: (224, 224)\n  PIXEL_MEAN: [0.48145466, 0.4578275, 0.40821073]\n'
+                                      'OPTIM:\n  LR: 0.5\n  MAX_EPOCH: 7\nMODEL:\n  BACKBONE:\n    NAME: "ViT-B/16"\n')
+    argv = ["--root", "DATA/", "--model", "FedOTPLoRA", "--seed", "1", "--num_users", "3", "--frac", "0.8", "--lr", "0.001",
+            "--OT", "None", "--gamma", "0.1", "--trainer", "GLP_OT_SVLoRA", "--round", "50", "--stepsize", "200",
+            "--input_no_transform", "False", "--attribute_type", "language", "--partition", "noniid-labeldir100",
+            "--beta", "0.3", "--n_ctx", "4", "--num_prompt", "2", "--unfreeze_image_encoder", "True", "--lora_rank", "12",
+            "--lora_alpha", "2", "--lora_type", "FairLoRA", "--dataset-config-file", str(tmp_path / "ds.yaml"),
+            "--config-file", str(tmp_path / "tr.yaml"), "--output-dir", str(tmp_path / "out"), "--shared_half_s", "True",
+            "--lambda_fairness", "0.0"]                              # scripts/fairfedlora_fairfedmed.sh
+    args = FM.build_parser().parse_args(argv)
+    assert args.input_no_transform is True and args.shared_half_s is True and args.lora_local_s is False
+    cfg = FM.setup_cfg(args)
+    FM.check_scope(args, cfg)
+    assert cfg.INPUT.SIZE == (224, 224) and cfg.INPUT.NO_TRANSFORM is True
+    assert cfg.OPTIM.LR == 0.001 and cfg.OPTIM.MAX_EPOCH == 1 and cfg.OPTIM.STEPSIZE == 200      # command line wins
+    assert cfg.DATALOADER.TRAIN_X.BATCH_SIZE == 32 and cfg.TEST.BATCH_SIZE == 100
+    lo = cfg.TRAINER.GLP_OT_LORA
+    assert (lo.RANK, lo.ALPHA, lo.TYPE, lo.UNFREEZE_IMAGE_ENCODER) == (12, 2.0, "FairLoRA", True)
+    assert cfg.TRAINER.GLP_OT.N == 2 and cfg.TRAINER.GLP_OT.N_CTX == 4 and cfg.DATASET.ATTRIBUTE_TYPE == "language"
+    for bad in (["--model", "fedavg"], ["--OT", "COT"], ["--trainer", "PromptFL"]):
+        a = FM.build_parser().parse_args(argv + bad)
+        with pytest.raises(NotImplementedError):
+            FM.check_scope(a, FM.setup_cfg(a))

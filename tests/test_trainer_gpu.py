@@ -377,3 +377,33 @@ def test_trainer_on_fairfedmed_files_uint8_equals_float32_transport(tmp_path):
     for k, v in a["global_weights"].items():
         assert torch.equal(v, b["global_weights"][k]), k
     assert a["acc"] == b["acc"] and a["auc"] == b["auc"]
+
+
+def test_cli_runs_the_fairlora_script_on_files(tmp_path):
+    """python -m fairfedmed_amd.federated_main with the flags of scripts/fairfedlora_fairfedmed.sh on a FairFedMed tree
+    on disk (reduced geometry through cfg_hook): rounds run, per-client final weights are written."""
+    from fairfedmed_amd import data as D
+    from fairfedmed_amd import federated_main as FM
+    D.write_synthetic_fairfedmed(str(tmp_path / "DATA"), sites=3, n_train=16, n_test=8, size=64, seed=9,
+                                 attribute_type="language")
+    (tmp_path / "tr.yaml").write_text('DATALOADER:\n  TRAIN_X:\n    BATCH_SIZE: 8\n  TEST:\n    BATCH_SIZE: 8\n'
+                                      'INPUT:\n  SIZE: (64, 64)\nMODEL:\n  BACKBONE:\n    NAME: "tiny"\n')
+    out = tmp_path / "out"
+    argv = ["--root", str(tmp_path / "DATA"), "--model", "FedOTPLoRA", "--seed", "1", "--num_users", "3", "--frac", "0.8",
+            "--lr", "0.001", "--OT", "None", "--gamma", "0.1", "--trainer", "GLP_OT_SVLoRA", "--round", "2",
+            "--stepsize", "200", "--attribute_type", "language", "--attributes", "language", "race", "gender",
+            "--n_ctx", "4", "--num_prompt", "2", "--unfreeze_image_encoder", "True", "--lora_rank", "4",
+            "--lora_alpha", "2", "--lora_type", "FairLoRA", "--config-file", str(tmp_path / "tr.yaml"),
+            "--output-dir", str(out), "--shared_half_s", "True", "--prec", "fp32"]
+    lines = []
+
+    def hook(cfg):
+        cfg.MODEL.GEOMETRY = C.vit_tiny(rank=4)
+
+    hist = FM.main(argv, log=lambda *a: lines.append(" ".join(str(x) for x in a)), cfg_hook=hook)
+    assert len(hist["acc"]) == 2 and all(np.isfinite(hist["auc"]))
+    for idx in range(3):
+        w = torch.load(out / f"global_client{idx}_final.pth")
+        assert "prompt_learner.ctx" in w and any("lora_S" in k for k in w)
+        assert not any("original_linear" in k for k in w)
+    assert any("Global test acc" in ln for ln in lines) and any("maximum test acc" in ln for ln in lines)
