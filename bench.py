@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--rank", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="fold the side streams into the main stream for the timed steps (one kernel at a time): the "
+                         "mode the roofline pass measures in; use it under rocprofv3 to get per-kernel durations "
+                         "that are comparable with roofline.avg_launch_us")
     ap.add_argument("--launch", default="replay", choices=["replay", "eager", "graph"],
                     help="replay: recorded launch plan (default); eager: Python per launch; graph: one hipGraph per step")
     return ap.parse_args()
@@ -170,6 +174,8 @@ def main():
         eng.sgd_step(opt.lr, opt.momentum, opt.weight_decay)
 
     eng.use_replay = args.launch == "replay"
+    if args.serial:
+        eng.set_overlap(False)
     graphed = eng.capture_train_step(BATCH, opt.lr, opt.momentum, opt.weight_decay) if args.launch == "graph" else None
 
     def step():
