@@ -1,0 +1,141 @@
+"""Edge cases of the hot path on the GPU: the ranks and group counts the reference's scripts actually use (rank 12,
+the 'language' / 'ethnicity' attributes), ranks beyond the fused rank-16 path, maximum rank and group count, one
+image, error conventions of the C ABI and of the trainer (SURVEY.md §8(b) 'Error conventions')."""
+import ctypes as C_
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from fairfedmed_amd import config as C
+from fairfedmed_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def cos(got, ref):
+    got = torch.as_tensor(got).double().cpu().flatten()
+    ref = torch.as_tensor(ref).double().cpu().flatten()
+    return float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-300))
+
+
+def rel(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("rank,G,bs", [(12, 3, 5),      # scripts/fairfedlora_fairfedmed.sh: LoRA_RANK=12, language (3 groups)
+                                       (12, 2, 3),      # ethnicity / gender: 2 groups
+                                       (16, 3, 4),      # BASELINE config 4 (3D OCT run): rank 16, last fused rank
+                                       (24, 3, 4),      # beyond 16: stand-alone down projection + VALU kernels
+                                       (32, 8, 9),      # FFM_MAX_RANK, FFM_MAX_GROUPS
+                                       (2, 2, 1)])      # smallest even rank, one image
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_step_vs_oracle_over_ranks_and_groups(rank, G, bs, dtype):
+    from oracle import fairlora_oracle as O
+    from fairfedmed_amd.engine import FairLoRAEngine
+    mcfg = C.vit_tiny(rank=rank, num_groups=G)
+    sd = synth.make_state_dict(mcfg, seed=rank, lora_init="random")
+    batch = synth.make_batch(mcfg, bs, seed=77 + rank)
+    keys = synth.trainable_keys(mcfg)
+    eng = FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=bs)
+    out = eng.forward_backward(batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda())
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    f32 = dtype == torch.float32
+    assert int(out["finite"]) == 1
+    assert rel(out["logits"], logits) < (2e-5 if f32 else 3e-2)
+    assert abs(float(out["loss"]) - float(loss)) <= (2e-5 if f32 else 1e-2) * abs(float(loss))
+    for k in keys:
+        g, ref = eng.params.view(k, "grad"), grads[k]
+        if float(ref.abs().max()) == 0.0:
+            assert float(g.abs().max()) < 1e-12, k
+        elif f32:
+            assert rel(g, ref) < 2e-3, (k, rel(g, ref))
+        else:
+            assert cos(g, ref) > 0.985, (k, cos(g, ref))
+
+
+def test_reference_initialisation_of_the_scripts_rank():
+    """'same+cycle' singular values at r = 12, G = 3 (trainers/GLP_OT_SVLoRA.py:402-417): A = 0, so the first step has
+    dS = dB = 0 exactly and dA != 0."""
+    from fairfedmed_amd.engine import FairLoRAEngine
+    mcfg = C.vit_tiny(rank=12, num_groups=3)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
+    batch = synth.make_batch(mcfg, 4, seed=5)
+    eng = FairLoRAEngine(mcfg, sd, dtype=torch.float32, max_images=4)
+    eng.forward_backward(batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda())
+    for k in synth.trainable_keys(mcfg):
+        g = eng.params.view(k, "grad")
+        if k.endswith(("lora_S.weight", "lora_B.weight")):
+            assert float(g.abs().max()) == 0.0, k
+        elif k.endswith("lora_A.weight"):
+            assert float(g.abs().max()) > 0.0, k
+
+
+def test_engine_argument_errors():
+    from fairfedmed_amd.engine import FairLoRAEngine
+    mcfg = C.vit_tiny(rank=4)
+    eng = FairLoRAEngine(mcfg, synth.make_state_dict(mcfg, seed=1), dtype=torch.float32, max_images=4)
+    b = synth.make_batch(mcfg, 5, seed=1)
+    with pytest.raises(ValueError):
+        eng.forward(b["img"].cuda(), None)                            # more images than max_images
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(2, 3, 32, 32, device="cuda"), None)   # wrong resolution
+    with pytest.raises(TypeError):
+        eng.forward(torch.zeros(2, 3, 64, 64, device="cuda", dtype=torch.float64), None)
+    with pytest.raises(TypeError):
+        eng.forward(b["img"][:2], None)                               # CPU tensor: there is no CPU path
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Status codes of include/ffm_hip.h: FFM_EINVAL (-1) for bad shapes / alignment / NULL, nothing is launched."""
+    from fairfedmed_amd import _lib as L
+    lib = L.load()
+    x = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    st = L.stream_ptr()
+    a = L.GemmArgs(L.ptr(x), L.ptr(x), L.ptr(x), 64, 64, 32, 64, 64, 64, 0, 0, None, None, None, None, None, None,
+                   None, None, None, None, None, None, None, 0, 0, 0.0, 0.0, None)
+    assert lib.ffm_gemm_nt(C_.byref(a), L.dtype_code(torch.bfloat16), st) == -1      # K * 2 B is not a multiple of 128 B
+    a.K, a.flags = 64, L.EPI_BIAS
+    assert lib.ffm_gemm_nt(C_.byref(a), L.dtype_code(torch.bfloat16), st) == -1      # bias flag without a bias pointer
+    a.flags = 0
+    assert lib.ffm_gemm_nt(C_.byref(a), 7, st) == -1                                  # unknown dtype code
+    assert lib.ffm_gemm_nt(C_.byref(a), L.dtype_code(torch.bfloat16), st) == 0
+    f = torch.zeros(64, device="cuda")
+    assert lib.ffm_layernorm_fwd(None, L.ptr(x), L.ptr(f), L.ptr(f), None, None, 64, 64, 1, st) == -1
+    assert lib.ffm_sgd_momentum(L.ptr(f), L.ptr(f), None, 64, C_.c_float(0.1), C_.c_float(0.9), C_.c_float(0.0), 1, st) == -1
+    assert lib.ffm_eval_counts(L.ptr(f), L.ptr(f), None, 0, 2, L.ptr(f), st) == -1    # N = 0
+    assert lib.ffm_expand_u8(L.ptr(f), L.ptr(f), 1, 1, 6, 1, st) == -1                # HW % 4 != 0
+    assert lib.ffm_bn_fwd(L.ptr(x), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), None, None, L.ptr(x), 64, 64,
+                          1, 0, 1, st) == -1                                           # training without scratch
+    torch.cuda.synchronize()
+
+
+def test_trainer_error_conventions_and_single_class_batch():
+    """Dassl/dassl/engine/trainer.py:260-262: a non-finite loss raises FloatingPointError; a single-class batch reports
+    auc = 1 (trainers/GLP_OT_SVLoRA.py:965-967); unknown LoRA types / datasets raise NotImplementedError."""
+    from tests.test_trainer_gpu import make_cfg
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4)
+    cfg = make_cfg(prec="fp32")
+    tr = GLP_OT_SVLoRA(cfg, data=SyntheticFedData(mcfg, 1, 2, 1, 8))
+    tr.num_batches, tr.batch_idx = 10, 0
+    batch = synth.make_batch(mcfg, 8, seed=3)
+    batch["label"] = torch.ones_like(batch["label"])
+    s = tr.forward_backward(batch)
+    assert s["auc"] == 1.0 and np.isfinite(s["loss"])
+    bad = dict(batch)
+    bad["img"] = batch["img"].clone()
+    bad["img"][0, 0, 0, 0] = float("nan")
+    with pytest.raises(FloatingPointError, match="Loss is infinite or NaN!"):
+        tr.forward_backward(bad)
+    cfg2 = make_cfg()
+    cfg2.TRAINER.GLP_OT_LORA.TYPE = "SVLoRA"
+    with pytest.raises(NotImplementedError):
+        GLP_OT_SVLoRA(cfg2, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
+    cfg3 = make_cfg()
+    cfg3.DATASET.NAME = "ImageNet"
+    with pytest.raises(NotImplementedError):
+        GLP_OT_SVLoRA(cfg3, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
