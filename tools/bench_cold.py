@@ -21,9 +21,18 @@ for i in range(NS):
     attr = torch.randint(0, G, (32,), device="cuda", dtype=torch.int32)
     ro = ops.RankOp(rk, torch.randn(G, R, device="cuda", generator=g), attr, 197, 0.25, 0.7,
                     t_out=torch.empty(M, R, device="cuda"), ts_out=torch.empty(M, R, device="cuda"))
-    sets.append(dict(a=a, b=b, out=torch.empty(M, N, device="cuda", dtype=dt), bp=ops.pack_b(b),
-                     kw=dict(bias=torch.randn(N, device="cuda", generator=g), gelu_out=torch.empty(M, N, device="cuda", dtype=dt),
-                             lw=torch.randn(R, N, device="cuda", generator=g), rankop=ro)))
+    if "dx" in sys.argv:
+        # dX(c_proj): reads the saved pre-activation (38.7 MB, cold in a real step) for the GELU derivative
+        rows = max(ops.gemm_tiles_m(M, N, K, 0, 0, dt, False), 512)
+        ro = ops.RankOp(rk, torch.randn(G, R, device="cuda", generator=g), attr, 197, 0.25, 0.7,
+                        ts_out=torch.empty(M, R, device="cuda"), t_fwd=torch.randn(M, R, device="cuda", generator=g),
+                        ds_part=torch.empty(rows, G, R, device="cuda"))
+        kw = dict(dgelu_aux=torch.randn(M, N, device="cuda", generator=g).to(dt),
+                  lw=torch.randn(N, R, device="cuda", generator=g), lw_is_kr=True, rankop=ro)
+    else:
+        kw = dict(bias=torch.randn(N, device="cuda", generator=g), gelu_out=torch.empty(M, N, device="cuda", dtype=dt),
+                  lw=torch.randn(R, N, device="cuda", generator=g), rankop=ro)
+    sets.append(dict(a=a, b=b, out=torch.empty(M, N, device="cuda", dtype=dt), bp=ops.pack_b(b), kw=kw))
 filler_a = torch.randn(6304, 3072, device="cuda").to(dt)
 filler_b = torch.empty_like(filler_a)
 
