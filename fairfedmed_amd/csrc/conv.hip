@@ -35,22 +35,28 @@ inline int grid1d(size_t n, int cap = 16384) {
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H,
                                                           int W, int stride, int Kp, f32x4 mean3, f32x4 std3) {
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    const size_t total = (size_t)B * Ho * Wo * Kp;
+    constexpr int VN = VecC<T>::N;                                   // one 16-byte store per thread
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1, kc = Kp / VN;
+    const size_t total = (size_t)B * Ho * Wo * kc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kp);
-        size_t r = i / Kp;
+        const int k0 = (int)(i % kc) * VN;
+        size_t r = i / kc;
         const int ox = (int)(r % Wo); r /= Wo;
         const int oy = (int)(r % Ho);
         const int b = (int)(r / Ho);
-        float v = 0.f;
-        if (k < 27) {
-            const int c = k % 3, tap = k / 3, ky = tap / 3, kx = tap % 3;
-            const int y = oy * stride + ky - 1, x = ox * stride + kx - 1;
-            if (y >= 0 && y < H && x >= 0 && x < W)
-                v = (img[(((size_t)b * 3 + c) * H + y) * W + x] / 255.0f - mean3[c]) / std3[c];
+        float v[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const int k = k0 + e;
+            v[e] = 0.f;
+            if (k < 27) {
+                const int c = k % 3, tap = k / 3, ky = tap / 3, kx = tap % 3;
+                const int y = oy * stride + ky - 1, x = ox * stride + kx - 1;
+                if (y >= 0 && y < H && x >= 0 && x < W)
+                    v[e] = (img[(((size_t)b * 3 + c) * H + y) * W + x] / 255.0f - mean3[c]) / std3[c];
+            }
         }
-        cols[i] = Elem<T>::from_f(v);
+        VecC<T>::store(cols + i * VN, v);
     }
 }
 
@@ -421,9 +427,10 @@ __global__ __launch_bounds__(256) void attnpool_tokens_kernel(const T* __restric
 extern "C" int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
                                const float* std3, int dtype, void* stream) {
     if (!img || !cols || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0 || stride <= 0 || Kp < 27) return FFM_EINVAL;
+    if (Kp % (dtype == FFM_BF16 ? 8 : 4) || ((uintptr_t)cols & 15)) return FFM_EINVAL;
     const f32x4 m = {mean3[0], mean3[1], mean3[2], 0.f}, sd = {std3[0], std3[1], std3[2], 1.f};
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-    const int g = grid1d((size_t)B * Ho * Wo * Kp);
+    const int g = grid1d((size_t)B * Ho * Wo * Kp / (dtype == FFM_BF16 ? 8 : 4));
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((stem_im2col_kernel<bf16_t>), dim3(g), dim3(256), 0, s, img, (bf16_t*)cols, B, H, W, stride, Kp, m, sd),

@@ -502,6 +502,9 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
             FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)                    // c_proj forward
             FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                    // dX of c_proj
             FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR)                                    // dX of c_fc
+            FFM_GEMM_CASE(true, FFM_EPI_LORA)                                                      // RN50 conv1 / conv3 (no bias)
+            FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA)                                       // RN50 attention-pool projections
+            FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_RESIDUAL)                 // RN50 dX of conv1 + identity path
             default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1>(a, s) : launch_gemm<float, true, -1>(a, s);
         }
     }
