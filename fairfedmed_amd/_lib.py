@@ -71,6 +71,7 @@ SIGNATURES = {
     "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "ffm_expand_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

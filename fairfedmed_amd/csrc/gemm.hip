@@ -61,10 +61,59 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
     }
 }
 
+// Kernel argument: the public ffm_gemm_args plus the implicit-convolution view of the A operand (CV instantiation).
+struct gemm_kargs {
+    ffm_gemm_args g;
+    int conv_h, conv_w, conv_c;      // A = NHWC activation [B*H*W, C]; logical A row = the 3x3 / pad 1 patch of the pixel
+    const void* conv_zero;           // >= 16 zero bytes in device memory: source of padded / out-of-image chunks
+};
+
+// Implicit im2col: the 16-byte chunk a lane fetches for K-tile kt lies in ONE tap (C % chunk == 0); its source is the
+// same channel offset of the neighbouring pixel, or the zero buffer outside the image / beyond tap 8 (K padding).
+// The lane's chunk index (slot ^ rsub) does not depend on the instruction, so (tap, channel) advance once per K-tile.
+template <typename T>
+struct ConvA {
+    int y[4], x[4], pix[4];          // the lane's four tile rows: pixel coordinates and linear pixel index
+    int tap, cb;                     // tap and channel BYTE offset of the lane's chunk in the current K-tile
+    __device__ __forceinline__ void init(const gemm_kargs& k, int m0, int wave, int lane) {
+        const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int g = m0 + (wave * 4 + q) * 8 + rsub;
+            g = g < k.g.M ? g : k.g.M - 1;
+            pix[q] = g;
+            x[q] = g % k.conv_w;
+            y[q] = (g / k.conv_w) % k.conv_h;
+        }
+        const int kb = (slot ^ rsub) * 16, cbytes = k.conv_c * (int)sizeof(T);
+        tap = kb / cbytes;
+        cb = kb % cbytes;
+    }
+    __device__ __forceinline__ void stage(const gemm_kargs& k, char* lds_tile, int wave) {
+        const char* xb = reinterpret_cast<const char*>(k.g.a);
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const size_t cbytes = (size_t)k.conv_c * sizeof(T);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = y[q] + dy, xx = x[q] + dx;
+            const bool in = tap < 9 && yy >= 0 && yy < k.conv_h && xx >= 0 && xx < k.conv_w;
+            const char* src = in ? xb + (size_t)(pix[q] + dy * k.conv_w + dx) * cbytes + cb
+                                 : reinterpret_cast<const char*>(k.conv_zero);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds_tile + (wave * 4 + q) * 1024),
+                                             16, 0, 0);
+        }
+        cb += KT_BYTES;                                          // next K-tile
+        const int cbi = k.conv_c * (int)sizeof(T);
+        while (cb >= cbi) { cb -= cbi; ++tap; }
+    }
+};
+
 // FL >= 0: the epilogue flags are a compile-time constant (the combinations the engine uses are
 // instantiated below, so the epilogue is straight-line code); FL < 0: generic, flags read at run time.
-template <typename T, bool RK, int FL>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
+template <typename T, bool RK, int FL, bool CV = false>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
+    const ffm_gemm_args& p = px.g;
     typedef typename Mma16<T>::frag_t frag_t;
     constexpr int BUF = buf_bytes<RK>();
     const int flags = FL >= 0 ? FL : p.flags;
@@ -105,7 +154,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
     };
 
     // prologue: tile 0 -> buffer 0
-    stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+    ConvA<T> cva;
+    if constexpr (CV) {
+        cva.init(px, m0, wave, lane);
+        cva.stage(px, smem, wave);
+    } else {
+        stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+    }
     stage_tile<T>(B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
     stage_rank(0, smem + 2 * TILE_BYTES);
 
@@ -192,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
         char* Bs = As + TILE_BYTES;
         if (kt + 1 < nk) {
             char* An = smem + (cur ^ 1) * BUF;
-            stage_tile<T>(A, p.lda, m0, p.M, (kt + 1) * KT_BYTES, An, wave, lane);
+            if constexpr (CV) cva.stage(px, An, wave);
+            else stage_tile<T>(A, p.lda, m0, p.M, (kt + 1) * KT_BYTES, An, wave, lane);
             stage_tile<T>(B, p.ldb, n0, p.N, (kt + 1) * KT_BYTES, An + TILE_BYTES, wave, lane);
             stage_rank((kt + 1) * KT_BYTES, An + 2 * TILE_BYTES);
         }
@@ -430,8 +486,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(ffm_gemm_args p) {
     }
 }
 
-template <typename T, bool RK, int FL>
-int launch_gemm(const ffm_gemm_args& a, hipStream_t s) {
+template <typename T, bool RK, int FL, bool CV = false>
+int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = nullptr) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int r = (a.flags & FFM_EPI_LORA) ? a.rank : 0;
     int lds = epi_lds_bytes(r, RK);
@@ -440,13 +496,16 @@ int launch_gemm(const ffm_gemm_args& a, hipStream_t s) {
     if (lds > 65536) {
         static bool done = false;                     // one per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL, CV>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return (int)e;
             done = true;
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL>), dim3(tiles), dim3(256), lds, s, a);
+    gemm_kargs ka;
+    if (conv) ka = *conv;
+    else { ka.g = a; ka.conv_h = ka.conv_w = ka.conv_c = 0; ka.conv_zero = nullptr; }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV>), dim3(tiles), dim3(256), lds, s, ka);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -522,6 +581,25 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1>(a, s) : launch_gemm<float, false, -1>(a, s);
     }
 #undef FFM_GEMM_CASE
+}
+
+extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
+                                const void* zeros, int dtype, void* stream) {
+    if (!x || !w || !y || !zeros || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return FFM_EINVAL;
+    if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
+    const size_t es = dtype == FFM_BF16 ? 2 : 4;
+    if (((size_t)C * es) % 16 || ((size_t)Kp * es) % KT_BYTES || Kp < 9 * C || N % 8) return FFM_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)zeros) & 15) return FFM_EINVAL;
+    if ((long long)B * H * W > 0x7fffffffLL) return FFM_EUNSUP;
+    gemm_kargs ka;
+    ffm_gemm_args& a = ka.g;
+    a = ffm_gemm_args{};
+    a.a = x; a.b = w; a.c = y;
+    a.M = B * H * W; a.N = N; a.K = Kp;
+    a.lda = C; a.ldb = Kp; a.ldc = N;
+    ka.conv_h = H; ka.conv_w = W; ka.conv_c = C; ka.conv_zero = zeros;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
 }
 
 extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {

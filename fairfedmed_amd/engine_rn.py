@@ -7,8 +7,8 @@ weights and biases trainable (:822-829), everything else frozen.
 
 Data layout: activations are NHWC rows, row = (image, y, x), channels contiguous,
 so every 1x1 convolution IS ffm_gemm_nt on the rows (with the FairLoRA epilogue),
-3x3 convolutions are im2col + ffm_gemm_nt with the weight re-ordered once to
-[Cout, (ky, kx, cin)], and the attention pool runs on [image*L, E] token rows with
+3x3 convolutions are an implicit GEMM (ffm_conv3x3_nhwc: the GEMM's A loader reads the patch from the
+neighbouring pixels, weight re-ordered once to [Cout, (ky, kx, cin)]; the input gradient is the same call on dY), and the attention pool runs on [image*L, E] token rows with
 the ViT attention kernels (head_dim 64, 32 heads).  The text tower, logits head,
 flat parameter buffer, SGD, streams and launch-plan replay are the base class's.
 """
@@ -138,7 +138,6 @@ class _Bneck:
         self.bn1, self.bn2 = _BN(eng, p + "bn1.", planes, Ri), _BN(eng, p + "bn2.", planes, Ri)
         self.bn3 = _BN(eng, p + "bn3.", out, Ro)
         self.Kp = _round_up(9 * planes, eng.kq)
-        eng.cols_elems = max(eng.cols_elems, Ri * self.Kp)
         # saved activations
         self.z1, self.a1, self.z2, self.a2 = e(Ri, planes), e(Ri, planes), e(Ri, planes), e(Ri, planes)
         self.a2p = e(Ro, planes) if stride > 1 else None
@@ -161,8 +160,8 @@ class _Bneck:
         w3 = sd[p + "conv3.original_linear.weight"].reshape(4 * self.planes, self.planes)
         putw(p + "w1", e._w(w1)); putw(p + "w1t", e._wt(w1))
         putw(p + "w3", e._w(w3)); putw(p + "w3t", e._wt(w3))
-        w2 = e.conv3x3_rows(sd[p + "conv2.weight"], self.Kp)
-        putw(p + "w2", e._w(w2)); putw(p + "w2t", e._wt(w2))
+        putw(p + "w2", e._w(e.conv3x3_rows(sd[p + "conv2.weight"], self.Kp)))
+        putw(p + "w2b", e._w(e.conv3x3_rows_bwd(sd[p + "conv2.weight"], self.Kp)))
         if self.has_down:
             wd = sd[p + "downsample.0.weight"].reshape(4 * self.planes, self.inpl)
             putw(p + "wd", e._w(wd)); putw(p + "wdt", e._wt(wd))
@@ -174,9 +173,7 @@ class _Bneck:
         z1, a1, z2, a2, z3, out = self.z1[:ri], self.a1[:ri], self.z2[:ri], self.a2[:ri], self.z3[:ro], self.out[:ro]
         self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi)
         self.bn1.fwd(z1, a1, True)
-        cols = e.cols_view(ri, self.Kp)
-        ops.im2col3x3(a1, cols, images, Hi, Hi, 1)
-        ops.gemm_nt(cols, W[p + "w2"], z2)
+        ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16)          # implicit GEMM: no im2col buffer
         self.bn2.fwd(z2, a2, True)
         a = a2
         if self.stride > 1:
@@ -219,9 +216,7 @@ class _Bneck:
             da2 = self.da2[:ri]
             ops.avgpool2(self.da2p[:ro], da2, images, Hi, Hi, backward=True)
         self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
-        dcols = e.cols_view(ri, self.Kp)
-        ops.gemm_nt(self.dz2[:ri], W[p + "w2t"], dcols)
-        ops.col2im3x3(dcols, self.da1[:ri], images, Hi, Hi, 1)
+        ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16)   # dX = conv3x3(dY; w')
         self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
         self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid)
         return self.dx[:ri]
@@ -245,7 +240,7 @@ class RN50Engine(FairLoRAEngine):
         self.kq = 64 if dt == torch.bfloat16 else 32             # GEMM K granularity (128 bytes)
         self.rnw: Dict[str, Tensor] = {}
         self.bns: List[_BN] = []
-        self.bn_scratch = self.bn_cmax = self.cols_elems = 0
+        self.bn_scratch = self.bn_cmax = 0
         self.bn_training = False
         self.pack_entries: list = []
         e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)
@@ -254,16 +249,14 @@ class RN50Engine(FairLoRAEngine):
         self.H1, self.H2 = H1, H1 // 2
         self.ones_s = torch.ones(1, cfg.lora.rank, device=dev, dtype=torch.float32)
         # stem: conv1 (stride 2) .. conv3, three BatchNorms, 2x2 average pool
-        self.Kp1, self.Kp2 = _round_up(27, self.kq), _round_up(9 * (w // 2), self.kq)
-        self.Kc = _round_up(w // 2, self.kq)                      # K of the dX product of stem conv2
+        self.Kp1, self.Kp2, self.Kp3 = _round_up(27, self.kq), _round_up(9 * (w // 2), self.kq), _round_up(9 * w, self.kq)
         self.cols1 = e(R1, self.Kp1)
-        self.cols_elems = R1 * self.Kp2
+        self.zero16 = torch.zeros(64, device=dev, dtype=dt)       # source of the zero padding of the implicit GEMMs
         self.sbn = [_BN(self, f"image_encoder.bn{i}.", c, R1) for i, c in ((1, w // 2), (2, w // 2), (3, w))]
         self.sz = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
         self.sa = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
         self.dsa = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
         self.dsz = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
-        self.dsz2p = e(R1, self.Kc) if self.Kc != w // 2 else None
         self.p0 = e(max_images * self.H2 * self.H2, w)
         # residual stages
         self.blocks: List[_Bneck] = []
@@ -286,7 +279,6 @@ class RN50Engine(FairLoRAEngine):
         self.delta = torch.zeros_like(self.lse)
         self.d_o, self.dqkv, self.dtok = e(T, E), e(T, 3 * E), [e(T, E), e(T, E)]
         self.dx4 = e(max_images * v.spacial * v.spacial, E)
-        self.cols_flat = torch.zeros(self.cols_elems, device=dev, dtype=dt)
         self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
         self.bn_k12 = torch.zeros(2 * self.bn_cmax, device=dev, dtype=torch.float32)
         self.rn_plans: Dict[int, ops.ReducePlan] = {}
@@ -300,14 +292,20 @@ class RN50Engine(FairLoRAEngine):
     def _n_layer_events(self) -> int:
         return 1
 
-    def cols_view(self, rows: int, Kp: int) -> Tensor:
-        return self.cols_flat[:rows * Kp].view(rows, Kp)
-
     def conv3x3_rows(self, w: Tensor, Kp: int) -> Tensor:
         """[Cout, Cin, 3, 3] -> [Cout, Kp] with k = (ky*3 + kx)*Cin + c, zero padded (the order ffm_im2col3x3 writes)."""
         co = w.shape[0]
         rows = w.float().permute(0, 2, 3, 1).reshape(co, -1)
         out = torch.zeros(co, Kp, dtype=torch.float32)
+        out[:, :rows.shape[1]] = rows
+        return out
+
+    def conv3x3_rows_bwd(self, w: Tensor, Kp: int) -> Tensor:
+        """[Cout, Cin, 3, 3] -> [Cin, Kp] with k = (ky'*3 + kx')*Cout + co holding w[co, ci, 2-ky', 2-kx']: the input
+        gradient of the convolution is the same implicit GEMM applied to dY with this matrix."""
+        ci = w.shape[1]
+        rows = w.float().flip(2, 3).permute(1, 2, 3, 0).reshape(ci, -1)
+        out = torch.zeros(ci, Kp, dtype=torch.float32)
         out[:, :rows.shape[1]] = rows
         return out
 
@@ -322,13 +320,10 @@ class RN50Engine(FairLoRAEngine):
 
         w = v.width
         putw("s1", self._w(self.conv3x3_rows(sd[ie + "conv1.weight"], self.Kp1)))
-        s2 = self.conv3x3_rows(sd[ie + "conv2.weight"], self.Kp2)
-        putw("s2", self._w(s2))
-        s2t = torch.zeros(self.Kp2, self.Kc)                      # dX operand, K padded to the GEMM granularity
-        s2t[:, :w // 2] = s2.t()
-        putw("s2t", self._w(s2t))
-        s3 = self.conv3x3_rows(sd[ie + "conv3.weight"], self.Kp2)
-        putw("s3", self._w(s3)); putw("s3t", self._wt(s3))
+        putw("s2", self._w(self.conv3x3_rows(sd[ie + "conv2.weight"], self.Kp2)))
+        putw("s2b", self._w(self.conv3x3_rows_bwd(sd[ie + "conv2.weight"], self.Kp2)))
+        putw("s3", self._w(self.conv3x3_rows(sd[ie + "conv3.weight"], self.Kp2)))
+        putw("s3b", self._w(self.conv3x3_rows_bwd(sd[ie + "conv3.weight"], self.Kp3)))
         for blk in self.blocks:
             blk.load(sd, putw)
         ap = ie + "attnpool."
@@ -409,9 +404,7 @@ class RN50Engine(FairLoRAEngine):
         ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0])
         self.sbn[0].fwd(sz[0], sa[0], True)
         for i, wn in ((1, "s2"), (2, "s3")):
-            cols = self.cols_view(r1, self.Kp2)
-            ops.im2col3x3(sa[i - 1], cols, b, H1, H1, 1)
-            ops.gemm_nt(cols, W[wn], sz[i])
+            ops.conv3x3(sa[i - 1], W[wn], sz[i], b, H1, H1, self.zero16)
             self.sbn[i].fwd(sz[i], sa[i], True)
         x = self.p0[:b * H2 * H2]
         ops.avgpool2(sa[2], x, b, H1, H1)
@@ -457,17 +450,9 @@ class RN50Engine(FairLoRAEngine):
         dsa, dsz = [t[:r1] for t in self.dsa], [t[:r1] for t in self.dsz]
         ops.avgpool2(g, dsa[2], b, H1, H1, backward=True)
         self.sbn[2].bwd(dsa[2], sa[2], sz[2], dsz[2])
-        dcols = self.cols_view(r1, self.Kp2)
-        ops.gemm_nt(dsz[2], W["s3t"], dcols)
-        ops.col2im3x3(dcols, dsa[1], b, H1, H1, 1)
+        ops.conv3x3(dsz[2], W["s3b"], dsa[1], b, H1, H1, self.zero16)
         self.sbn[1].bwd(dsa[1], sa[1], sz[1], dsz[1])
-        gz = dsz[1]
-        if self.dsz2p is not None:
-            gz = self.dsz2p[:r1]
-            c = dsz[1].shape[1]
-            self._glue(lambda gz=gz, src=dsz[1], c=c: gz[:, :c].copy_(src))
-        ops.gemm_nt(gz, W["s2t"], dcols)
-        ops.col2im3x3(dcols, dsa[0], b, H1, H1, 1)
+        ops.conv3x3(dsz[1], W["s2b"], dsa[0], b, H1, H1, self.zero16)
         self.sbn[0].bwd(dsa[0], sa[0], sz[0], dsz[0])
         self._reduce(b).run()
 

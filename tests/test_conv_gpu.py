@@ -156,3 +156,42 @@ def test_avgpool_add_relu_and_attnpool_tokens(ops, dt):
     df = torch.empty_like(feat)
     ops.attnpool_tokens(dt_, None, df, B, HW, backward=True)
     assert rel(df.reshape(B, HW, E), fr.grad) < tol(dt)
+
+
+def _rows_fwd(w, Kp):
+    """[Co, Ci, 3, 3] -> [Co, Kp], k = (ky*3 + kx)*Ci + c."""
+    r = w.float().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    out = torch.zeros(w.shape[0], Kp, device=w.device)
+    out[:, :r.shape[1]] = r
+    return out
+
+
+def _rows_bwd(w, Kp):
+    """[Co, Ci, 3, 3] -> [Ci, Kp], k = (ky'*3 + kx')*Co + co holding w[co, ci, 2-ky', 2-kx']: dX = conv3x3(dY; w')."""
+    r = w.float().flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1)
+    out = torch.zeros(w.shape[1], Kp, device=w.device)
+    out[:, :r.shape[1]] = r
+    return out
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("B,H,W,C,Co", [(2, 16, 16, 64, 64), (3, 14, 14, 32, 64), (2, 8, 12, 32, 32), (1, 7, 7, 128, 64),
+                                        (5, 28, 28, 64, 64), (2, 4, 4, 512, 512)])
+def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, Co):
+    """ffm_conv3x3_nhwc: the patches are never materialised; forward and (with the re-ordered weight) the input
+    gradient against F.conv2d and its autograd, incl. non-square maps, tile-ragged pixel counts and padded K."""
+    kq = 64 if dt == torch.bfloat16 else 32
+    rup = lambda v: (v + kq - 1) // kq * kq
+    x = rnd(B, C, H, W, dt=dt, seed=1)
+    w = rnd(Co, C, 3, 3, dt=dt, scale=1.0 / math.sqrt(9 * C), seed=2)
+    zeros = torch.zeros(64, device="cuda", dtype=dt)
+    xr = x.float().requires_grad_(True)
+    ref = F.conv2d(xr, w.float(), padding=1)
+    y = torch.empty(B * H * W, Co, device="cuda", dtype=dt)
+    ops.conv3x3(nhwc(x), _rows_fwd(w, rup(9 * C)).to(dt), y, B, H, W, zeros)
+    assert rel(nchw(y.float(), B, H, W), ref.detach()) < tol(dt)
+    g = rnd(B, Co, H, W, dt=dt, seed=3)
+    ref.backward(g.float())
+    dx = torch.empty(B * H * W, C, device="cuda", dtype=dt)
+    ops.conv3x3(nhwc(g), _rows_bwd(w, rup(9 * Co)).to(dt), dx, B, H, W, zeros)
+    assert rel(nchw(dx.float(), B, H, W), xr.grad) < tol(dt)
