@@ -209,9 +209,7 @@ class FairLoRALinear(nn.Module):
 
 class LoRALinear(nn.Module):
     """Plain LoRA, y = x W^T + b + (alpha / r) (x A) B (trainers/GLP_OT_SVLoRA.py:203-252; the RN50 attention pool's
-    q/k/v/c projections).  It is the FairLoRA product with one group and s = 1, so it runs on the same kernels.
-    (The reference's SVLoRALinear is not mirrored: its forward applies torch.diag to an [r, 1] weight, which only
-    type-checks for r = 1, and no script selects it.)"""
+    q/k/v/c projections).  It is the FairLoRA product with one group and s = 1, so it runs on the same kernels."""
 
     def __init__(self, original_linear: nn.Linear, rank: int = 4, alpha: float = 0.04):
         super().__init__()
@@ -250,23 +248,68 @@ class LoRALinear(nn.Module):
         return y.reshape(*lead, -1)
 
 
+class SVLoRALinear(nn.Module):
+    """One shared diagonal of singular values, y = x W^T + b + (alpha / r) ((x A) * s) B
+    (trainers/GLP_OT_SVLoRA.py:255-330): FairLoRA with a single group.  As in the reference, ``lora_S.weight`` is a
+    1-D tensor of length r after ``reset_parameters`` (linspace(1, 0.1, r) replaces the [r, 1] embedding weight)."""
+
+    def __init__(self, original_linear: nn.Linear, rank: int = 4, alpha: float = 0.4, global_s: bool = False):
+        super().__init__()
+        if global_s:
+            raise NotImplementedError("GLOBAL_S is False in every script; not built")
+        self.original_linear = original_linear
+        self.rank, self.alpha, self.scaling, self.global_s = rank, alpha, alpha / rank, global_s
+        self.lora_A, self.lora_B = _Emb(original_linear.in_features, rank), _Emb(rank, original_linear.out_features)
+        self.lora_S = _Emb(rank, 1)
+        self.to(original_linear.weight.device)
+        for p in self.original_linear.parameters():
+            p.requires_grad = False
+        self.reset_parameters()
+        self._cache = None
+
+    def reset_parameters(self):
+        nn.init.zeros_(self.lora_A.weight)
+        self.lora_S.weight.data = torch.linspace(1, 0.1, steps=self.rank, device=self.lora_S.weight.device)
+        nn.init.normal_(self.lora_B.weight)
+
+    _frozen = FairLoRALinear._frozen
+
+    def forward(self, x: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("SVLoRALinear runs on the MI355X HIP kernels only; there is no CPU path")
+        lead, fin = x.shape[:-1], x.shape[-1]
+        W, Wt = self._frozen(x.dtype)
+        x2d = x.reshape(-1, fin).contiguous()
+        bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
+        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight.view(1, -1), self.lora_B.weight,
+                              None, x2d.shape[0], self.scaling, 0.7)
+        return y.reshape(*lead, -1)
+
+
 def apply_lora_to_model(model: nn.Module, unfreeze_image_encoder: bool, rank: int = 4, alpha: float = 0.04,
                         lora_type: str = "FairLoRA", global_s: bool = False, num_attrs: int = 1) -> None:
     """The reference's injection rules (trainers/GLP_OT_SVLoRA.py:503-573) for modules under 'image_encoder.':
     ViT - every nn.Linear whose name contains '.mlp.' becomes a FairLoRALinear; ResNet - every 1x1 nn.Conv2d named
     '*conv*' under 'layer*' becomes a FairLoRALinear (downsample.0 is not named conv and stays), every nn.Linear
     of 'attnpool' a plain LoRALinear."""
-    if lora_type != "FairLoRA":
+    if lora_type not in ("LoRA", "SVLoRA", "FairLoRA"):
         raise NotImplementedError(lora_type)
     for name, module in dict(model.named_modules()).items():
         if not (unfreeze_image_encoder and name.startswith("image_encoder.")):
             continue
         if isinstance(module, nn.Linear) and ".mlp." in name:
-            new = FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s, num_attrs=num_attrs)
+            if lora_type == "LoRA":
+                new = LoRALinear(module, rank=rank, alpha=alpha)
+            elif lora_type == "SVLoRA":
+                new = SVLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s)
+            else:
+                new = FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s, num_attrs=num_attrs)
         elif name.startswith("image_encoder.layer") or name.startswith("image_encoder.attnpool"):
             if "attnpool" in name and isinstance(module, nn.Linear):
                 new = LoRALinear(module, rank=rank, alpha=alpha)
             elif isinstance(module, nn.Conv2d) and "conv" in name and tuple(module.weight.shape[-2:]) == (1, 1):
+                if lora_type != "FairLoRA":
+                    raise NotImplementedError(lora_type)           # :561-567: the ResNet branch only knows FairLoRA
                 new = FairLoRALinear(module, rank=rank, alpha=alpha, global_s=global_s, num_attrs=num_attrs)
             else:
                 continue

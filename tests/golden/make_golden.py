@@ -221,6 +221,37 @@ def golden_lora_plain(M, out):
     out["lora_plain.weight"] = layer.weight(x).detach().numpy()
 
 
+def golden_svlora():
+    """SVLoRALinear (one shared diagonal of singular values; trainers/GLP_OT_SVLoRA.py:255-330): initial lora_S and
+    a forward / backward with trained-looking factors.  Written to tests/golden/svlora.npz."""
+    import torch.nn as nn
+    M, *_ = import_reference() if "trainers.GLP_OT_SVLoRA" not in sys.modules else (sys.modules["trainers.GLP_OT_SVLoRA"],)
+    out = {}
+    L, Bn, fin, fout, r = 50, 4, 128, 192, 8
+    x = rng_tensor("svlora.x", (L, Bn, fin))
+    g = rng_tensor("svlora.g", (L, Bn, fout))
+    lin = nn.Linear(fin, fout)
+    lin.weight.data = rng_tensor("svlora.W", (fout, fin)) * fin ** -0.5
+    lin.bias.data = rng_tensor("svlora.b", (fout,)) * 0.1
+    layer = M.SVLoRALinear(lin, rank=r, alpha=2.0, global_s=False)
+    out["svlora.s_init"] = layer.lora_S.weight.detach().numpy().copy()
+    out["svlora.s_shape"] = np.array(layer.lora_S.weight.shape)
+    layer.lora_A.weight.data = rng_tensor("svlora.A", (fin, r)) * 0.1
+    layer.lora_B.weight.data = rng_tensor("svlora.B", (r, fout))
+    layer.lora_S.weight.data = layer.lora_S.weight.data * (1.0 + 0.1 * rng_tensor("svlora.S", (r,)))
+    out["svlora.S"] = layer.lora_S.weight.detach().numpy().copy()
+    xin = x.clone().requires_grad_(True)
+    y = layer(xin)
+    y.backward(g)
+    out["svlora.y"] = y.detach().numpy()
+    out["svlora.dx"] = xin.grad.numpy()
+    out["svlora.dA"] = layer.lora_A.weight.grad.numpy()
+    out["svlora.dS"] = layer.lora_S.weight.grad.numpy()
+    out["svlora.dB"] = layer.lora_B.weight.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "svlora.npz"), **out)
+    print("svlora.npz:", {k: v.shape for k, v in out.items()})
+
+
 def golden_s_init(M, out):
     import torch.nn as nn
     for r in (4, 8, 12, 16, 32):
@@ -392,6 +423,7 @@ def golden_dataset():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.json only")
+    ap.add_argument("--only-svlora", action="store_true", help="regenerate tests/golden/svlora.npz only")
     ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
     ap.add_argument("--time-ref", action="store_true", help="time the reference CPU step at bs=32")
     args = ap.parse_args()
@@ -401,7 +433,11 @@ def main():
     if args.only_dataset:
         golden_dataset()
         return
+    if args.only_svlora:
+        golden_svlora()
+        return
     golden_dataset()
+    golden_svlora()
 
     out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
     golden_layers(M, out)

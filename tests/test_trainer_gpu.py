@@ -407,3 +407,47 @@ def test_cli_runs_the_fairlora_script_on_files(tmp_path):
         assert "prompt_learner.ctx" in w and any("lora_S" in k for k in w)
         assert not any("original_linear" in k for k in w)
     assert any("Global test acc" in ln for ln in lines) and any("maximum test acc" in ln for ln in lines)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_svlora_linear_vs_reference_golden(golden_dir, dtype):
+    """SVLoRALinear (--lora_type SVLoRA; trainers/GLP_OT_SVLoRA.py:255-330) on the HIP kernels vs the imported
+    reference layer: initial singular values (1-D, linspace(1, 0.1, r)), forward, all gradients."""
+    from fairfedmed_amd.model import SVLoRALinear, apply_lora_to_model
+    from tests.golden.make_golden import rng_tensor
+    gold = np.load(os.path.join(golden_dir, "svlora.npz"))
+    L, Bn, fin, fout, r = 50, 4, 128, 192, 8
+    lin = torch.nn.Linear(fin, fout)
+    lin.weight.data = rng_tensor("svlora.W", (fout, fin)) * fin ** -0.5
+    lin.bias.data = rng_tensor("svlora.b", (fout,)) * 0.1
+    layer = SVLoRALinear(lin.cuda(), rank=r, alpha=2.0)
+    assert tuple(layer.lora_S.weight.shape) == tuple(gold["svlora.s_shape"]) == (r,)
+    assert rel(layer.lora_S.weight.detach(), gold["svlora.s_init"]) < 1e-7
+    assert float(layer.lora_A.weight.abs().max()) == 0.0
+    layer.lora_A.weight.data.copy_(rng_tensor("svlora.A", (fin, r)) * 0.1)
+    layer.lora_B.weight.data.copy_(rng_tensor("svlora.B", (r, fout)))
+    layer.lora_S.weight.data.copy_(torch.from_numpy(gold["svlora.S"]))
+    xin = rng_tensor("svlora.x", (L, Bn, fin)).cuda().to(dtype).requires_grad_(True)
+    y = layer(xin)
+    y.backward(rng_tensor("svlora.g", (L, Bn, fout)).cuda().to(dtype))
+    t1, t2 = (3e-5, 1e-4) if dtype == torch.float32 else (1.5e-2, 4e-2)
+    assert rel(y.detach().float().cpu(), gold["svlora.y"]) < t1
+    assert rel(xin.grad.float().cpu(), gold["svlora.dx"]) < t1
+    assert rel(layer.lora_A.weight.grad, gold["svlora.dA"]) < t2
+    assert rel(layer.lora_B.weight.grad, gold["svlora.dB"]) < t2
+    assert rel(layer.lora_S.weight.grad, gold["svlora.dS"]) < t2
+    # the injection rule knows the three types on the ViT branch
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 64))
+    class Mdl(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.image_encoder = torch.nn.Sequential(Blk())
+    for typ, cls in (("SVLoRA", "SVLoRALinear"), ("LoRA", "LoRALinear"), ("FairLoRA", "FairLoRALinear")):
+        m = Mdl()
+        apply_lora_to_model(m, True, rank=4, alpha=2.0, lora_type=typ, num_attrs=3)
+        assert type(m.image_encoder[0].mlp[0]).__name__ == cls
+    with pytest.raises(NotImplementedError):
+        apply_lora_to_model(Mdl(), True, lora_type="DoRA")
