@@ -447,17 +447,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     out[o] = accumulate ? out[o] + s : s;
 }
 
-// many small reductions in one launch: blockIdx.y selects the descriptor
+// many small reductions in one launch: blockIdx.y selects the descriptor.  4 lanes share an output, 32 when the
+// tensor has more than 64 partial rows (RN50 layer1: 784), combined by shuffles in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_multi_kernel(const ffm_reduce_desc* __restrict__ descs) {
     const ffm_reduce_desc d = descs[blockIdx.y];
-    if ((int)(blockIdx.x * blockDim.x) >= 4 * d.n) return;     // whole block beyond this tensor (uniform)
+    const int L = d.nsplit > 64 ? 32 : 4, sh = d.nsplit > 64 ? 5 : 2;
+    if ((long long)blockIdx.x * blockDim.x >= (long long)L * d.n) return;     // whole block beyond this tensor (uniform)
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = gid >> 2, q = gid & 3;
+    const int i = gid >> sh, q = gid & (L - 1);
     float s = 0.f;
     if (i < d.n)
-        for (int sp = q; sp < d.nsplit; sp += 4) s += d.part[(size_t)sp * d.n + i];
+        for (int sp = q; sp < d.nsplit; sp += L) s += d.part[(size_t)sp * d.n + i];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
+    if (L == 32) {
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 16, 64);
+    }
     if (i >= d.n || q != 0) return;
     int o = i;
     if (d.transpose_K > 0) {

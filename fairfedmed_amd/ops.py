@@ -402,7 +402,7 @@ class ReducePlan:
         for i, (part, nsplit, n, out, tK, tr) in enumerate(entries):
             _dev(part, out)
             arr[i] = L.ReduceDesc(part.data_ptr(), out.data_ptr(), nsplit, n, tK, tr)
-            self.max_n = max(self.max_n, n)
+            self.max_n = max(self.max_n, n * (8 if nsplit > 64 else 1))   # 32 lanes per output beyond 64 partial rows
         raw = bytes(arr)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.n = len(entries)

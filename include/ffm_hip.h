@@ -271,7 +271,9 @@ int ffm_reduce_partials(const float* part, int nsplit, int n, float* out, int tr
 
 /*
  * The same reduction for many tensors in ONE launch (all LoRA gradients of a
- * step): descs_dev is a DEVICE array of ndesc descriptors, max_n = max over n.
+ * step): descs_dev is a DEVICE array of ndesc descriptors, max_n = max over the
+ * descriptors of n * (nsplit > 64 ? 8 : 1) (the launch width: 4 lanes per output,
+ * 32 for tensors with more than 64 partial rows).
  */
 typedef struct ffm_reduce_desc {
     const float* part;
