@@ -229,3 +229,28 @@ def test_uint8_transport_is_bit_identical(case):
     assert torch.equal(ea.forward(f32.cuda(), attr), eb.forward(u8.cuda(), attr))
     with pytest.raises(TypeError):
         eb.forward(u8, attr)                                            # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("bs", [1, 5, 24, 40])
+def test_vitb16_other_batch_sizes_bf16_vs_fp32_engine(bs):
+    """Batch sizes other than the benchmark's: the GEMM selector moves between the panel kernel (one round of tiles;
+    ragged last row tile at 24 x 197 rows) and the 128x128 kernel (bs 40: more than 256 panel tiles; bs 1: 197 rows),
+    and a smaller batch runs inside an engine sized for a larger one."""
+    mcfg = C.vit_b16(rank=8)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, bs, seed=100 + bs, signal=0.2)
+    img, attr, label = to_dev(batch)
+    ref = make_engine(mcfg, sd, torch.float32, bs)
+    eng = make_engine(mcfg, sd, torch.bfloat16, bs + 3)               # max_images larger than the batch
+    o_ref = ref.forward_backward(img, attr, label)
+    o = eng.forward_backward(img, attr, label)
+    torch.cuda.synchronize()
+    assert int(o["finite"]) == 1 and rel(o["logits"], o_ref["logits"]) < 5e-2
+    assert abs(float(o["loss"]) - float(o_ref["loss"])) <= 1e-2 * abs(float(o_ref["loss"]))
+    for k in synth.trainable_keys(mcfg):
+        g, gr = eng.params.view(k, "grad"), ref.params.view(k, "grad")
+        if float(gr.abs().max()) > 0:
+            assert cos(g, gr) > 0.97, (k, cos(g, gr))
+    # the recorded plan replays bit-identically
+    again = eng.forward_backward(img, attr, label)
+    assert torch.equal(again["logits"], o["logits"])
