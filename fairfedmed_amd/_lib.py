@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libffm_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
