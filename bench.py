@@ -142,8 +142,15 @@ def main():
     use_dist = (world > 1 or launched) and not os.environ.get("FFM_BENCH_NO_DIST")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # FFM_BENCH_ONE_DEVICE=1 (test rig only): all ranks share cuda:0 and talk over gloo, so the N > 1 code path
+        # can be exercised on a one-GPU box; the number it prints is meaningless
+        one_dev = bool(os.environ.get("FFM_BENCH_ONE_DEVICE"))
+        if one_dev:
+            local = 0
         torch.cuda.set_device(local)
-        if os.environ.get("FFM_BENCH_LAZY_PG"):
+        if one_dev:
+            dist.init_process_group("gloo")
+        elif os.environ.get("FFM_BENCH_LAZY_PG"):
             dist.init_process_group("nccl")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
