@@ -182,8 +182,13 @@ def main(argv: Optional[List[str]] = None, log=print, cfg_hook=None):
     if ranks and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("FFM_ONE_DEVICE"):                # test rig: every rank on cuda:0, gloo instead of RCCL
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    cfg.DEVICE = f"cuda:{torch.cuda.current_device()}"       # one client per GPU: this rank's device
     if args.seed > 0:                                       # set_random_seed (Dassl/dassl/utils/tools.py)
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)
@@ -207,6 +212,8 @@ def main(argv: Optional[List[str]] = None, log=print, cfg_hook=None):
         cfg.MODEL.STATE_DICT = torch.load(args.state_dict, map_location="cpu")
     else:
         log("NOTE: no --state-dict given and CLIP weights cannot be downloaded here: deterministic synthetic weights")
+    if cfg.MODEL.BACKBONE.NAME in ("tiny", "rn_tiny"):      # reduced geometries for smoke runs (64 x 64 inputs)
+        cfg.MODEL.GEOMETRY = C.vit_tiny() if cfg.MODEL.BACKBONE.NAME == "tiny" else C.rn_tiny()
     if cfg_hook is not None:
         cfg_hook(cfg)
     tr = build_trainer(cfg)

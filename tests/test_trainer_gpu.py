@@ -451,3 +451,29 @@ def test_svlora_linear_vs_reference_golden(golden_dir, dtype):
         assert type(m.image_encoder[0].mlp[0]).__name__ == cls
     with pytest.raises(NotImplementedError):
         apply_lora_to_model(Mdl(), True, lora_type="DoRA")
+
+
+def test_cli_under_torch_distributed_run_two_ranks(tmp_path):
+    """The command line launched as `python -m torch.distributed.run --nproc-per-node 2 -m fairfedmed_amd.federated_main`
+    (one client per rank; here both ranks share the test box's GPU over gloo, FFM_ONE_DEVICE=1): rounds run, ranks agree,
+    rank 0 writes the final global buffer."""
+    import subprocess
+    import sys
+    from fairfedmed_amd import data as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    D.write_synthetic_fairfedmed(str(tmp_path / "DATA"), sites=2, n_train=16, n_test=8, size=64, seed=9)
+    (tmp_path / "tr.yaml").write_text('DATALOADER:\n  TRAIN_X:\n    BATCH_SIZE: 8\n  TEST:\n    BATCH_SIZE: 8\n'
+                                      'INPUT:\n  SIZE: (64, 64)\nMODEL:\n  BACKBONE:\n    NAME: "tiny"\n')
+    out = tmp_path / "out"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29518", "-m", "fairfedmed_amd.federated_main",
+           "--root", str(tmp_path / "DATA"), "--model", "FedOTPLoRA", "--trainer", "GLP_OT_SVLoRA", "--num_users", "2",
+           "--frac", "1.0", "--round", "2", "--OT", "None", "--attribute_type", "race", "--attributes", "race", "gender",
+           "--n_ctx", "4", "--num_prompt", "2", "--unfreeze_image_encoder", "True", "--lora_rank", "4", "--lora_alpha", "2",
+           "--lora_type", "FairLoRA", "--shared_half_s", "True", "--config-file", str(tmp_path / "tr.yaml"),
+           "--output-dir", str(out), "--prec", "fp32"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, FFM_ONE_DEVICE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "global_test_acc_list:" in r.stdout and "round 1:" in r.stdout
+    flat = torch.load(out / "global_flat_final.pth")
+    assert flat.dim() == 1 and flat.numel() > 1000 and bool(torch.isfinite(flat).all())
