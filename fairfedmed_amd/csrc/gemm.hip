@@ -10,6 +10,7 @@
 // to the per-lane SOURCE address (lane -> row r = l>>3, slot p = l&7 reads
 // global chunk p ^ (r&7)) and again on the ds_read side.
 #include "gemm_panel.h"
+#include <cstdlib>
 
 namespace {
 
@@ -548,6 +549,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (ffm_skinny_ok(a, dtype)) {
+        static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
+        if (!off) return ffm_skinny_launch(a, s);
+    }
     if (a.b_packed) {
         const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);

@@ -18,3 +18,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
 int ffm_panel_ds_rows(int M, int N, int cfg);
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s);
 int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s);      // gemm_panel_rk.hip
+
+// gemm_skinny.hip: M <= 64 rows (text tower), bf16, plain epilogues
+bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype);
+int ffm_skinny_launch(const ffm_gemm_args& a, hipStream_t s);

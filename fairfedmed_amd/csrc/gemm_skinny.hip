@@ -1,0 +1,117 @@
+// Skinny GEMM: C = epilogue(A * B^T) for M <= 64 rows (the text tower: 4 prompts x 10 tokens = 40 rows against
+// 512..2048-wide frozen weights).  The 128x128 kernel gives such a product N/128 = 4..16 blocks, each streaming its
+// 128-column slice of the weight serially: 10-22 us of pure latency per launch, 96 launches per step on the side
+// stream.  Here a block owns 16 output columns and ALL rows; its four waves split K, every wave issues the loads of 8
+// K32 steps before the first MFMA, and the partial accumulators meet in LDS: N/16 = 32..128 blocks, 2-5 us.
+// bf16 only (the fp32 parity mode keeps the 128x128 kernel); epilogues: none, bias, bias+residual, bias+GELU, dGELU.
+#include "gemm_panel.h"
+
+namespace {
+
+constexpr int SK_COLS = 16, SK_WAVES = 4, SK_MF = 4, SK_UN = 8;
+
+template <int FL>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
+    __shared__ f32x4 red[SK_WAVES - 1][SK_MF][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * SK_COLS;
+    const int nmf = (p.M + 15) >> 4;                               // 1..4 row fragments (uniform)
+    const int kw = p.K / SK_WAVES, k0 = wave * kw;                 // this wave's K range, a multiple of 32
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a);
+    const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.b) + (size_t)(n0 + col) * p.ldb + k0 + kg * 8;
+    const bf16_t* ap[SK_MF];
+#pragma unroll
+    for (int mf = 0; mf < SK_MF; ++mf) {
+        int row = mf * 16 + col;
+        row = row < p.M ? row : p.M - 1;                           // clamped rows are never stored
+        ap[mf] = A + (size_t)row * p.lda + k0 + kg * 8;
+    }
+    f32x4 acc[SK_MF];
+#pragma unroll
+    for (int mf = 0; mf < SK_MF; ++mf) acc[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < kw; ks += 32 * SK_UN) {
+        bf16x8 bf[SK_UN], af[SK_UN][SK_MF];
+#pragma unroll
+        for (int u = 0; u < SK_UN; ++u) {
+            if (ks + 32 * u < kw) {
+                bf[u] = *reinterpret_cast<const bf16x8*>(bp + ks + 32 * u);
+#pragma unroll
+                for (int mf = 0; mf < SK_MF; ++mf)
+                    if (mf < nmf) af[u][mf] = *reinterpret_cast<const bf16x8*>(ap[mf] + ks + 32 * u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SK_UN; ++u) {
+            if (ks + 32 * u < kw) {
+#pragma unroll
+                for (int mf = 0; mf < SK_MF; ++mf)
+                    if (mf < nmf) Mma16<bf16_t>::mma(acc[mf], af[u][mf], bf[u]);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mf = 0; mf < SK_MF; ++mf)
+            if (mf < nmf) red[wave - 1][mf][lane] = acc[mf];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int n = n0 + col;
+    const float bias = (FL & FFM_EPI_BIAS) ? p.bias[n] : 0.f;
+    bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
+#pragma unroll
+    for (int mf = 0; mf < SK_MF; ++mf) {
+        if (mf >= nmf) break;
+        f32x4 v = acc[mf];
+#pragma unroll
+        for (int w = 0; w < SK_WAVES - 1; ++w) {
+            const f32x4 o = red[w][mf][lane];
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = mf * 16 + 4 * kg + e;
+            if (row >= p.M) continue;
+            const size_t o = (size_t)row * p.ldc + n;
+            float x = v[e] + bias;
+            if (FL & FFM_EPI_RESIDUAL) x += (float)reinterpret_cast<const bf16_t*>(p.res)[o];
+            if (FL & FFM_EPI_DGELU) x *= Act<bf16_t>::gelu_grad((float)reinterpret_cast<const bf16_t*>(p.aux)[o]);
+            C[o] = (bf16_t)x;
+            if (FL & FFM_EPI_GELU) reinterpret_cast<bf16_t*>(p.c2)[o] = (bf16_t)Act<bf16_t>::gelu(x);
+        }
+    }
+}
+
+template <int FL>
+int launch(const ffm_gemm_args& a, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_skinny_kernel<FL>), dim3(a.N / SK_COLS), dim3(SK_WAVES * 64), 0, s, a);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+}  // namespace
+
+bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
+    if (dtype != FFM_BF16 || a.M > 16 * SK_MF || a.N % SK_COLS || a.K % (32 * SK_WAVES)) return false;
+    switch (a.flags) {
+        case 0:
+        case FFM_EPI_BIAS:
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL:
+        case FFM_EPI_BIAS | FFM_EPI_GELU:
+        case FFM_EPI_DGELU: return true;
+    }
+    return false;
+}
+
+int ffm_skinny_launch(const ffm_gemm_args& a, hipStream_t s) {
+    switch (a.flags) {
+        case 0: return launch<0>(a, s);
+        case FFM_EPI_BIAS: return launch<FFM_EPI_BIAS>(a, s);
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL: return launch<FFM_EPI_BIAS | FFM_EPI_RESIDUAL>(a, s);
+        case FFM_EPI_BIAS | FFM_EPI_GELU: return launch<FFM_EPI_BIAS | FFM_EPI_GELU>(a, s);
+        case FFM_EPI_DGELU: return launch<FFM_EPI_DGELU>(a, s);
+    }
+    return FFM_EINVAL;
+}

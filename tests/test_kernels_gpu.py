@@ -514,3 +514,40 @@ def test_casts(ops):
     assert torch.equal(ops.cast_to_f32(x.to(torch.bfloat16)), x.to(torch.bfloat16).float())
     assert torch.equal(ops.transpose_cast(x, torch.bfloat16), x.t().contiguous().to(torch.bfloat16))
     assert torch.equal(ops.transpose_cast(x, torch.float32), x.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 1536, 512), (40, 512, 2048), (40, 2048, 512), (1, 512, 128), (64, 128, 128),
+                                   (33, 48, 640), (8, 512, 512)])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_res", "bias_gelu", "dgelu"])
+def test_skinny_gemm_text_tower_shapes(M, N, K, mode):
+    """gemm_skinny.hip (M <= 64 rows, bf16): the text tower's products and epilogues against fp32 PyTorch on the same
+    bf16 operands; split-K over four waves must not change the result beyond fp32 summation order."""
+    from fairfedmed_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 1000 + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    aux = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    act = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ref = a.float() @ w.float().t()
+    rel = lambda got, want: float((got.double() - want.double()).abs().max() / want.double().abs().max())
+    if mode == "plain":
+        ops.gemm_nt(a, w, out)
+    elif mode == "bias":
+        ops.gemm_nt(a, w, out, bias=bias)
+        ref = ref + bias
+    elif mode == "bias_res":
+        ops.gemm_nt(a, w, out, bias=bias, res=res)
+        ref = ref + bias + res.float()
+    elif mode == "bias_gelu":
+        ops.gemm_nt(a, w, out, bias=bias, gelu_out=act)
+        ref = ref + bias
+        assert rel(act.float(), ref * torch.sigmoid(1.702 * ref)) < 1e-2
+    else:
+        ops.gemm_nt(a, w, out, dgelu_aux=aux)
+        x = aux.float()
+        s = torch.sigmoid(1.702 * x)
+        ref = ref * (s * (1 + 1.702 * x * (1 - s)))
+    assert rel(out.float(), ref) < 1e-2                              # bf16 rounding of the output only
