@@ -139,3 +139,27 @@ def test_trainer_error_conventions_and_single_class_batch():
     cfg3.DATASET.NAME = "ImageNet"
     with pytest.raises(NotImplementedError):
         GLP_OT_SVLoRA(cfg3, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
+
+
+def test_lambda_fairness_changes_the_reported_loss_only():
+    """TRAINER.LAMBDA_FAIRNESS != 0 (trainers/GLP_OT_SVLoRA.py:930-948): the confidence-gap term is
+    built from detached values, so it moves the reported loss and never the gradients."""
+    from oracle import fairlora_oracle as O
+    from tests.test_trainer_gpu import make_cfg
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 8, seed=11)
+    keys = synth.trainable_keys(mcfg)
+    out = {}
+    for lam in (0.0, 0.5):
+        cfg = make_cfg(prec="fp32")
+        cfg.TRAINER.LAMBDA_FAIRNESS = lam
+        cfg.MODEL.STATE_DICT = sd
+        tr = GLP_OT_SVLoRA(cfg, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
+        tr.num_batches, tr.batch_idx = 10, 0
+        s = tr.forward_backward(batch)
+        ref_loss, _, _ = O.loss_and_grads(sd, batch, mcfg, keys, lambda_fairness=lam)
+        assert abs(s["loss"] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)), (lam, s["loss"], float(ref_loss))
+        out[lam] = (s["loss"], tr.engine.params.grad.clone())
+    assert out[0.5][0] > out[0.0][0] and torch.equal(out[0.0][1], out[0.5][1])
