@@ -163,3 +163,30 @@ def test_lambda_fairness_changes_the_reported_loss_only():
         assert abs(s["loss"] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss)), (lam, s["loss"], float(ref_loss))
         out[lam] = (s["loss"], tr.engine.params.grad.clone())
     assert out[0.5][0] > out[0.0][0] and torch.equal(out[0.0][1], out[0.5][1])
+
+
+def test_disable_attr_runs_one_group_without_attributes():
+    """--disable_attr (TRAINER.GLP_OT_LORA.DISABLE_ATTR; trainers/GLP_OT_SVLoRA.py:841, 462): one group, no attribute is
+    handed to the model; loss and gradients equal the oracle's with num_groups = 1 and attr = None."""
+    from oracle import fairlora_oracle as O
+    from tests.test_trainer_gpu import make_cfg
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4, num_groups=1)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(C.vit_tiny(rank=4), 8, seed=11)          # attrs in 0..2 are present but must be ignored
+    cfg = make_cfg(prec="fp32")
+    cfg.TRAINER.GLP_OT_LORA.DISABLE_ATTR = True
+    cfg.MODEL.STATE_DICT = sd
+    tr = GLP_OT_SVLoRA(cfg, data=SyntheticFedData(C.vit_tiny(rank=4), 1, 1, 1, 8))
+    assert tr.engine.cfg.lora.num_groups == 1
+    tr.num_batches, tr.batch_idx = 10, 0
+    p0 = tr.engine.params.flat.clone()
+    s = tr.forward_backward(batch)
+    keys = synth.trainable_keys(mcfg)
+    ref_loss, _, grads = O.loss_and_grads(sd, {"img": batch["img"], "label": batch["label"], "attrs": None}, mcfg, keys)
+    assert abs(s["loss"] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    for k in keys:
+        g = tr.engine.params.view(k, "grad")
+        if float(grads[k].abs().max()) > 0:
+            assert rel(g, grads[k]) < 2e-3, k
+    assert not torch.equal(p0, tr.engine.params.flat)                  # the SGD step ran
