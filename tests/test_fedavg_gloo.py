@@ -233,3 +233,35 @@ def test_compat_sequential_optimizer_reproduces_the_shared_optimizer_across_rank
     used = ref != 0
     assert torch.allclose(on[0][used], ref[used], rtol=1e-5, atol=1e-7)
     assert not torch.allclose(off[0][used], ref[used], rtol=1e-3, atol=1e-5)
+
+
+def _pers_worker(rank, world, port, outdir):
+    from fairfedmed_amd import federated as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = F.FedArgs(num_users=3, round=3, shared_half_s=True, seed=5, idxs_users_train=[0, 2], local_s=True,
+                     avg_prompt=1, num_prompt=2)
+    hist = F.run_fedotplora_ranks(_FlatTrainer(3), args, log=lambda *_: None)
+    torch.save({"flat": hist["global_flat"], "acc": hist["acc"]}, os.path.join(outdir, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_personalised_clients_over_two_ranks_equal_the_single_process_driver():
+    """--idxs_users_train with LOCAL_S (federated_main.py:645-652): only clients 0 and 2 train, each keeps its own local
+    prompts ctx[avg_prompt:] and lora_S; every client is evaluated with its personalised weights.  The rank-parallel
+    driver must report the same per-round scores (they depend on the personalised weights) and the same global."""
+    from fairfedmed_amd import federated as F
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_pers_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, f"p{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"]) and got[0]["acc"] == got[1]["acc"]
+    tr = _FlatTrainer(3)
+    args = F.FedArgs(num_users=3, round=3, shared_half_s=True, seed=5, idxs_users_train=[0, 2], local_s=True,
+                     avg_prompt=1, num_prompt=2)
+    hist = F.run_fedotplora(tr, args, log=lambda *_: None)
+    p = tr.engine.params
+    for k, v in hist["global_weights"].items():
+        o, s = p.offsets[k]
+        ref = v.reshape(-1)
+        assert torch.allclose(got[0]["flat"][o:o + ref.numel()], ref, rtol=1e-5, atol=1e-7), k
+    assert all(abs(a - b) < 1e-6 for a, b in zip(got[0]["acc"], hist["acc"])), (got[0]["acc"], hist["acc"])
