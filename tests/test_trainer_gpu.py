@@ -477,3 +477,26 @@ def test_cli_under_torch_distributed_run_two_ranks(tmp_path):
     assert "global_test_acc_list:" in r.stdout and "round 1:" in r.stdout
     flat = torch.load(out / "global_flat_final.pth")
     assert flat.dim() == 1 and flat.numel() > 1000 and bool(torch.isfinite(flat).all())
+
+
+def test_rn_state_dict_keys_order_dtypes_and_live_buffers():
+    """CustomCLIP over the RN50 engine: state_dict() has the reference ResNet's keys in ITS order (tests/golden/
+    make_golden.py asserts manifest order == the imported reference's), BatchNorm counters are int64, running
+    statistics are live views of the engine's buffers."""
+    from fairfedmed_amd.model import CustomCLIP
+    mcfg = C.rn_tiny(rank=4, num_groups=2)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    model = CustomCLIP(mcfg, sd, dtype=torch.float32, max_images=6)
+    got = model.state_dict()
+    man = synth.manifest(mcfg)
+    assert list(got.keys()) == list(man.keys())
+    for k, shp in man.items():
+        assert tuple(got[k].shape) == tuple(shp), k
+        assert got[k].dtype == (torch.int64 if k.endswith("num_batches_tracked") else torch.float32), k
+    assert {n for n, p in model.named_parameters() if p.requires_grad} == set(synth.trainable_keys(mcfg))
+    assert {n for n, _ in model.named_buffers()} >= set(synth.buffer_keys(mcfg))
+    b = synth.make_batch(mcfg, 6, seed=3)
+    model.engine.forward_backward(b["img"].cuda(), b["attrs"].t()[0].cuda(), b["label"].cuda())
+    after = model.state_dict()
+    k = "image_encoder.layer1.0.bn1.running_mean"
+    assert float(after[k].abs().max()) > 0 and int(after["image_encoder.bn1.num_batches_tracked"]) == 1
