@@ -254,3 +254,32 @@ def test_vitb16_other_batch_sizes_bf16_vs_fp32_engine(bs):
     # the recorded plan replays bit-identically
     again = eng.forward_backward(img, attr, label)
     assert torch.equal(again["logits"], o["logits"])
+
+
+@pytest.mark.parametrize("kind", ["vitb_bf16", "rn_tiny_bf16", "oct3d_f32"])
+def test_training_is_bit_reproducible_across_engines_and_streams(kind):
+    """Every float reduction is a fixed-order tree (no atomics) and the three HIP streams are ordered by events: two
+    engines built from the same state_dict must produce bit-identical losses, gradients and weights over several steps
+    (a missing stream dependency or a racy reduction would show up here as a difference)."""
+    from fairfedmed_amd.engine_rn import create_engine
+    if kind == "vitb_bf16":
+        mcfg, bs, dt, steps = C.vit_b16(rank=8), 32, torch.bfloat16, 4
+    elif kind == "rn_tiny_bf16":
+        mcfg, bs, dt, steps = C.rn_tiny(rank=4, num_groups=2), 6, torch.bfloat16, 4
+    else:
+        mcfg, bs, dt, steps = C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 3, torch.float32, 3
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, bs, seed=5, signal=0.2)
+    img, attr, label = to_dev(batch)
+    runs = []
+    for _ in range(2):
+        eng = create_engine(mcfg, sd, dtype=dt, max_images=vit_images(mcfg, bs))
+        losses = []
+        for _ in range(steps):
+            out = eng.forward_backward(img, attr, label)
+            losses.append(out["loss"].clone())
+            eng.sgd_step(1e-3, 0.9, 5e-4)
+        torch.cuda.synchronize()
+        runs.append((torch.cat(losses), eng.params.grad.clone(), eng.params.flat.clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
