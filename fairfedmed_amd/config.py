@@ -115,6 +115,13 @@ class ModelCfg:
     # 3D OCT: slices are grouped by `dim_per_3d_slice` channels
     # (trainers/GLP_OT_SVLoRA.py:585-595); 0 = 2D input.
     dim_per_3d_slice: int = 0
+    # logits head (TRAINER.GLP_OT.OT): 'None' (every FairLoRA script), 'Sinkhorn' or 'COT' with the plan's
+    # parameters EPS / THRESH / MAX_ITER / TOP_PERCENT (trainers/GLP_OT_SVLoRA.py:604-613)
+    ot: str = "None"
+    ot_eps: float = 0.1
+    ot_thresh: float = 1e-3
+    ot_max_iter: int = 100
+    ot_top_percent: float = 1.0
 
     def to_dict(self):
         return asdict(self)

@@ -299,9 +299,39 @@ def preprocess(sd: Dict[str, Tensor], image: Tensor, cfg) -> Tensor:
     return (x - mean) / std
 
 
+def sinkhorn_plan(K: Tensor, u: Tensor, v: Tensor, thresh: float, max_iter: int) -> Tensor:
+    """CustomCLIP.Sinkhorn (trainers/GLP_OT_SVLoRA.py:615-634): K [P, M, N], u [P, M], v [P, N]; ONE stopping test for
+    the whole batch (the mean of |r - r0| over all P problems)."""
+    r, c = torch.ones_like(u), torch.ones_like(v)
+    for _ in range(max_iter):
+        r0 = r
+        r = u / torch.matmul(K, c.unsqueeze(-1)).squeeze(-1)
+        c = v / torch.matmul(K.permute(0, 2, 1).contiguous(), r.unsqueeze(-1)).squeeze(-1)
+        if float((r - r0).abs().mean()) < thresh:
+            break
+    return torch.matmul(r.unsqueeze(-1), c.unsqueeze(-2)) * K
+
+
+def cot_plan(a: Tensor, b: Tensor, K: Tensor, thresh: float, max_iter: int) -> Tensor:
+    """CustomCLIP.entropic_COT_fast (:636-675): the partial-transport scaling iterations on the Gibbs kernel K."""
+    dx, dy = torch.ones_like(a), torch.ones_like(b)
+    Kp = torch.matmul(torch.diag_embed(1 / a, dim1=1), K)
+    Kq = torch.matmul(torch.diag_embed(1 / b, dim1=1), K.permute(0, 2, 1))
+    u, v, cpt = dx, dy, 0
+    while cpt < max_iter:
+        v0 = v
+        u = torch.minimum(torch.div(dx, torch.matmul(Kp, v.unsqueeze(-1)).squeeze(-1)), dx)
+        v = torch.div(dy, torch.matmul(Kq, u.unsqueeze(-1)).squeeze(-1))
+        cpt += 1
+        if float((v - v0).abs().mean()) < thresh:
+            break
+    return torch.matmul(torch.matmul(torch.diag_embed(u, dim1=1), K), torch.diag_embed(v, dim1=1))
+
+
 def clip_logits(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cfg, training: bool = True) -> Tensor:
-    """CustomCLIP.forward with OT='None' (trainers/GLP_OT_SVLoRA.py:677-763).  `training` only matters for the
-    BatchNorm layers of the RN50 trunk."""
+    """CustomCLIP.forward (trainers/GLP_OT_SVLoRA.py:677-763) with cfg.ot in {'None', 'Sinkhorn', 'COT'}; the
+    transport plan is built under no_grad, as in the reference.  `training` only matters for the BatchNorm layers of
+    the RN50 trunk."""
     b = image.shape[0]
     x = preprocess(sd, image, cfg)
     feats = vision_forward(sd, x, attr, cfg, training)              # [L, B*S, d]
@@ -312,7 +342,23 @@ def clip_logits(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor], cf
     text = F.normalize(text, dim=2)
     sim = torch.einsum("mbd,ncd->mnbc", feats, text).contiguous()
     sim = sim.view(M, cfg.n_prompts, -1).permute(2, 0, 1)          # [B*S*n_cls, M, N]
-    sim_op = sim.mean(dim=(1, 2))
+    ot = getattr(cfg, "ot", "None")
+    if ot == "None":
+        sim_op = sim.mean(dim=(1, 2))
+    else:
+        N = cfg.n_prompts
+        xx = torch.full((sim.shape[0], M), 1.0 / M, dtype=sim.dtype)
+        yy = torch.full((sim.shape[0], N), 1.0 / N, dtype=sim.dtype)
+        with torch.no_grad():
+            KK = torch.exp(-(1.0 - sim) / cfg.ot_eps)
+            if ot == "Sinkhorn":
+                T = sinkhorn_plan(KK, xx, yy, cfg.ot_thresh, cfg.ot_max_iter)
+            elif ot == "COT":
+                yy = yy * min(float(torch.sum(xx)), cfg.ot_top_percent)           # (:724-726)
+                T = cot_plan(xx, yy, KK, cfg.ot_thresh, cfg.ot_max_iter)
+            else:
+                raise NotImplementedError(ot)
+        sim_op = torch.sum(T * sim, dim=(1, 2))
     sim_op = sim_op.contiguous().view(b, -1, cfg.n_cls).mean(1)     # average the slices (:753-754)
     return sd["logit_scale"].exp() * sim_op
 

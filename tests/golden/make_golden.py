@@ -91,14 +91,15 @@ from fairfedmed_amd import synth            # noqa: E402
 
 
 def ref_cfg(mcfg: C.ModelCfg, lambda_fairness=0.0):
+    ot = NS(EPS=mcfg.ot_eps, THRESH=mcfg.ot_thresh, OT=mcfg.ot, TOP_PERCENT=mcfg.ot_top_percent, MAX_ITER=mcfg.ot_max_iter)
     return NS(
         INPUT=NS(PIXEL_MEAN=list(mcfg.pixel_mean), PIXEL_STD=list(mcfg.pixel_std),
                  SIZE=(mcfg.vision.image_size, mcfg.vision.image_size)),
         DATASET=NS(NAME="FairFedMed", MODALITY_TYPE="slo_fundus" if not mcfg.dim_per_3d_slice else "oct_bscans",
                    DIM_PER_3D_SLICE=mcfg.dim_per_3d_slice, ATTRIBUTES=["race"], ATTRIBUTE_TYPE="race"),
         TRAINER=NS(GLP_OT=NS(N_CTX=mcfg.n_ctx, CTX_INIT=False, CSC=False, N=mcfg.n_prompts,
-                             CLASS_TOKEN_POSITION="end", EPS=0.1, THRESH=1e-3, OT="None",
-                             TOP_PERCENT=1.0, MAX_ITER=100, PREC="fp32"),
+                             CLASS_TOKEN_POSITION="end", EPS=ot.EPS, THRESH=ot.THRESH, OT=ot.OT,
+                             TOP_PERCENT=ot.TOP_PERCENT, MAX_ITER=ot.MAX_ITER, PREC="fp32"),
                    GLP_OT_LORA=NS(DISABLE_ATTR=False),
                    LAMBDA_FAIRNESS=lambda_fairness),
     )
@@ -219,6 +220,19 @@ def golden_lora_plain(M, out):
     out["lora_plain.dA"] = layer.lora_A.weight.grad.numpy()
     out["lora_plain.dB"] = layer.lora_B.weight.grad.numpy()
     out["lora_plain.weight"] = layer.weight(x).detach().numpy()
+
+
+def golden_ot(M, CLIP):
+    """The Sinkhorn / COT logits heads (trainers/GLP_OT_SVLoRA.py:615-675, 713-757) on the tiny ViT: logits, loss, all
+    gradients and a 3-step trajectory per head.  Written to tests/golden/ot.npz + ot.json."""
+    import dataclasses
+    out, meta = {}, {}
+    for ot, top in (("Sinkhorn", 1.0), ("COT", 0.8)):
+        mcfg = dataclasses.replace(C.vit_tiny(rank=4), ot=ot, ot_top_percent=top)
+        golden_model(M, CLIP, mcfg, f"ot_{ot.lower()}", 8, 3, out, meta)
+    np.savez_compressed(os.path.join(HERE, "ot.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "ot.json"), "w"), indent=1, sort_keys=True)
+    print("ot.npz:", len(out), "arrays")
 
 
 def golden_svlora():
@@ -424,6 +438,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.json only")
     ap.add_argument("--only-svlora", action="store_true", help="regenerate tests/golden/svlora.npz only")
+    ap.add_argument("--only-ot", action="store_true", help="regenerate tests/golden/ot.npz (Sinkhorn / COT heads) only")
     ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
     ap.add_argument("--time-ref", action="store_true", help="time the reference CPU step at bs=32")
     args = ap.parse_args()
@@ -435,6 +450,9 @@ def main():
         return
     if args.only_svlora:
         golden_svlora()
+        return
+    if args.only_ot:
+        golden_ot(M, CLIP)
         return
     golden_dataset()
     golden_svlora()

@@ -176,3 +176,27 @@ def test_vitb_step(golden_dir, meta):
         n = float(grads[k].norm())
         ref = meta["vitb_r8.grad_norms"][k]
         assert abs(n - ref) <= 1e-3 * ref + 1e-9, (k, n, ref)
+
+
+@pytest.mark.parametrize("ot,top", [("Sinkhorn", 1.0), ("COT", 0.8)])
+def test_ot_heads_step_and_trajectory(golden_dir, ot, top):
+    """The Sinkhorn / COT logits heads (trainers/GLP_OT_SVLoRA.py:615-675, 713-757): the
+    oracle's restatement against the imported reference's logits, loss, gradients and 3-step trajectory."""
+    import dataclasses
+    import json
+    gold = np.load(os.path.join(golden_dir, "ot.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "ot.json")))
+    tag = f"ot_{ot.lower()}"
+    mcfg = dataclasses.replace(C.vit_tiny(rank=4), ot=ot, ot_top_percent=top)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 8, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    close(logits.numpy(), gold[f"{tag}.logits"], rtol=1e-5, atol=1e-6, what="logits")
+    assert abs(float(loss) - meta[f"{tag}.loss0"]) <= 1e-5 * abs(meta[f"{tag}.loss0"])
+    for k in keys:
+        close(grads[k].numpy(), gold[f"{tag}.grad.{k}"], rtol=1e-4, atol=2e-6, what=k)
+    opt = O.SgdState()
+    for ref in meta[f"{tag}.traj"]:
+        s, _, _ = O.train_step(sd, opt, batch, mcfg, keys)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"]), (s, ref)
