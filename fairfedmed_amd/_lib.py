@@ -73,6 +73,8 @@ SIGNATURES = {
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "ffm_ot_head_fwd": [_vp] * 10 + [_i32] * 6 + [_f32, _f32, _i32, _f32, _i32, _vp],
+    "ffm_ot_head_bwd": [_vp] * 8 + [_i32] * 6 + [_vp],
     "ffm_expand_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

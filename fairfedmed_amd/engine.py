@@ -209,6 +209,22 @@ class FairLoRAEngine:
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
         self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+        self.ot = cfg.ot if cfg.ot != "None" else None
+        if self.ot:
+            # Sinkhorn / COT logits heads (trainers/GLP_OT_SVLoRA.py:615-675, 713-757; csrc/head_ot.hip)
+            if self.ot not in ops.OT_MODES:
+                raise NotImplementedError(cfg.ot)
+            if cfg.dim_per_3d_slice:
+                raise NotImplementedError("the transport heads are built for 2D inputs")
+            P, M, N = max_images * cfg.n_cls, v.tokens - 1, cfg.n_prompts
+            self.tn_buf = torch.zeros(N * cfg.n_cls, v.out_dim, device=dev, dtype=f32)
+            self.dtn = torch.zeros_like(self.tn_buf)
+            self.ot_sim = torch.zeros(P * M * N, device=dev, dtype=f32)
+            self.ot_T = torch.zeros_like(self.ot_sim)
+            self.ot_errs = torch.zeros(cfg.ot_max_iter * P, device=dev, dtype=f32)
+            self.ot_istop = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.ot_tsum = torch.zeros(P, device=dev, dtype=f32)
+            self.ot_dtn_part = torch.zeros(max_images * N * cfg.n_cls * v.out_dim, device=dev, dtype=f32)
         self.step_plans: Dict[tuple, list] = {}
         self.use_replay = True                        # replay recorded launch plans (host-side "graph")
         self.eot_rows = torch.tensor([i * self.txt_len + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
@@ -538,7 +554,8 @@ class FairLoRAEngine:
         self.txt.x[0][:rows].copy_(prompts.reshape(rows, t.width))
 
     def _text_glue_out(self, with_grad: bool) -> None:
-        """EOT gather, ln_final, projection, normalise, mean over prompts -> tbar_buf [n_cls, D]
+        """EOT gather, ln_final, projection, normalise (, mean over prompts) -> tbar_buf [n_cls, D], or with a transport
+        head every prompt's normalised feature tn_buf [N*n_cls, D]
         (trainers/GLP_OT_SVLoRA.py:62-64, 709-715).  4 rows: PyTorch glue, with autograd for the way back."""
         cfg, t = self.cfg, self.cfg.text
         rows = self.n_text * self.txt_len
@@ -548,13 +565,14 @@ class FairLoRAEngine:
                 xe.requires_grad_(True)
             y = torch.nn.functional.layer_norm(xe, (t.width,), self.lnfinal[0], self.lnfinal[1], 1e-5)
             tf = (y @ self.text_proj).view(cfg.n_prompts, cfg.n_cls, -1)
-            tbar = torch.nn.functional.normalize(tf, dim=2).mean(0)
-        self._tbar, self._xe = tbar, xe
-        self.tbar_buf.copy_(tbar.detach())
+            tn = torch.nn.functional.normalize(tf, dim=2)
+            tout = tn.reshape(cfg.n_prompts * cfg.n_cls, -1) if self.ot else tn.mean(0)
+        self._tbar, self._xe = tout, xe
+        (self.tn_buf if self.ot else self.tbar_buf).copy_(tout.detach())
 
     def _text_glue_back_in(self) -> None:
         rows = self.n_text * self.txt_len
-        self._tbar.backward(self.dtbar)
+        self._tbar.backward(self.dtn if self.ot else self.dtbar)
         g = self.txt.g[:rows]
         g.zero_()
         g[self.eot_rows] = self._xe.grad.to(self.dtype)
@@ -648,8 +666,28 @@ class FairLoRAEngine:
         ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows])
         if wait is not None:
             self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
-        ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
-                     images, L, cfg.n_cls)
+        self._head_forward(rows, images, L)
+
+    def _head_forward(self, rows: int, images: int, L: int) -> None:
+        cfg = self.cfg
+        if self.ot:
+            ops.ot_head_fwd(self.feat[:rows], self.tn_buf, self.logit_scale, self.rnorm, self.ot_sim, self.ot_T, self.ot_errs,
+                            self.ot_istop, self.ot_tsum, self.logits_img, images, L, cfg.n_cls, cfg.n_prompts, self.ot,
+                            cfg.ot_eps, cfg.ot_thresh, cfg.ot_max_iter, cfg.ot_top_percent)
+        else:
+            ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
+                         images, L, cfg.n_cls)
+
+    def _head_backward(self, rows: int, images: int, L: int) -> None:
+        cfg = self.cfg
+        if self.ot:
+            P = cfg.n_prompts * cfg.n_cls
+            ops.ot_head_bwd(self.feat[:rows], self.tn_buf, self.logit_scale, self.rnorm, self.ot_T, self.dlogits_img,
+                            self.dfeat[:rows], self.ot_dtn_part, images, L, cfg.n_cls, cfg.n_prompts)
+            ops.reduce_partials(self.ot_dtn_part, images, P * self.cfg.vision.out_dim, self.dtn.view(-1))
+        else:
+            ops.head_bwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
+                         self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
 
     def _vision_backward(self, b: int, S: int, has_attr: bool) -> None:
         """dfeat -> gradients of every trainable tensor of the image side (params.grad)."""
@@ -691,8 +729,7 @@ class FairLoRAEngine:
         self._vision_forward(b, S, has_attr, wait=self.ev_text_fwd)
         ops.ce_loss(self.logits_img, self.label_buf, self.logits, self.prob, self.loss, self.dlogits_img,
                     self.finite, b, S, cfg.n_cls)
-        ops.head_bwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.dlogits_img,
-                     self.dfeat[:rows], self.dtbar, images, L, cfg.n_cls)
+        self._head_backward(rows, images, L)
         self._ev_record(self.ev_head_bwd, main)
         self._ev_wait(self.side, self.ev_head_bwd)
         with self._on(self.side):

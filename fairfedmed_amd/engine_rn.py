@@ -421,8 +421,7 @@ class RN50Engine(FairLoRAEngine):
         self.ap["c"].fwd(self.att_o[:rows], W["ap_c"], self.feat[:rows], None, L, bias=W["ap_cb"])
         if wait is not None:
             self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
-        ops.head_fwd(self.feat[:rows], self.tbar_buf, self.logit_scale, self.fbar, self.rnorm, self.logits_img,
-                     b, L, cfg.n_cls)
+        self._head_forward(rows, b, L)
 
     # --------------------------------------------------------------- backward --
     def _vision_backward(self, b: int, S: int, has_attr: bool) -> None:

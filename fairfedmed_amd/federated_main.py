@@ -11,7 +11,7 @@ One process: the reference's sequential round loop (``federated.run_fedotplora``
 ``python -m torch.distributed.run --nproc-per-node N`` the clients of a round are dealt to the ranks and the round
 ends in one all-reduce (``federated.run_fedotplora_ranks``; ``--compat-sequential-optimizer`` restores the
 reference's shared optimizer).  Only the branch the FairLoRA scripts use is built: ``--model FedOTPLoRA``,
-``--trainer GLP_OT_SVLoRA``, ``--OT None``; anything else raises NotImplementedError.
+``--trainer GLP_OT_SVLoRA`` (``--OT None | Sinkhorn | COT``); anything else raises NotImplementedError.
 
 Differences a user must know (no network in the build image): pretrained CLIP weights are not downloaded - pass
 ``--state-dict file.pt`` (a CustomCLIP state_dict) or the deterministic synthetic weights are used; ``--synthetic``
@@ -159,8 +159,8 @@ def check_scope(args, cfg) -> None:
         raise NotImplementedError(f"--model {args.model}: only the FedOTPLoRA branch (federated_main.py:604-726) is built")
     if cfg.TRAINER.NAME != "GLP_OT_SVLoRA":
         raise NotImplementedError(f"--trainer {cfg.TRAINER.NAME}: only GLP_OT_SVLoRA is built")
-    if str(args.OT) != "None":
-        raise NotImplementedError(f"--OT {args.OT}: the FairLoRA scripts run with OT=None; Sinkhorn / COT heads are not built")
+    if str(args.OT) not in ("None", "Sinkhorn", "COT"):
+        raise NotImplementedError(f"--OT {args.OT}: choose None (the FairLoRA scripts), Sinkhorn or COT")
     if not args.unfreeze_image_encoder:
         raise NotImplementedError("--unfreeze_image_encoder must be set: without it no FairLoRA adapter is injected")
 

@@ -339,6 +339,28 @@ def attnpool_tokens(inp: Tensor, pos: Optional[Tensor], out: Tensor, B: int, HW:
           L.dtype_code(inp.dtype), L.stream_ptr())
 
 
+OT_MODES = {"Sinkhorn": 1, "COT": 2}
+
+
+def ot_head_fwd(f: Tensor, tn: Tensor, logit_scale: Tensor, rnorm: Tensor, sim: Tensor, T: Tensor, errs: Tensor,
+                istop: Tensor, tsum: Tensor, logits_img: Tensor, B: int, Ltok: int, n_cls: int, N: int, mode: str,
+                eps: float, thresh: float, max_iter: int, top_percent: float) -> None:
+    _dev(f, tn, logit_scale, rnorm, sim, T, errs, istop, tsum, logits_img)
+    assert f.is_contiguous() and tn.is_contiguous() and istop.dtype == torch.int32
+    _call("ffm_ot_head_fwd", L.ptr(f), L.ptr(_f32(tn)), L.ptr(_f32(logit_scale)), L.ptr(_f32(rnorm)), L.ptr(_f32(sim)),
+          L.ptr(_f32(T)), L.ptr(_f32(errs)), L.ptr(istop), L.ptr(_f32(tsum)), L.ptr(_f32(logits_img)), B, Ltok, f.shape[1],
+          n_cls, N, OT_MODES[mode], eps, thresh, max_iter, top_percent, L.dtype_code(f.dtype), L.stream_ptr())
+
+
+def ot_head_bwd(f: Tensor, tn: Tensor, logit_scale: Tensor, rnorm: Tensor, T: Tensor, dlogits_img: Tensor, df: Tensor,
+                dtn_part: Tensor, B: int, Ltok: int, n_cls: int, N: int) -> None:
+    _dev(f, tn, logit_scale, rnorm, T, dlogits_img, df, dtn_part)
+    assert f.is_contiguous() and df.is_contiguous() and f.dtype == df.dtype
+    _call("ffm_ot_head_bwd", L.ptr(f), L.ptr(_f32(tn)), L.ptr(_f32(logit_scale)), L.ptr(_f32(rnorm)), L.ptr(_f32(T)),
+          L.ptr(_f32(dlogits_img)), L.ptr(df), L.ptr(_f32(dtn_part)), B, Ltok, f.shape[1], n_cls, N, L.dtype_code(f.dtype),
+          L.stream_ptr())
+
+
 def expand_u8(src: Tensor, dst: Tensor, rep: int) -> Tensor:
     """uint8 [B, C1, H, W] -> fp32 [B, C1*rep, H, W] with each channel repeated rep times (ffm_expand_u8)."""
     _dev(src, dst)

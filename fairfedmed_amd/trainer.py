@@ -136,6 +136,9 @@ class GLP_OT_SVLoRA:
         disable = getattr(lora, "DISABLE_ATTR", False)
         G = 1 if disable else len(self.retrieval_attributes(cfg.DATASET.ATTRIBUTE_TYPE))
         names = list(self.dm.dataset.classnames)
+        got = cfg.TRAINER.GLP_OT
+        if str(got.OT) not in ("None", "Sinkhorn", "COT"):
+            raise NotImplementedError(got.OT)                       # trainers/GLP_OT_SVLoRA.py:729-730
         try:
             eot = tuple(KNOWN_EOT[n.replace("_", " ")] for n in names)
         except KeyError as e:
@@ -149,7 +152,9 @@ class GLP_OT_SVLoRA:
                           lora=C.LoraCfg(rank=lora.RANK, alpha=lora.ALPHA, num_groups=G),
                           n_prompts=cfg.TRAINER.GLP_OT.N, n_ctx=cfg.TRAINER.GLP_OT.N_CTX, n_cls=len(names), eot=eot,
                           pixel_mean=tuple(cfg.INPUT.PIXEL_MEAN), pixel_std=tuple(cfg.INPUT.PIXEL_STD),
-                          dim_per_3d_slice=cfg.DATASET.DIM_PER_3D_SLICE if is_3d else 0)
+                          dim_per_3d_slice=cfg.DATASET.DIM_PER_3D_SLICE if is_3d else 0,
+                          ot=str(got.OT), ot_eps=float(getattr(got, "EPS", 0.1)), ot_thresh=float(getattr(got, "THRESH", 1e-3)),
+                          ot_max_iter=int(getattr(got, "MAX_ITER", 100)), ot_top_percent=float(getattr(got, "TOP_PERCENT", 1.0)))
 
     # ------------------------------------------------------------- model --
     def build_model(self):

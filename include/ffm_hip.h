@@ -334,6 +334,24 @@ int ffm_eval_counts(const float* prob, const int64_t* label, const int64_t* attr
                     void* stream);
 
 /*
+ * Logits heads with a transport plan, TRAINER.GLP_OT.OT = 'Sinkhorn' (mode 1) / 'COT' (mode 2)
+ * (trainers/GLP_OT_SVLoRA.py:615-675, 713-757).  f: [B*L, D] dtype (token 0 of every image is dropped), tn: fp32
+ * [N*n_cls, D] L2-normalised text features, row n*n_cls + c.  Per problem p = b*n_cls + c over M = L-1 tokens:
+ *   sim [P][M][N] cosine similarities, K = exp(-(1 - sim)/eps), T [P][M][N] = plan after the iteration at which the
+ *   batch-mean change of the iterate first drops below thresh (<= max_iter; ONE stopping index for the whole batch,
+ *   as in the reference), logits_img[b][c] = exp(logit_scale) * sum T * sim.
+ * Saved for the backward: rnorm [B*L], T.  Scratch: sim, errs [max_iter][P], istop [1], tsum [P].
+ * Backward (T is a constant, the reference builds it under no_grad): df [B*L, D] dtype and the per-image partials
+ * dtn_part [B][N*n_cls][D] of d tn (reduce over B with ffm_reduce_partials).  L-1 <= 256, N <= 8, n_cls <= 8, D <= 1024.
+ */
+int ffm_ot_head_fwd(const void* f, const float* tn, const float* logit_scale, float* rnorm, float* sim, float* T,
+                    float* errs, int32_t* istop, float* tsum, float* logits_img, int B, int L, int D, int n_cls,
+                    int N, int mode, float eps, float thresh, int max_iter, float top_percent, int dtype, void* stream);
+int ffm_ot_head_bwd(const void* f, const float* tn, const float* logit_scale, const float* rnorm, const float* T,
+                    const float* dlogits_img, void* df, float* dtn_part, int B, int L, int D, int n_cls, int N,
+                    int dtype, void* stream);
+
+/*
  * torch.optim.SGD(momentum, weight_decay, dampening=0) over one flat fp32
  * buffer (Dassl/dassl/optim/optimizer.py:105-113): d = g + wd*p;
  * buf = first_step ? d : mu*buf + d; p -= lr*buf.

@@ -242,7 +242,7 @@ def test_cli_flags_config_tree_and_scope(tmp_path):
     lo = cfg.TRAINER.GLP_OT_LORA
     assert (lo.RANK, lo.ALPHA, lo.TYPE, lo.UNFREEZE_IMAGE_ENCODER) == (12, 2.0, "FairLoRA", True)
     assert cfg.TRAINER.GLP_OT.N == 2 and cfg.TRAINER.GLP_OT.N_CTX == 4 and cfg.DATASET.ATTRIBUTE_TYPE == "language"
-    for bad in (["--model", "fedavg"], ["--OT", "COT"], ["--trainer", "PromptFL"]):
+    for bad in (["--model", "fedavg"], ["--OT", "Wasserstein"], ["--trainer", "PromptFL"]):
         a = FM.build_parser().parse_args(argv + bad)
         with pytest.raises(NotImplementedError):
             FM.check_scope(a, FM.setup_cfg(a))
