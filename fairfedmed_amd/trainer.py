@@ -295,11 +295,44 @@ class GLP_OT_SVLoRA:
         os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
         torch.save(sd, filename)
 
+    def save_model(self, epoch, directory, is_best=False, model_name=""):
+        """Per registered model a checkpoint `<directory>/<name>/model.pth.tar-<epoch+1>` with the sub-module's state_dict,
+        the epoch and the shared optimizer / scheduler state (Dassl/dassl/engine/trainer.py:149-175,
+        Dassl/dassl/utils/torchtools.py:27-80); `is_best` also writes `model-best.pth.tar`."""
+        mom, scal = self.optimizer_state()
+        for name in self.get_model_names():
+            d = os.path.join(directory, name)
+            os.makedirs(d, exist_ok=True)
+            ckpt = {"state_dict": OrderedDict((k, v.detach().cpu()) for k, v in self._models[name].state_dict().items()),
+                    "epoch": epoch + 1, "optimizer": {"momentum": mom.detach().cpu(), "scalars": scal.cpu()},
+                    "scheduler": {"last_epoch": self.sched.last_epoch}}
+            path = os.path.join(d, model_name or f"model.pth.tar-{epoch + 1}")
+            torch.save(ckpt, path)
+            if is_best:
+                torch.save(ckpt, os.path.join(d, "model-best.pth.tar"))
+
     def load_model(self, directory, epoch=None):
+        """trainers/GLP_OT_SVLoRA.py:1023-1053: `<directory>/<name>/model-best.pth.tar` (or `model.pth.tar-<epoch>`) for
+        every registered model; the fixed token vectors are ignored; load_state_dict(strict=False)."""
         if not directory:
             print("Note that load_model() is skipped as no pretrained model is given")
             return
-        raise FileNotFoundError(f'Model not found at "{directory}"')
+        model_file = "model-best.pth.tar" if epoch is None else "model.pth.tar-" + str(epoch)
+        frozen_changed = False
+        train = set(self.engine.params.keys)
+        for name in self.get_model_names():
+            path = os.path.join(directory, name, model_file)
+            if not os.path.exists(path):
+                raise FileNotFoundError('Model not found at "{}"'.format(path))
+            ckpt = torch.load(path, map_location="cpu")
+            sd = ckpt["state_dict"]
+            for k in ("token_prefix", "token_suffix"):
+                sd.pop(k, None)
+            print('Loading weights to {} from "{}" (epoch = {})'.format(name, path, ckpt["epoch"]))
+            self._models[name].load_state_dict(sd, strict=False)
+            frozen_changed |= any(f"{name}.{k}" not in train for k in sd)
+        if frozen_changed:                                            # rebuild the compute-dtype copies of frozen tensors
+            self.engine.load_frozen(self.model.state_dict())
 
     def fed_before_train(self, is_global=False):
         self.start_epoch = 0

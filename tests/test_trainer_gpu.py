@@ -500,3 +500,32 @@ def test_rn_state_dict_keys_order_dtypes_and_live_buffers():
     after = model.state_dict()
     k = "image_encoder.layer1.0.bn1.running_mean"
     assert float(after[k].abs().max()) > 0 and int(after["image_encoder.bn1.num_batches_tracked"]) == 1
+
+
+def test_save_model_load_model_round_trip(tmp_path):
+    """Dassl's checkpoint layout (`<dir>/<name>/model.pth.tar-<epoch>`, `model-best.pth.tar`) and the trainer's
+    load_model hook (trainers/GLP_OT_SVLoRA.py:1023-1053): a trained trainer's weights come back in a fresh one and
+    give the same logits; the fixed token vectors are not taken from the file; a missing file raises."""
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4)
+    data = SyntheticFedData(mcfg, 1, 3, 1, 8, signal=0.3)
+    tr = GLP_OT_SVLoRA(make_cfg(prec="fp32"), data=data)
+    tr.fed_before_train()
+    tr.train(idx=0, global_epoch=0, is_fed=True)
+    tr.save_model(4, str(tmp_path), is_best=True)
+    assert os.path.exists(tmp_path / "prompt_learner" / "model.pth.tar-5") and os.path.exists(tmp_path / "image_encoder" / "model-best.pth.tar")
+    batch = synth.make_batch(mcfg, 8, seed=99)
+    img, attr = batch["img"].cuda(), batch["attrs"].t()[0].cuda()
+    want = tr.model_inference(img, attr).clone()
+    fresh = GLP_OT_SVLoRA(make_cfg(prec="fp32"), data=data)
+    assert not torch.equal(fresh.model_inference(img, attr), want)
+    bad = torch.load(tmp_path / "prompt_learner" / "model-best.pth.tar")
+    bad["state_dict"]["token_prefix"] = torch.full_like(bad["state_dict"]["token_prefix"], 7.0)    # must be ignored
+    torch.save(bad, tmp_path / "prompt_learner" / "model-best.pth.tar")
+    fresh.load_model(str(tmp_path))
+    assert torch.equal(fresh.model_inference(img, attr), want)
+    fresh.load_model(str(tmp_path), epoch=5)
+    assert torch.equal(fresh.model_inference(img, attr), want)
+    with pytest.raises(FileNotFoundError):
+        fresh.load_model(str(tmp_path), epoch=9)
+    fresh.load_model("")                                              # no directory: skipped, as in the reference
