@@ -80,6 +80,9 @@ def build_parser() -> argparse.ArgumentParser:
     a("--config-file", type=str, default="")
     a("--dataset-config-file", type=str, default="")
     a("--backbone", type=str, default="")
+    a("--eval-only", action="store_true")
+    a("--model-dir", type=str, default="")
+    a("--load-epoch", type=int)
     # accepted for script compatibility, unused on this path
     for flag, kw in (("--partition", dict(type=str, default="noniid-labeldir100")), ("--beta", dict(type=float, default=0.1)),
                      ("--iid", dict(default=False)), ("--useall", dict(default=False)), ("--num_shots", dict(type=int, default=2)),
@@ -217,6 +220,13 @@ def main(argv: Optional[List[str]] = None, log=print, cfg_hook=None):
     if cfg_hook is not None:
         cfg_hook(cfg)
     tr = build_trainer(cfg)
+    if args.eval_only:                                      # federated_main.py: load_model(model_dir, load_epoch), test, stop
+        tr.load_model(args.model_dir, epoch=args.load_epoch)
+        users = list(args.idxs_users_test) or list(range(args.num_users))
+        results = {idx: tr.test(idx=idx) for idx in users}
+        for idx, r in results.items():
+            log(f"client {idx}: acc {r[0]:.3f} err {r[1]:.3f} macro_f1 {r[2]:.3f} auc {r[3]:.4f}")
+        return {"eval": results}
     fargs = F.FedArgs(num_users=args.num_users, frac=args.frac, round=args.round, avg_prompt=args.avg_prompt,
                       num_prompt=args.num_prompt, idxs_users_train=args.idxs_users_train,
                       idxs_users_test=args.idxs_users_test, shared_half_s=args.shared_half_s, local_s=args.lora_local_s,

@@ -407,6 +407,22 @@ def test_cli_runs_the_fairlora_script_on_files(tmp_path):
         assert "prompt_learner.ctx" in w and any("lora_S" in k for k in w)
         assert not any("original_linear" in k for k in w)
     assert any("Global test acc" in ln for ln in lines) and any("maximum test acc" in ln for ln in lines)
+    # --eval-only --model-dir: evaluate every client with weights loaded through the trainer's load_model hook
+    from fairfedmed_amd.registry import build_trainer  # noqa: F401
+    cfg_seen = {}
+
+    def hook2(cfg):
+        hook(cfg)
+        cfg_seen["cfg"] = cfg
+    FM.main(argv + ["--round", "1"], log=lambda *a: None, cfg_hook=hook2)
+    # save a checkpoint from a trainer built the same way, then evaluate it through the command line
+    import fairfedmed_amd.trainer as T
+    tr = T.GLP_OT_SVLoRA(cfg_seen["cfg"])
+    tr.save_model(0, str(tmp_path / "ckpt"), is_best=True)
+    ev = FM.main(argv + ["--eval-only", "--model-dir", str(tmp_path / "ckpt")], log=lambda *a: lines.append(" ".join(map(str, a))),
+                 cfg_hook=hook)
+    assert sorted(ev["eval"]) == [0, 1, 2] and all(len(r) == 4 for r in ev["eval"].values())
+    assert any(ln.startswith("client 2: acc") for ln in lines)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
