@@ -214,8 +214,6 @@ class FairLoRAEngine:
             # Sinkhorn / COT logits heads (trainers/GLP_OT_SVLoRA.py:615-675, 713-757; csrc/head_ot.hip)
             if self.ot not in ops.OT_MODES:
                 raise NotImplementedError(cfg.ot)
-            if cfg.dim_per_3d_slice:
-                raise NotImplementedError("the transport heads are built for 2D inputs")
             P, M, N = max_images * cfg.n_cls, v.tokens - 1, cfg.n_prompts
             self.tn_buf = torch.zeros(N * cfg.n_cls, v.out_dim, device=dev, dtype=f32)
             self.dtn = torch.zeros_like(self.tn_buf)

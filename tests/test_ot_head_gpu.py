@@ -102,3 +102,22 @@ def test_trainer_selects_the_ot_head():
     cfg.TRAINER.GLP_OT.OT = "Wasserstein"
     with pytest.raises(NotImplementedError):
         GLP_OT_SVLoRA(cfg, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
+
+
+@pytest.mark.parametrize("ot", ["Sinkhorn", "COT"])
+def test_ot_head_with_the_3d_oct_front_end(ot):
+    """3D OCT: every slice group is an image of the transport problem and the logits are averaged over the slices
+    afterwards (trainers/GLP_OT_SVLoRA.py:752-754); the stopping test runs over all B * S * n_cls problems."""
+    from oracle import fairlora_oracle as O
+    from fairfedmed_amd.engine import FairLoRAEngine
+    mcfg = dataclasses.replace(C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), ot=ot, ot_top_percent=0.9)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 4, seed=21)                       # 4 volumes x 2 slice groups = 8 ViT images
+    keys = synth.trainable_keys(mcfg)
+    eng = FairLoRAEngine(mcfg, sd, dtype=torch.float32, max_images=8)
+    out = eng.forward_backward(*to_dev(batch))
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    assert rel(out["logits"], logits) < 3e-5 and abs(float(out["loss"]) - float(loss)) <= 2e-5 * abs(float(loss))
+    for k in keys:
+        if float(grads[k].abs().max()) > 0:
+            assert rel(eng.params.view(k, "grad"), grads[k]) < 3e-3, (k, rel(eng.params.view(k, "grad"), grads[k]))
