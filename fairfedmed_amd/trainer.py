@@ -239,7 +239,10 @@ class GLP_OT_SVLoRA:
         Set cfg.TRAIN.METRICS_EVERY = N > 1 to pay the host sync for the metrics only every N steps
         (the reference syncs three times per step; default 1 reproduces that)."""
         image, label, _, attr = self.parse_batch_train(batch)
-        out = self.engine.forward_backward(image, attr, label)
+        # PREC 'amp': the reference's branch calls self.model(image) WITHOUT the attribute (uniform group mix) and has
+        # no fairness term (trainers/GLP_OT_SVLoRA.py:890-898; SURVEY §5 quirk 5); autocast itself is not mirrored (fp32)
+        amp = self.cfg.TRAINER.GLP_OT.PREC == "amp"
+        out = self.engine.forward_backward(image, None if amp else attr, label)
         self.engine.sgd_step(self.get_current_lr(), self.optim.momentum, self.optim.weight_decay)
         every = getattr(getattr(self.cfg, "TRAIN", NS()), "METRICS_EVERY", 1)
         summary = {}
@@ -249,7 +252,7 @@ class GLP_OT_SVLoRA:
             logits, prob = out["logits"], out["prob"]
             lam = getattr(self.cfg.TRAINER, "LAMBDA_FAIRNESS", 0.0)
             loss = float(out["loss"])
-            if lam != 0.0 and attr is not None:                         # detached fairness term (:930-948)
+            if lam != 0.0 and attr is not None and not amp:             # detached fairness term (:930-948)
                 correct = prob[torch.arange(len(label)), label]
                 vals = torch.stack([1 - correct[attr == g].mean() for g in torch.unique(attr)])
                 loss += lam * float(torch.mean(torch.abs(vals - vals.mean())))

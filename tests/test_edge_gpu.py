@@ -190,3 +190,24 @@ def test_disable_attr_runs_one_group_without_attributes():
         if float(grads[k].abs().max()) > 0:
             assert rel(g, grads[k]) < 2e-3, k
     assert not torch.equal(p0, tr.engine.params.flat)                  # the SGD step ran
+
+
+def test_prec_amp_trains_without_the_attribute():
+    """TRAINER.GLP_OT.PREC = 'amp' (trainers/GLP_OT_SVLoRA.py:890-898): the training step calls the model without the
+    attribute, i.e. with the uniform 1/G group mix; inference still passes it."""
+    from oracle import fairlora_oracle as O
+    from tests.test_trainer_gpu import make_cfg
+    from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 8, seed=11)
+    cfg = make_cfg(prec="amp")
+    cfg.MODEL.STATE_DICT = sd
+    tr = GLP_OT_SVLoRA(cfg, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
+    tr.num_batches, tr.batch_idx = 10, 0
+    s = tr.forward_backward(batch)
+    ref_loss, _, _ = O.loss_and_grads(sd, {"img": batch["img"], "label": batch["label"], "attrs": None}, mcfg,
+                                      synth.trainable_keys(mcfg))
+    with_attr, _, _ = O.loss_and_grads(sd, batch, mcfg, synth.trainable_keys(mcfg))
+    assert abs(s["loss"] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
+    assert abs(float(ref_loss) - float(with_attr)) > 1e-6             # the two mixes do differ on this batch
