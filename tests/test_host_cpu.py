@@ -246,3 +246,17 @@ def test_cli_flags_config_tree_and_scope(tmp_path):
         a = FM.build_parser().parse_args(argv + bad)
         with pytest.raises(NotImplementedError):
             FM.check_scope(a, FM.setup_cfg(a))
+
+
+def test_missing_or_stale_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: without libffm_hip.so (or with one of another ABI version) every op raises at load time."""
+    from fairfedmed_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "libffm_hip.so"))
+    with pytest.raises(RuntimeError, match="is missing"):
+        L.load()
+    monkeypatch.undo()
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI"):
+        L.load()
