@@ -71,7 +71,7 @@ SIGNATURES = {
     "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "ffm_ot_head_fwd": [_vp] * 10 + [_i32] * 6 + [_f32, _f32, _i32, _f32, _i32, _vp],
     "ffm_ot_head_bwd": [_vp] * 8 + [_i32] * 6 + [_vp],

@@ -67,6 +67,8 @@ struct gemm_kargs {
     ffm_gemm_args g;
     int conv_h, conv_w, conv_c;      // A = NHWC activation [B*H*W, C]; logical A row = the 3x3 / pad 1 patch of the pixel
     const void* conv_zero;           // >= 16 zero bytes in device memory: source of padded / out-of-image chunks
+    int ksplit;                      // > 1: blockIdx.y owns a slice of the K tiles and writes an fp32 partial tile
+    float* part;                     // [ksplit][M][N] fp32 partial products (summed by splitk_reduce_kernel)
 };
 
 // Implicit im2col: the 16-byte chunk a lane fetches for K-tile kt lies in ONE tap (C % chunk == 0); its source is the
@@ -76,7 +78,7 @@ template <typename T>
 struct ConvA {
     int y[4], x[4], pix[4];          // the lane's four tile rows: pixel coordinates and linear pixel index
     int tap, cb;                     // tap and channel BYTE offset of the lane's chunk in the current K-tile
-    __device__ __forceinline__ void init(const gemm_kargs& k, int m0, int wave, int lane) {
+    __device__ __forceinline__ void init(const gemm_kargs& k, int m0, int wave, int lane, int kt0) {
         const int rsub = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -86,7 +88,7 @@ struct ConvA {
             x[q] = g % k.conv_w;
             y[q] = (g / k.conv_w) % k.conv_h;
         }
-        const int kb = (slot ^ rsub) * 16, cbytes = k.conv_c * (int)sizeof(T);
+        const int kb = kt0 * KT_BYTES + (slot ^ rsub) * 16, cbytes = k.conv_c * (int)sizeof(T);
         tap = kb / cbytes;
         cb = kb % cbytes;
     }
@@ -132,7 +134,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
 
     const T* A = reinterpret_cast<const T*>(p.a);
     const T* B = reinterpret_cast<const T*>(p.b);
-    const int nk = (int)((size_t)p.K * sizeof(T) / KT_BYTES);
+    const int nk_all = (int)((size_t)p.K * sizeof(T) / KT_BYTES);
+    int kt0 = 0, nk = nk_all;                                       // this block's K tiles: [kt0, kt0 + nk)
+    if constexpr (CV) {
+        if (px.ksplit > 1) {
+            const int per = (nk_all + px.ksplit - 1) / px.ksplit;
+            kt0 = blockIdx.y * per;
+            nk = nk_all - kt0 < per ? nk_all - kt0 : per;
+        }
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -157,12 +167,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     // prologue: tile 0 -> buffer 0
     ConvA<T> cva;
     if constexpr (CV) {
-        cva.init(px, m0, wave, lane);
+        cva.init(px, m0, wave, lane, kt0);
         cva.stage(px, smem, wave);
     } else {
         stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
     }
-    stage_tile<T>(B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<T>(B, p.ldb, n0, p.N, kt0 * KT_BYTES, smem + TILE_BYTES, wave, lane);
     stage_rank(0, smem + 2 * TILE_BYTES);
 
     // ---- persistent epilogue operands (their loads overlap the main loop)
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             char* An = smem + (cur ^ 1) * BUF;
             if constexpr (CV) cva.stage(px, An, wave);
             else stage_tile<T>(A, p.lda, m0, p.M, (kt + 1) * KT_BYTES, An, wave, lane);
-            stage_tile<T>(B, p.ldb, n0, p.N, (kt + 1) * KT_BYTES, An + TILE_BYTES, wave, lane);
+            stage_tile<T>(B, p.ldb, n0, p.N, (kt0 + kt + 1) * KT_BYTES, An + TILE_BYTES, wave, lane);
             stage_rank((kt + 1) * KT_BYTES, An + 2 * TILE_BYTES);
         }
 #pragma unroll
@@ -277,6 +287,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             }
         }
         __syncthreads();   // next tile landed (compiler drains vmcnt before the barrier); cur is free
+    }
+
+    if constexpr (CV) {
+        if (px.ksplit > 1) {                                        // fp32 partial tile, summed by splitk_reduce_kernel
+            float* P = px.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = m0 + wm * 64 + i * 16 + fgrp * 4 + e, col = n0 + wn * 64 + j * 16 + frow;
+                        if (row < p.M && col < p.N) P[(size_t)row * p.N + col] = acc[i][j][e];
+                    }
+            return;
+        }
     }
 
     // ---------------- epilogue: two halves of 64 rows through LDS ----------
@@ -505,8 +531,8 @@ int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = 
     }
     gemm_kargs ka;
     if (conv) ka = *conv;
-    else { ka.g = a; ka.conv_h = ka.conv_w = ka.conv_c = 0; ka.conv_zero = nullptr; }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV>), dim3(tiles), dim3(256), lds, s, ka);
+    else { ka.g = a; ka.conv_h = ka.conv_w = ka.conv_c = 0; ka.conv_zero = nullptr; ka.ksplit = 1; ka.part = nullptr; }
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV>), dim3(tiles, ka.ksplit > 1 ? ka.ksplit : 1), dim3(256), lds, s, ka);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -588,8 +614,22 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
 #undef FFM_GEMM_CASE
 }
 
+// y = sum_s part[s]  (split-K partial tiles of the implicit-GEMM convolution), 4 elements per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, T* __restrict__ y, size_t total4,
+                                                            size_t stride, int S) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(part + i * 4);
+        for (int s = 1; s < S; ++s) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + i * 4);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        Vec4<T>::store(y + i * 4, a);
+    }
+}
+
 extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
-                                const void* zeros, int dtype, void* stream) {
+                                const void* zeros, float* splitk_scratch, int64_t scratch_elems, int dtype, void* stream) {
     if (!x || !w || !y || !zeros || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return FFM_EINVAL;
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
@@ -603,8 +643,33 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
     a.M = B * H * W; a.N = N; a.K = Kp;
     a.lda = C; a.ldb = Kp; a.ldc = N;
     ka.conv_h = H; ka.conv_w = W; ka.conv_c = C; ka.conv_zero = zeros;
+    ka.ksplit = 1; ka.part = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
+    // Few output tiles and a long K (layer3 / layer4: 14 x 14 and 7 x 7 maps, K = 2304 / 4608): split K over grid.y so
+    // that the launch fills the chip; the fp32 partial tiles are summed by one more small kernel.
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
+    if (splitk_scratch && tiles < 160 && nk >= 16 && a.N % 4 == 0) {
+        int S = 512 / tiles;
+        if (S > 8) S = 8;
+        if (S > nk / 4) S = nk / 4;
+        while (S > 1 && (int64_t)S * a.M * a.N > scratch_elems) --S;
+        if (S > 1) {
+            const int per = (nk + S - 1) / S;
+            S = (nk + per - 1) / per;                               // no empty slice
+            ka.ksplit = S; ka.part = splitk_scratch;
+        }
+    }
+    const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
+    if (e || ka.ksplit <= 1) return e;
+    const size_t total = (size_t)a.M * a.N, total4 = total / 4;
+    size_t blocks = (total4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, ka.part, (bf16_t*)y, total4, total, ka.ksplit);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, ka.part, (float*)y, total4, total, ka.ksplit);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
 }
 
 extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {

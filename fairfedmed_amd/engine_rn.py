@@ -173,7 +173,7 @@ class _Bneck:
         z1, a1, z2, a2, z3, out = self.z1[:ri], self.a1[:ri], self.z2[:ri], self.a2[:ri], self.z3[:ro], self.out[:ro]
         self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi)
         self.bn1.fwd(z1, a1, True)
-        ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16)          # implicit GEMM: no im2col buffer
+        ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16, e.splitk)          # implicit GEMM: no im2col buffer
         self.bn2.fwd(z2, a2, True)
         a = a2
         if self.stride > 1:
@@ -216,7 +216,7 @@ class _Bneck:
             da2 = self.da2[:ri]
             ops.avgpool2(self.da2p[:ro], da2, images, Hi, Hi, backward=True)
         self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
-        ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16)   # dX = conv3x3(dY; w')
+        ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk)   # dX = conv3x3(dY; w')
         self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
         self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid)
         return self.dx[:ri]
@@ -252,6 +252,8 @@ class RN50Engine(FairLoRAEngine):
         self.Kp1, self.Kp2, self.Kp3 = _round_up(27, self.kq), _round_up(9 * (w // 2), self.kq), _round_up(9 * w, self.kq)
         self.cols1 = e(R1, self.Kp1)
         self.zero16 = torch.zeros(64, device=dev, dtype=dt)       # source of the zero padding of the implicit GEMMs
+        # split-K partial tiles of the deep, small-map convolutions (layer3 / layer4): up to 8 x [M, N] fp32
+        self.splitk = torch.zeros(8 * 160 * 128 * 128 // 4, device=dev, dtype=torch.float32)
         self.sbn = [_BN(self, f"image_encoder.bn{i}.", c, R1) for i, c in ((1, w // 2), (2, w // 2), (3, w))]
         self.sz = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]
         self.sa = [e(R1, w // 2), e(R1, w // 2), e(R1, w)]

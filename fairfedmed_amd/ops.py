@@ -277,14 +277,15 @@ def col2im3x3(dcols: Tensor, dx: Tensor, B: int, H: int, W: int, stride: int) ->
           L.stream_ptr())
 
 
-def conv3x3(x: Tensor, w: Tensor, out: Tensor, B: int, H: int, W: int, zeros: Tensor) -> Tensor:
+def conv3x3(x: Tensor, w: Tensor, out: Tensor, B: int, H: int, W: int, zeros: Tensor,
+            scratch: Optional[Tensor] = None) -> Tensor:
     """3x3 / pad 1 / stride 1 convolution on NHWC rows as an implicit GEMM (ffm_conv3x3_nhwc): x [B*H*W, C],
-    w [N, Kp] with k = (ky*3 + kx)*C + c, out [B*H*W, N]."""
-    _dev(x, w, out, zeros)
+    w [N, Kp] with k = (ky*3 + kx)*C + c, out [B*H*W, N].  scratch: fp32 buffer for split-K partial tiles (optional)."""
+    _dev(x, w, out, zeros, scratch)
     assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
     assert x.shape[0] == B * H * W and tuple(out.shape) == (B * H * W, w.shape[0]) and zeros.numel() * zeros.element_size() >= 16
     _call("ffm_conv3x3_nhwc", L.ptr(x), L.ptr(w), L.ptr(out), B, H, W, x.shape[1], w.shape[0], w.shape[1], L.ptr(zeros),
-          L.dtype_code(x.dtype), L.stream_ptr())
+          L.ptr(_f32(scratch)), 0 if scratch is None else scratch.numel(), L.dtype_code(x.dtype), L.stream_ptr())
     return out
 
 

@@ -193,11 +193,13 @@ int ffm_slice_bwd(const void* dcols, const float* img, const float* conv, const 
  * with the patches never written - the GEMM's A-tile loader fetches chunk (tap, c) of a pixel's patch straight from
  * the neighbouring pixel's channels (zeros outside the image and in the K padding come from `zeros`, >= 16 zero bytes
  * of device memory).  w: [N, Kp] with k = (ky*3 + kx)*C + c, zero padded to Kp (Kp * sizeof(dtype) % 128 == 0).
+ * splitk_scratch (optional, scratch_elems floats): with few output tiles and a long K (14 x 14 / 7 x 7 maps) the K
+ * tiles are split over up to 8 grid slices writing fp32 partial tiles [S][M][N] there, summed by a second small kernel.
  * The input gradient is the same call on dY with the weight re-ordered once to
  * w'[ci][(ky', kx', co)] = w[co][(2 - ky', 2 - kx', ci)]  (clip/model.py:20-24, 241-244 and their autograd).
  */
 int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
-                     const void* zeros, int dtype, void* stream);
+                     const void* zeros, float* splitk_scratch, int64_t scratch_elems, int dtype, void* stream);
 int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
                     const float* std3, int dtype, void* stream);
 int ffm_im2col3x3(const void* x, void* cols, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);

@@ -176,7 +176,8 @@ def _rows_bwd(w, Kp):
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 @pytest.mark.parametrize("B,H,W,C,Co", [(2, 16, 16, 64, 64), (3, 14, 14, 32, 64), (2, 8, 12, 32, 32), (1, 7, 7, 128, 64),
-                                        (5, 28, 28, 64, 64), (2, 4, 4, 512, 512)])
+                                        (5, 28, 28, 64, 64), (2, 4, 4, 512, 512), (8, 7, 7, 512, 512),
+                                        (4, 14, 14, 256, 256)])
 def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, Co):
     """ffm_conv3x3_nhwc: the patches are never materialised; forward and (with the re-ordered weight) the input
     gradient against F.conv2d and its autograd, incl. non-square maps, tile-ragged pixel counts and padded K."""
@@ -185,13 +186,17 @@ def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, C
     x = rnd(B, C, H, W, dt=dt, seed=1)
     w = rnd(Co, C, 3, 3, dt=dt, scale=1.0 / math.sqrt(9 * C), seed=2)
     zeros = torch.zeros(64, device="cuda", dtype=dt)
+    scratch = torch.zeros(8 * B * H * W * max(C, Co), device="cuda")       # split-K kicks in for few tiles and a long K
     xr = x.float().requires_grad_(True)
     ref = F.conv2d(xr, w.float(), padding=1)
     y = torch.empty(B * H * W, Co, device="cuda", dtype=dt)
     ops.conv3x3(nhwc(x), _rows_fwd(w, rup(9 * C)).to(dt), y, B, H, W, zeros)
     assert rel(nchw(y.float(), B, H, W), ref.detach()) < tol(dt)
+    y2 = torch.full_like(y, float("nan"))
+    ops.conv3x3(nhwc(x), _rows_fwd(w, rup(9 * C)).to(dt), y2, B, H, W, zeros, scratch)
+    assert rel(nchw(y2.float(), B, H, W), ref.detach()) < tol(dt)
     g = rnd(B, Co, H, W, dt=dt, seed=3)
     ref.backward(g.float())
     dx = torch.empty(B * H * W, C, device="cuda", dtype=dt)
-    ops.conv3x3(nhwc(g), _rows_bwd(w, rup(9 * Co)).to(dt), dx, B, H, W, zeros)
+    ops.conv3x3(nhwc(g), _rows_bwd(w, rup(9 * Co)).to(dt), dx, B, H, W, zeros, scratch)
     assert rel(nchw(dx.float(), B, H, W), xr.grad) < tol(dt)
