@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, c
 }
 
 // sum of the nblk partial rows of channel c, CS_FL adjacent lanes per channel (block = 256 / CS_FL channels)
-constexpr int CS_FL = 16;
+constexpr int CS_FL = 64;
 __device__ __forceinline__ void cs_total(const float* __restrict__ part, int nblk, int C, int c, double& s, double& q) {
     const int lane = threadIdx.x & (CS_FL - 1);
     s = q = 0.0;
@@ -485,7 +485,7 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
                    hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb),
                    hipLaunchKernelGGL((colsum_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb))
         FFM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
                            run_var, 0.1f, 1e-5f);
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, run_var, mean, rstd, C, 1e-5f);
@@ -512,7 +512,7 @@ extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, c
                hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb),
                hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb))
     FFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();
     const int g2 = grid1d((size_t)rows * C / 4);
     DISPATCH_T(dtype,
