@@ -456,6 +456,7 @@ def main():
         return
     golden_dataset()
     golden_svlora()
+    golden_ot(M, CLIP)
 
     out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
     golden_layers(M, out)
