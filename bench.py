@@ -10,7 +10,9 @@ and the fused SGD-momentum update, bf16 activations/frozen weights with fp32
 accumulation and fp32 trainable tensors, batch 32 of 224x224x3
 (BASELINE.json configs[1]).  With N > 1 every rank is one federated client
 (one process per GPU, weak scaling) and the K steps end with the round-boundary
-FedAvg all-reduce of the LoRA/ctx parameters over RCCL.
+FedAvg all-reduce of the LoRA/ctx parameters over RCCL.  `python bench.py --gpus N`
+starts the N ranks itself (torch.distributed.run children, before this process
+touches the GPU); started under torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      achieved TFLOP/s of the dominant kernel (the MFMA GEMM), timed
@@ -33,6 +35,9 @@ if ROOT not in sys.path:
 # own; with ROCm's default of 4 hardware queues they get multiplexed and the overlap is lost (measured:
 # 9.4 vs 6.9 ms/step once a communicator exists).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import socket
+import subprocess
 
 import torch
 import torch.distributed as dist
@@ -133,9 +138,38 @@ def cpu_baseline(mcfg, budget_s=30.0):
                       f"same ViT-B/16 FairLoRA r=8 workload; median {med:.3f} s/step"}
 
 
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run and
+    relay their output and exit code.  Nothing in THIS process has touched the GPU (importing torch does not
+    initialise HIP), so the children are ordinary subprocesses, not an exec of a GPU process."""
+    have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if have < n and not os.environ.get("FFM_BENCH_ONE_DEVICE"):
+        raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for line in proc.stdout:                         # rank 0's JSON line (and anything else the ranks print)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
@@ -290,7 +324,9 @@ def main():
                        "global_batch": BATCH * world, "clients": world,
                        "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite,
                        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
-                       "launch": args.launch},
+                       "launch": args.launch,
+                       "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                       "backend": dist.get_backend() if use_dist else None},
         }
         if fedavg_us is not None:
             res["config"]["fedavg_round_boundary_us"] = fedavg_us

@@ -6,6 +6,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -260,3 +261,40 @@ def test_missing_or_stale_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
     with pytest.raises(RuntimeError, match="ABI"):
         L.load()
+
+
+def test_bench_gpus_flag_builds_a_rank_launch(monkeypatch):
+    """bench.py --gpus N outside a launcher starts N torch.distributed.run ranks of itself and relays the exit code."""
+    import importlib
+    import io
+    import bench
+    importlib.reload(bench)
+    seen = {}
+
+    class FakeProc:
+        stdout = io.StringIO('{"metric": "x"}\n')
+
+        def wait(self):
+            return 7
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return FakeProc()
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # more ranks than devices is an error, not a silent one-rank run
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 1 GPU" in str(e.value.code)
