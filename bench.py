@@ -212,7 +212,9 @@ def main():
 
     def eager_step():
         eng.forward_backward(img, attr, label)
-        eng.sgd_step(opt.lr, opt.momentum, opt.weight_decay)
+        # model_update as the reference runs it: its one optimizer is registered under two names and stepped for each
+        # (trainers/GLP_OT_SVLoRA.py:866-870, Dassl/dassl/engine/trainer.py:333-337); one fused launch here
+        eng.sgd_step(opt.lr, opt.momentum, opt.weight_decay, repeats=2)
 
     eng.use_replay = args.launch == "replay"
     if args.serial:

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libffm_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     "ffm_ce_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_sgd_momentum": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
+    "ffm_sgd_momentum_n": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
     "ffm_sgd_momentum_dev": [_vp, _vp, _vp, _i64, _vp, _vp],
     "ffm_scale_by": [_vp, _vp, _vp, _i64, _vp],
     "ffm_fedavg_finish": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],

@@ -164,3 +164,11 @@ def rn_tiny(rank: int = 4, alpha: float = 2.0, num_groups: int = 2) -> ModelCfg:
     return ModelCfg(vision=ResNetCfg(image_size=64, width=64, layers=(1, 1, 1, 1), out_dim=256),
                     text=TextCfg(context_length=77, width=128, heads=2, layers=2),
                     lora=LoraCfg(rank=rank, alpha=alpha, num_groups=num_groups), eot=(9, 8))
+
+
+def rn_tiny2(rank: int = 4, alpha: float = 2.0, num_groups: int = 2) -> ModelCfg:
+    """rn_tiny with identity-skip Bottlenecks: stages (2, 1, 2, 1), so layer1.1 and layer3.1 have no downsample
+    path (clip/model.py:41-60; 12 of RN50's 16 blocks are of that kind)."""
+    import dataclasses
+    base = rn_tiny(rank=rank, alpha=alpha, num_groups=num_groups)
+    return dataclasses.replace(base, vision=dataclasses.replace(base.vision, layers=(2, 1, 2, 1)))

@@ -17,6 +17,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// `repeats` applications of the same update on the SAME gradient in one pass over memory: the reference registers
+// 'prompt_learner' and 'image_encoder' with ONE optimizer (trainers/GLP_OT_SVLoRA.py:866-870) and Dassl's model_update
+// steps every registered name (Dassl/dassl/engine/trainer.py:333-337), so optim.step() runs twice per batch.
+__global__ __launch_bounds__(256) void sgd_n_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ buf, int64_t n, float lr, float mu, float wd,
+                                                    int first, int repeats) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pi = p[i];
+        const float gi = g[i];
+        float b = first ? 0.f : buf[i];
+        for (int k = 0; k < repeats; ++k) {
+            const float d = gi + wd * pi;
+            b = (first && k == 0) ? d : mu * b + d;
+            pi = pi - lr * b;
+        }
+        buf[i] = b;
+        p[i] = pi;
+    }
+}
+
 // same update with the hyper-parameters read from device memory (hp = {lr, momentum, weight_decay}),
 // so that a captured hipGraph keeps working when the LR scheduler changes lr.  With a zero-initialised
 // momentum buffer the general formula equals torch's first-step rule (mu*0 + d == d exactly).
@@ -105,6 +125,15 @@ extern "C" int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n,
     if (!p || !g || !buf || n <= 0) return FFM_EINVAL;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
                        weight_decay, first_step);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_sgd_momentum_n(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                  float weight_decay, int first_step, int repeats, void* stream) {
+    if (!p || !g || !buf || n <= 0 || repeats < 1 || repeats > 16) return FFM_EINVAL;
+    hipLaunchKernelGGL(sgd_n_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
+                       weight_decay, first_step, repeats);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

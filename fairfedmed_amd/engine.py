@@ -767,10 +767,11 @@ class FairLoRAEngine:
         return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
 
     @torch.no_grad()
-    def sgd_step(self, lr: float, momentum: float, weight_decay: float) -> None:
+    def sgd_step(self, lr: float, momentum: float, weight_decay: float, repeats: int = 1) -> None:
+        """optim.step(), `repeats` times on the gradients of the last forward_backward (one launch)."""
         p = self.params
-        ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0)
-        p.steps += 1
+        ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0, repeats)
+        p.steps += repeats
 
     def set_overlap(self, on: bool) -> None:
         """on: text tower and LoRA-gradient reductions run on their own streams beside the vision chain

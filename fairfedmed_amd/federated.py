@@ -177,7 +177,7 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     users = cfg.DATASET.USERS if hasattr(cfg.DATASET, "USERS") else args.num_users
     attribute = attribute or cfg.DATASET.ATTRIBUTE_TYPE
     if args.seed is not None:
-        np.random.seed(args.seed)                       # same draws on every rank
+        np.random.seed(args.seed)
     n_client, by_attr = _counts(trainer, attribute, users)
     params = trainer.engine.params
     flat, offsets = params.flat, params.offsets
@@ -196,8 +196,19 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     has_buf = hasattr(eng, "buffers_flat")
     global_buf = eng.buffers_flat() if has_buf else None
     per_client_buf = {i: global_buf.clone() for i in range(users)} if has_buf else None
+    # LR schedule: the reference's ONE scheduler advances by (local epochs x registered names) per trained client, in
+    # client order, whichever process trains it.  Every rank therefore positions its scheduler from the GLOBAL count of
+    # client-epochs before each of its clients (and after the round), so the schedule does not depend on the world size
+    can_position = hasattr(trainer, "set_lr_epoch") and not args.compat_sequential_optimizer
+    per_client_epochs = trainer.max_epoch * trainer.steps_per_update() if can_position else 0
+    sched_pos = trainer.sched.last_epoch if can_position else 0
     for epoch in range(args.round):
-        idxs_users = select_clients(epoch, args, users)
+        # rank 0 draws the round's clients (numpy's global generator, like the reference) and everybody uses ITS list:
+        # with an unseeded generator (--seed <= 0) the ranks would otherwise pick different subsets and the all-reduce
+        # would silently combine inconsistent participants
+        pick = [select_clients(epoch, args, users) if rank == 0 else None]
+        dist.broadcast_object_list(pick, src=0)
+        idxs_users = [int(u) for u in pick[0]]
         acc = torch.zeros_like(flat)
         acc_buf = torch.zeros_like(global_buf) if has_buf else None
         total = sum(n_client[int(u)] for u in idxs_users)
@@ -208,6 +219,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
                 flat.copy_(global_flat if epoch == 0 else per_client[idx])
                 if has_buf:
                     eng.load_buffers_flat(global_buf if epoch == 0 else per_client_buf[idx])
+                if can_position:
+                    trainer.set_lr_epoch(sched_pos + j * per_client_epochs)
                 trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
                 local_after[idx] = flat.detach().clone()
                 w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
@@ -222,6 +235,9 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
                 dist.broadcast(scal, src=j % world)
                 if not mine:
                     trainer.load_optimizer_state(mom, scal)
+        if can_position:
+            sched_pos += len(idxs_users) * per_client_epochs
+            trainer.set_lr_epoch(sched_pos)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         if has_buf:
             dist.all_reduce(acc_buf, op=dist.ReduceOp.SUM)
@@ -277,4 +293,20 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         hist["global_buffers"] = global_buf
     trainer.fed_after_train()
     hist["global_flat"] = global_flat
+    # the per-client weights the reference saves as global_client{idx}_final.pth (federated_main.py:771-774), rebuilt
+    # from the flat buffers (every rank holds all of them: personalised pieces were exchanged above)
+    lwp = {}
+    for idx, f in per_client.items():
+        w = {k: f[off:off + int(np.prod(shp))].view(shp).clone() for k, (off, shp) in offsets.items()}
+        if has_buf:                                                  # layout of RN50Engine.buffers_flat()
+            off = 0
+            buf = per_client_buf[idx]
+            for name in ("running_mean", "running_var"):
+                for bn in eng.bns:
+                    w[bn.prefix + name] = buf[off:off + bn.C].clone()
+                    off += bn.C
+            for i, bn in enumerate(eng.bns):
+                w[bn.prefix + "num_batches_tracked"] = buf[off + i].to(torch.int64)
+        lwp[idx] = w
+    hist["local_weights_per"] = lwp
     return hist

@@ -95,6 +95,8 @@ def build_parser() -> argparse.ArgumentParser:
     a("--synthetic-batches", type=int, default=4)
     a("--transport", type=str, default="uint8", choices=["uint8", "float32"])
     a("--compat-sequential-optimizer", action="store_true")
+    a("--save-trainable-only", action="store_true",
+      help="global_client{idx}_final.pth without the frozen CLIP tensors (the reference saves the full state_dict)")
     return p
 
 
@@ -236,13 +238,16 @@ def main(argv: Optional[List[str]] = None, log=print, cfg_hook=None):
     hist = (F.run_fedotplora_ranks if ranks else F.run_fedotplora)(tr, fargs, log=log if rank == 0 else (lambda *_: None))
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
-        if "local_weights_per" in hist:                     # federated_main.py:771-774
-            for idx, w in hist["local_weights_per"].items():
-                name = os.path.join(args.output_dir, f"global_client{idx}_final.pth")
-                log(f"Save client-{idx} global weights: {name}")
-                torch.save({k: v.cpu() for k, v in w.items()}, name)
-        else:
-            torch.save(hist["global_flat"].cpu(), os.path.join(args.output_dir, "global_flat_final.pth"))
+        # federated_main.py:771-774: one global_client{idx}_final.pth per client holding the client's FULL state_dict
+        # (the frozen CLIP tensors are the same in every file; --save-trainable-only keeps the tensors that differ)
+        base = None if args.save_trainable_only else {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+        for idx, w in hist["local_weights_per"].items():
+            name = os.path.join(args.output_dir, f"global_client{idx}_final.pth")
+            log(f"Save client-{idx} global weights: {name}")
+            sd = {k: v.detach().cpu() for k, v in w.items()}
+            if base is not None:
+                sd = type(base)((k, sd.get(k, v)) for k, v in base.items())
+            torch.save(sd, name)
         log("global_test_acc_list:", hist["acc"])
         log("maximum test acc:", max(hist["acc"]))
         log("mean of acc:", float(np.mean(hist["acc"][-5:])))

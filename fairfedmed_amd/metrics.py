@@ -55,8 +55,12 @@ def auc_macro_ovr(prob: np.ndarray, label: np.ndarray) -> float:
 
 
 def macro_f1(pred: np.ndarray, label: np.ndarray, num_classes: int) -> float:
+    """sklearn f1_score(average="macro", labels=np.unique(y_true)) as the reference's evaluator calls it
+    (evaluation/evaluator_oph.py:70-75): the mean runs over the classes PRESENT in the labels only."""
     f = []
     for c in range(num_classes):
+        if not np.any(label == c):
+            continue
         tp = float(np.sum((pred == c) & (label == c)))
         fp = float(np.sum((pred == c) & (label != c)))
         fn = float(np.sum((pred != c) & (label == c)))
@@ -156,16 +160,20 @@ def _rates_from_row(r):
 
 
 def basic_from_counts(counts: np.ndarray):
-    """[accuracy %, error %, macro-F1 %, AUC] of SimpleTrainer.test from the 'all' row."""
+    """[accuracy %, error %, macro-F1 %, AUC %] of SimpleTrainer.test from the 'all' row: the first four entries of
+    Classification_oph.evaluate's results (evaluation/evaluator_oph.py:66-96: macro-F1 over the classes present in the
+    labels, 100 * compute_auc)."""
     r = np.asarray(counts)[-1]
     tp, fp, tn, fn = (int(r[k]) for k in (TP, FP, TN, FN))
     n = tp + fp + tn + fn
     acc = 100.0 * (tp + tn) / n
     f = []
-    for a, b, c in ((tn, fn, fp), (tp, fp, fn)):                  # class 0: tp' = TN, fp' = FN, fn' = FP; class 1
+    for a, b, c, present in ((tn, fn, fp, tn + fp > 0), (tp, fp, fn, tp + fn > 0)):   # class 0: tp' = TN, fp' = FN, fn' = FP
+        if not present:
+            continue
         d = 2 * a + b + c
         f.append(0.0 if d == 0 else 2 * a / d)
-    return [acc, 100.0 - acc, 100.0 * float(np.mean(f)), _auc_from_row(r)]
+    return [acc, 100.0 - acc, 100.0 * float(np.mean(f)), 100.0 * _auc_from_row(r)]
 
 
 def comprehensive_scores_from_counts(counts_by_attr) -> dict:

@@ -516,10 +516,16 @@ def head_bwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: 
 
 
 def sgd_momentum(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, weight_decay: float,
-                 first_step: bool) -> None:
+                 first_step: bool, repeats: int = 1) -> None:
+    """torch.optim.SGD.step(), `repeats` times on the same gradient (the reference's shared optimizer is stepped once
+    per registered model name: Dassl/dassl/engine/trainer.py:333-337)."""
     _dev(p, g, buf)
-    _call("ffm_sgd_momentum", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
-                                      weight_decay, int(first_step), L.stream_ptr())
+    if repeats == 1:
+        _call("ffm_sgd_momentum", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
+              weight_decay, int(first_step), L.stream_ptr())
+    else:
+        _call("ffm_sgd_momentum_n", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
+              weight_decay, int(first_step), int(repeats), L.stream_ptr())
 
 
 def sgd_momentum_dev(p: Tensor, g: Tensor, buf: Tensor, hp: Tensor) -> None:

@@ -77,13 +77,14 @@ class SyntheticFedData:
 
     def __init__(self, mcfg: C.ModelCfg, num_clients: int, train_batches: int, test_batches: int, batch_size: int,
                  attribute: str = "race", classnames=("NOT Glaucoma", "Glaucoma"), seed: int = 1234,
-                 signal: float = 0.25, device: str = "cpu"):
+                 signal: float = 0.25, device: str = "cpu", test_batch_size: Optional[int] = None):
         ng = {attribute: mcfg.lora.num_groups}
-        mk = lambda s: {k: v.to(device) for k, v in synth.make_batch(mcfg, batch_size, seed=s, signal=signal).items()}
+        mk = lambda s, n=batch_size: {k: v.to(device) for k, v in synth.make_batch(mcfg, n, seed=s, signal=signal).items()}
+        tbs = test_batch_size or batch_size
         self.fed_train_loader_x_dict, self.fed_test_loader_x_dict = {}, {}
         for c in range(num_clients):
             tr = [mk(seed + 1000 * c + i) for i in range(train_batches)]
-            te = [mk(seed + 1000 * c + 500 + i) for i in range(test_batches)]
+            te = [mk(seed + 1000 * c + 500 + i, tbs) for i in range(test_batches)]
             self.fed_train_loader_x_dict[c] = _Loader(_ListDataset(tr, [attribute], ng))
             self.fed_test_loader_x_dict[c] = _Loader(_ListDataset(te, [attribute], ng))
         self.dataset = NS(classnames=list(classnames))
@@ -178,8 +179,11 @@ class GLP_OT_SVLoRA:
                         param_groups=[{"lr": o.LR}])
         stepsize = o.STEPSIZE[-1] if isinstance(o.STEPSIZE, (list, tuple)) else o.STEPSIZE
         self.sched = NS(step_size=stepsize if stepsize > 0 else o.MAX_EPOCH, gamma=o.GAMMA, last_epoch=0)
+        # trainers/GLP_OT_SVLoRA.py:866-870: BOTH names are registered with the SAME optimizer and scheduler objects
+        # when UNFREEZE_IMAGE_ENCODER is set (every FairLoRA script sets it)
         self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
-        self.register_model("image_encoder", self.model.image_encoder, self.optim, self.sched)
+        if getattr(cfg.TRAINER.GLP_OT_LORA, "UNFREEZE_IMAGE_ENCODER", True):
+            self.register_model("image_encoder", self.model.image_encoder, self.optim, self.sched)
 
     def register_model(self, name="model", model=None, optim=None, sched=None):
         assert name not in self._models, "Found duplicate model names"
@@ -195,10 +199,27 @@ class GLP_OT_SVLoRA:
     def get_current_lr(self, names=None):
         return self.optim.param_groups[0]["lr"]
 
+    def steps_per_update(self, names=None) -> int:
+        """How often TrainerBase.model_update / update_lr step the ONE shared optimizer / scheduler per call: once per
+        registered model name (Dassl/dassl/engine/trainer.py:253-258, 333-337), i.e. TWICE with the image encoder
+        registered.  cfg.TRAINER.COMPAT_DOUBLE_STEP = False gives the single step a
+        reader of the reference would expect (a deliberate divergence; the goldens pin the default)."""
+        if not getattr(self.cfg.TRAINER, "COMPAT_DOUBLE_STEP", True):
+            return 1
+        return sum(1 for n in self.get_model_names(names) if self._optims[n] is not None)
+
     def update_lr(self, names=None):
-        """StepLR.step() (Dassl/dassl/optim/lr_scheduler.py:100-115), once per local epoch."""
+        """StepLR.step() (Dassl/dassl/optim/lr_scheduler.py:100-115) at the end of a local epoch, once per registered
+        name that carries the (shared) scheduler."""
         s = self.sched
-        s.last_epoch += 1
+        s.last_epoch += self.steps_per_update(names)
+        self.optim.param_groups[0]["lr"] = self.optim.lr0 * s.gamma ** (s.last_epoch // s.step_size)
+
+    def set_lr_epoch(self, last_epoch: int) -> None:
+        """Position the (shared) StepLR as if `last_epoch` scheduler steps had been taken: the rank-parallel round loop
+        calls this with the global count of client-epochs, so the schedule is the reference's whatever the world size."""
+        s = self.sched
+        s.last_epoch = int(last_epoch)
         self.optim.param_groups[0]["lr"] = self.optim.lr0 * s.gamma ** (s.last_epoch // s.step_size)
 
     def optimizer_state(self):
@@ -243,7 +264,8 @@ class GLP_OT_SVLoRA:
         # no fairness term (trainers/GLP_OT_SVLoRA.py:890-898); autocast itself is not mirrored (fp32)
         amp = self.cfg.TRAINER.GLP_OT.PREC == "amp"
         out = self.engine.forward_backward(image, None if amp else attr, label)
-        self.engine.sgd_step(self.get_current_lr(), self.optim.momentum, self.optim.weight_decay)
+        self.engine.sgd_step(self.get_current_lr(), self.optim.momentum, self.optim.weight_decay,
+                             repeats=1 if amp else self.steps_per_update())     # amp: scaler.step(optim) once (:896)
         every = getattr(getattr(self.cfg, "TRAIN", NS()), "METRICS_EVERY", 1)
         summary = {}
         if every <= 1 or (self.batch_idx + 1) % every == 0 or (self.batch_idx + 1) == self.num_batches:
@@ -347,8 +369,9 @@ class GLP_OT_SVLoRA:
     # -------------------------------------------------------------- test --
     @torch.no_grad()
     def test(self, split=None, is_global=False, current_epoch=0, idx=-1, global_test=False):
-        """[acc, err, macro_f1, auc] over the client's test loader (SimpleTrainer.test,
-        Dassl/dassl/engine/trainer.py:523-569; federated_main.py:685-690 indexes [0..3])."""
+        """[acc, err, macro_f1, auc] over the client's test loader, all four in percent as the reference's evaluator
+        stores them (SimpleTrainer.test, Dassl/dassl/engine/trainer.py:523-569; evaluation/evaluator_oph.py:66-96:
+        auc = 100 * compute_auc; federated_main.py:685-690 indexes [0..3])."""
         self.set_model_mode("eval")
         probs, labels, attrs_all = [], [], []
         for batch in self.fed_test_loader_x_dict[idx]:
@@ -378,4 +401,4 @@ class GLP_OT_SVLoRA:
         self.last_results = {"accuracy": acc, "error_rate": 100.0 - acc}
         if prob.shape[1] == 2 and y.min() != y.max():
             self.last_results.update(comprehensive_scores(prob, y, attrs_d.cpu().numpy()))
-        return [acc, 100.0 - acc, 100.0 * macro_f1(pred, y, prob.shape[1]), auc_macro_ovr(prob, y)]
+        return [acc, 100.0 - acc, 100.0 * macro_f1(pred, y, prob.shape[1]), 100.0 * auc_macro_ovr(prob, y)]

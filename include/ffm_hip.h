@@ -40,7 +40,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 4   /* 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 5   /* 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -360,6 +360,15 @@ int ffm_ot_head_bwd(const void* f, const float* tn, const float* logit_scale, co
  */
 int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                      float weight_decay, int first_step, void* stream);
+
+/*
+ * `repeats` (1..16) consecutive applications of that update on the SAME gradient, in one pass over memory.  The
+ * reference registers 'prompt_learner' and 'image_encoder' with one shared optimizer
+ * (trainers/GLP_OT_SVLoRA.py:866-870) and TrainerBase.model_update steps the optimizer of every registered name
+ * (Dassl/dassl/engine/trainer.py:333-337): with UNFREEZE_IMAGE_ENCODER, optim.step() runs twice per batch.
+ */
+int ffm_sgd_momentum_n(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                       float weight_decay, int first_step, int repeats, void* stream);
 
 /* The same update with {lr, momentum, weight_decay} read from DEVICE memory (hp[3]) and a momentum buffer
  * that starts at zero: safe to capture in a hipGraph while the LR schedule changes lr between replays. */

@@ -418,14 +418,32 @@ class SgdState:
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.buf: Dict[str, Tensor] = {}
 
-    def step(self, sd: Dict[str, Tensor], grads: Dict[str, Tensor]) -> None:
-        for k, g in grads.items():
-            d = g + self.weight_decay * sd[k]
-            if k not in self.buf:
-                self.buf[k] = d.clone()
-            else:
-                self.buf[k] = self.momentum * self.buf[k] + d
-            sd[k] = sd[k] - self.lr * self.buf[k]
+    def step(self, sd: Dict[str, Tensor], grads: Dict[str, Tensor], repeats: int = 1) -> None:
+        """`repeats` = how many registered model names share the optimizer: TrainerBase.model_update calls
+        optim.step() once per name on the same gradients (Dassl/dassl/engine/trainer.py:333-337), twice with
+        UNFREEZE_IMAGE_ENCODER (trainers/GLP_OT_SVLoRA.py:866-870)."""
+        for _ in range(repeats):
+            for k, g in grads.items():
+                d = g + self.weight_decay * sd[k]
+                if k not in self.buf:
+                    self.buf[k] = d.clone()
+                else:
+                    self.buf[k] = self.momentum * self.buf[k] + d
+                sd[k] = sd[k] - self.lr * self.buf[k]
+
+
+class StepLRState:
+    """torch.optim.lr_scheduler.StepLR over an SgdState (Dassl/dassl/optim/lr_scheduler.py:100-115):
+    lr = lr0 * gamma ** (last_epoch // step_size).  TrainerBase.update_lr steps the scheduler of EVERY registered
+    model name (Dassl/dassl/engine/trainer.py:253-258); the two names of the FairLoRA run share one scheduler, so an
+    epoch end advances it by two."""
+
+    def __init__(self, opt: "SgdState", step_size: int, gamma: float = 0.1):
+        self.opt, self.lr0, self.step_size, self.gamma, self.last_epoch = opt, opt.lr, step_size, gamma, 0
+
+    def step(self, repeats: int = 1) -> None:
+        self.last_epoch += repeats
+        self.opt.lr = self.lr0 * self.gamma ** (self.last_epoch // self.step_size)
 
 
 def loss_and_grads(sd: Dict[str, Tensor], batch, cfg, trainable: List[str], lambda_fairness: float = 0.0):
@@ -451,11 +469,15 @@ def loss_and_grads(sd: Dict[str, Tensor], batch, cfg, trainable: List[str], lamb
     return loss.detach(), logits.detach(), grads
 
 
-def train_step(sd: Dict[str, Tensor], opt: SgdState, batch, cfg, trainable: List[str]):
-    """forward_backward: loss -> backward -> SGD step; returns the summary dict
-    (trainers/GLP_OT_SVLoRA.py:959-970)."""
+def train_step(sd: Dict[str, Tensor], opt: SgdState, batch, cfg, trainable: List[str], optimizer_steps: int = 2,
+               sched: Optional[StepLRState] = None, last_batch: bool = False):
+    """forward_backward: loss -> backward -> model_update (-> update_lr after the epoch's last batch); returns the
+    summary dict (trainers/GLP_OT_SVLoRA.py:959-973).  optimizer_steps = 2 is the reference's run configuration (both
+    'prompt_learner' and 'image_encoder' registered with the one optimizer and scheduler)."""
     loss, logits, grads = loss_and_grads(sd, batch, cfg, trainable)
-    opt.step(sd, grads)
+    opt.step(sd, grads, optimizer_steps)
+    if sched is not None and last_batch:
+        sched.step(optimizer_steps)
     prob = torch.softmax(logits, -1)
     acc = float((logits.argmax(-1) == batch["label"]).float().mean() * 100.0)
     auc = auc_binary(prob.numpy(), batch["label"].numpy())

@@ -275,7 +275,7 @@ def golden_s_init(M, out):
             assert float(layer.lora_A.weight.abs().max()) == 0.0
 
 
-def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="random"):
+def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="random", num_batches=None, step_size=200):
     sd = synth.make_state_dict(mcfg, seed=1, lora_init=lora_init)
     model = build_reference_model(M, CLIP, mcfg, sd)
     batch = synth.make_batch(mcfg, batch_size, seed=1234)
@@ -295,13 +295,15 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
     if mcfg.dim_per_3d_slice:
         params += list(model.proj_per_3d_slice.parameters())      # trainers/GLP_OT_SVLoRA.py:862-863
     tr.optim = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4, dampening=0, nesterov=False)
-    tr.sched = torch.optim.lr_scheduler.StepLR(tr.optim, step_size=200, gamma=0.1)
+    tr.sched = torch.optim.lr_scheduler.StepLR(tr.optim, step_size=step_size, gamma=0.1)
     from collections import OrderedDict
-    tr._models = OrderedDict(prompt_learner=model.prompt_learner, image_encoder=model.image_encoder)
-    tr._optims = OrderedDict(prompt_learner=tr.optim, image_encoder=None)
-    tr._scheds = OrderedDict(prompt_learner=tr.sched, image_encoder=None)
+    # the reference's own wiring (trainers/GLP_OT_SVLoRA.py:866-870): both names carry the SAME optimizer and
+    # scheduler, so model_update steps the optimizer twice per batch and update_lr the scheduler twice per epoch
+    tr._models, tr._optims, tr._scheds = OrderedDict(), OrderedDict(), OrderedDict()
+    tr.register_model("prompt_learner", model.prompt_learner, tr.optim, tr.sched)
+    tr.register_model("image_encoder", model.image_encoder, tr.optim, tr.sched)
     tr._writer = None
-    tr.num_batches = 10 ** 9
+    tr.num_batches = num_batches if num_batches else steps      # the last step of an "epoch" calls update_lr()
     model.train()
 
     # step 0 by hand to capture logits and grads before the update
@@ -330,11 +332,15 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
     # K-step trajectory through the reference's own forward_backward
     traj = []
     for i in range(steps):
-        tr.batch_idx = i
+        tr.batch_idx = i % tr.num_batches
         s = tr.forward_backward(batch)
+        s["lr_after"] = tr.optim.param_groups[0]["lr"]
         traj.append(s)
         print(tag, "step", i, s)
     meta[f"{tag}.traj"] = traj
+    meta[f"{tag}.sched"] = {"last_epoch": tr.sched.last_epoch, "lr": tr.optim.param_groups[0]["lr"],
+                            "num_batches": tr.num_batches, "step_size": step_size,
+                            "optimizer_steps_per_batch": sum(1 for o in tr._optims.values() if o is not None)}
     post = model.state_dict()
     for k in synth.buffer_keys(mcfg):                              # RN50: BatchNorm running statistics after the steps
         out[f"{tag}.post.{k}"] = post[k].detach().numpy().copy()
@@ -471,6 +477,9 @@ def main():
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_r4", 8, 3, out, meta)
     golden_model(M, CLIP, C.vit_tiny(rank=8, num_groups=2), "tiny_r8g2", 6, 2, out, meta)
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_refinit", 8, 3, out, meta, lora_init="reference")
+    # two local epochs of two batches with StepLR(step_size=2): the scheduler is stepped twice per epoch, so the
+    # second epoch already runs at lr * gamma
+    golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_sched", 8, 4, out, meta, num_batches=2, step_size=2)
     np.savez_compressed(os.path.join(HERE, "tiny.npz"), **out)
 
     out = {}   # 3D OCT front end: 6 samples x 2 slice groups of 4 B-scans -> 12 ViT images
@@ -479,11 +488,15 @@ def main():
 
     out = {}   # RN50 trunk (one Bottleneck per stage, RN50's channel widths, 64x64 images), G = 2 as in configs[4]
     golden_model(M, CLIP, C.rn_tiny(rank=4, num_groups=2), "rn_tiny_r4g2", 6, 3, out, meta)
+    # the same trunk with identity-skip Bottlenecks (stages (2, 1, 2, 1)): layer1.1 / layer3.1 have no downsample
+    golden_model(M, CLIP, C.rn_tiny2(rank=4, num_groups=2), "rn_tiny2_r4g2", 6, 3, out, meta)
     np.savez_compressed(os.path.join(HERE, "rn_tiny.npz"), **out)
 
     if args.vitb:
         out = {}
         golden_model(M, CLIP, C.vit_b16(rank=8), "vitb_r8", 8, 3, out, meta)
+        # the bench workload's batch size (the bf16 panel GEMMs are selected from 6304 token rows on)
+        golden_model(M, CLIP, C.vit_b16(rank=8), "vitb_r8_bs32", 32, 2, out, meta)
         np.savez_compressed(os.path.join(HERE, "vitb.npz"), **out)
     else:
         prev = os.path.join(HERE, "meta.json")

@@ -45,7 +45,7 @@ class OracleTrainer:
     def train(self, idx, global_epoch, is_fed, is_last_client):
         for batch in self.fed_train_loader_x_dict[idx]:
             self.O.train_step(self.sd, self.opt, batch, self.mcfg, self.keys)
-        self.last_epoch += 1                                         # StepLR.step() once per local epoch
+        self.last_epoch += 2                   # update_lr: the shared StepLR is stepped once per registered name (2)
         self.opt.lr = self.lr0 * self.gamma ** (self.last_epoch // self.step_size)
 
     def test(self, idx, current_epoch):
@@ -59,12 +59,16 @@ class OracleTrainer:
         prob, y = torch.cat(probs).numpy(), torch.cat(labels).numpy()
         pred = prob.argmax(-1)
         acc = 100.0 * float((pred == y).mean())
-        return [acc, 100.0 - acc, 100.0 * M.macro_f1(pred, y, 2), M.auc_macro_ovr(prob, y)]
+        return [acc, 100.0 - acc, 100.0 * M.macro_f1(pred, y, 2), 100.0 * M.auc_macro_ovr(prob, y)]
 
 
-# measured: fp32 equal to four decimals (0.8714, 0.8788, 0.8778 on both sides); bf16 0.8695, 0.8758, 0.8758 - within
-# 0.003 on 128 test samples per client (one of 4096 score pairs = 0.00024)
-@pytest.mark.parametrize("prec,tol", [("fp32", 0.002), ("bf16", 0.006)])
+# north_star: AUC within +-0.002 of the reference after equal rounds, in BOTH precisions (bf16 is the mode the bench
+# number is quoted in).  2048 test samples per client (32 batches of 64): ~10^6 score pairs per client, so one
+# swapped pair moves the AUC by 1e-6 and what is left is the systematic effect of bf16 activations.
+TEST_BATCHES, TEST_BS = 32, 64
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 0.0005), ("bf16", 0.002)])
 def test_auc_after_equal_rounds(prec, tol):
     from fairfedmed_amd import federated as F
     from fairfedmed_amd.registry import build_trainer
@@ -73,19 +77,24 @@ def test_auc_after_equal_rounds(prec, tol):
     from tests.test_trainer_gpu import make_cfg
     mcfg = C.vit_tiny(rank=4)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
-    data = SyntheticFedData(mcfg, USERS, train_batches=6, test_batches=8, batch_size=BS, signal=0.45)
+    data = SyntheticFedData(mcfg, USERS, train_batches=6, test_batches=TEST_BATCHES, batch_size=BS, signal=0.45,
+                            test_batch_size=TEST_BS)
+    assert all(len(l.dataset) >= 2000 for l in data.fed_test_loader_x_dict.values())
     args = F.FedArgs(num_users=USERS, frac=1.0, round=ROUNDS, shared_half_s=True, seed=0)
     cfg = make_cfg(prec=prec, bs=BS)
+    cfg.TEST.BATCH_SIZE = TEST_BS
     cfg.OPTIM.LR = 2e-2                                              # large enough for the AUC to move in 3 rounds
     cfg.DATASET.USERS, cfg.TEST.NO_TEST, cfg.TRAIN.METRICS_EVERY = USERS, True, 0
     cfg.DATA, cfg.MODEL.STATE_DICT = data, sd
     hip = F.run_fedotplora(build_trainer(cfg), args, log=lambda *_: None)
     ref = F.run_fedotplora(OracleTrainer(mcfg, data, sd, lr=2e-2, step_size=cfg.OPTIM.STEPSIZE, gamma=cfg.OPTIM.GAMMA),
                            args, log=lambda *_: None)
-    print(prec, "AUC per round  HIP", [round(a, 4) for a in hip["auc"]], " oracle", [round(a, 4) for a in ref["auc"]])
-    assert max(ref["auc"]) - min(ref["auc"]) > 0.01 or abs(ref["auc"][-1] - 0.5) > 0.02, "the run must move the AUC"
+    # test() reports the AUC in percent, as the reference's evaluator does (evaluation/evaluator_oph.py:88-96)
+    hip_auc, ref_auc = [a / 100.0 for a in hip["auc"]], [a / 100.0 for a in ref["auc"]]
+    print(prec, "AUC per round  HIP", [round(a, 5) for a in hip_auc], " oracle", [round(a, 5) for a in ref_auc])
+    assert max(ref_auc) - min(ref_auc) > 0.01 or abs(ref_auc[-1] - 0.5) > 0.02, "the run must move the AUC"
     for r in range(ROUNDS):
-        assert abs(hip["auc"][r] - ref["auc"][r]) <= tol, (r, hip["auc"], ref["auc"])
+        assert abs(hip_auc[r] - ref_auc[r]) <= tol, (r, hip_auc, ref_auc)
         assert abs(hip["acc"][r] - ref["acc"][r]) <= (1e-9 if prec == "fp32" else 5.0)
     if prec == "fp32":
         for k, v in ref["global_weights"].items():

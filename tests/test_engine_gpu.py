@@ -106,9 +106,11 @@ def test_tiny_trajectory_fp32(golden_dir, tag, mcfg, bs, init):
     batch = synth.make_batch(mcfg, bs, seed=1234)
     eng = make_engine(mcfg, sd, torch.float32, vit_images(mcfg, bs))
     img, attr, label = to_dev(batch)
+    reps = meta[f"{tag}.sched"]["optimizer_steps_per_batch"]          # 2: the reference's shared optimizer (quirk 9)
+    assert reps == 2
     for ref in meta[f"{tag}.traj"]:
         out = eng.forward_backward(img, attr, label)
-        eng.sgd_step(1e-3, 0.9, 5e-4)
+        eng.sgd_step(1e-3, 0.9, 5e-4, repeats=reps)
         assert abs(float(out["loss"]) - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (float(out["loss"]), ref)
     for k in synth.trainable_keys(mcfg):
         assert rel(eng.params.view(k), gold[f"{tag}.post.{k}"]) < 1e-4, k
@@ -126,34 +128,42 @@ def test_no_attr_uniform_mix():
     assert rel(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("tag,bs", [("vitb_r8", 8), ("vitb_r8_bs32", 32)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_vitb16_step_vs_reference_golden(golden_dir, dtype):
-    """Full ViT-B/16 r=8 G=3 step (bs 8) against the imported reference's logits, loss and gradients."""
+def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
+    """Full ViT-B/16 r=8 G=3 step against the imported reference's logits, loss, gradients and loss trajectory: bs 8,
+    and bs 32 = the bench workload, whose 6304 token rows select the bf16 panel GEMMs on fragment-packed weights."""
     path = os.path.join(golden_dir, "vitb.npz")
     gold = np.load(path)
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
     mcfg = C.vit_b16(rank=8)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
-    batch = synth.make_batch(mcfg, 8, seed=1234)
-    eng = make_engine(mcfg, sd, dtype, 8)
+    batch = synth.make_batch(mcfg, bs, seed=1234)
+    eng = make_engine(mcfg, sd, dtype, bs)
     assert eng.params.numel == 741952
+    f32 = dtype == torch.float32
+    if bs == 32 and not f32:
+        from fairfedmed_amd import ops
+        w = mcfg.vision.width
+        assert eng.vis.blocks[0].packed is not None
+        assert ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, torch.bfloat16, True) != \
+            ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, torch.bfloat16, False), "panel kernel not selected"
     img, attr, label = to_dev(batch)
     out = eng.forward_backward(img, attr, label)
     torch.cuda.synchronize()
-    f32 = dtype == torch.float32
-    l0 = meta["vitb_r8.loss0"]
-    print("vitb", dtype, "loss", float(out["loss"]), "ref", l0, "logit err", rel(out["logits"], gold["vitb_r8.logits"]))
+    l0 = meta[f"{tag}.loss0"]
+    print(tag, dtype, "loss", float(out["loss"]), "ref", l0, "logit err", rel(out["logits"], gold[f"{tag}.logits"]))
     assert abs(float(out["loss"]) - l0) <= (1e-4 if f32 else 1e-2) * abs(l0)
-    assert rel(out["logits"], gold["vitb_r8.logits"]) < (1e-4 if f32 else 5e-2)
+    assert rel(out["logits"], gold[f"{tag}.logits"]) < (1e-4 if f32 else 5e-2)
     from tests.golden.make_golden import sub
     worst, wcos = 0.0, 1.0
     for k in synth.trainable_keys(mcfg):
         g = eng.params.view(k, "grad").cpu()
-        n, ref_n = float(g.norm()), meta["vitb_r8.grad_norms"][k]
+        n, ref_n = float(g.norm()), meta[f"{tag}.grad_norms"][k]
         assert abs(n - ref_n) <= (2e-3 if f32 else 8e-2) * ref_n + 1e-12, (k, n, ref_n)
-        key = f"vitb_r8.grad.{k}" if f"vitb_r8.grad.{k}" in gold else f"vitb_r8.gradsub.{k}"
+        key = f"{tag}.grad.{k}" if f"{tag}.grad.{k}" in gold else f"{tag}.gradsub.{k}"
         ref = gold[key]
-        got = g.numpy() if key.startswith("vitb_r8.grad.") else sub(g, 1024)
+        got = g.numpy() if key.startswith(f"{tag}.grad.") else sub(g, 1024)
         e = rel(got, ref)
         worst = max(worst, e)
         wcos = min(wcos, cos(got, ref))
@@ -161,7 +171,17 @@ def test_vitb16_step_vs_reference_golden(golden_dir, dtype):
             assert e < 5e-3, (k, e)
         else:
             assert cos(got, ref) > 0.97, (k, cos(got, ref), e)
-    print("vitb", dtype, "worst grad err", worst, "worst cosine", wcos)
+    print(tag, dtype, "worst grad err", worst, "worst cosine", wcos)
+    # the reference's forward_backward trajectory (two optimizer steps per batch: quirk 9)
+    for i, ref in enumerate(meta[f"{tag}.traj"]):
+        if i:
+            out = eng.forward_backward(img, attr, label)
+        eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)
+        assert abs(float(out["loss"]) - ref["loss"]) <= (1e-4 if f32 else 1e-2) * abs(ref["loss"]), (i, float(out["loss"]), ref)
+    if f32:
+        for k in synth.trainable_keys(mcfg):
+            if f"{tag}.post.{k}" in gold:
+                assert rel(eng.params.view(k), gold[f"{tag}.post.{k}"]) < 1e-4, k
 
 
 def test_vitb16_bs32_panel_path_vs_fp32_engine():

@@ -17,6 +17,9 @@ from fairfedmed_amd import synth
 
 pytestmark = pytest.mark.gpu
 TAG, BS = "rn_tiny_r4g2", 6
+# rn_tiny2: stages (2, 1, 2, 1) - layer1.1 / layer3.1 are identity-skip Bottlenecks (no downsample path), the kind 12 of
+# RN50's 16 blocks are (clip/model.py:41-60)
+GEOMS = {"rn_tiny_r4g2": C.rn_tiny, "rn_tiny2_r4g2": C.rn_tiny2}
 
 
 def cos(got, ref):
@@ -31,9 +34,9 @@ def rel(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-def setup(dtype, seed=1):
+def setup(dtype, seed=1, tag=TAG):
     from fairfedmed_amd.engine_rn import create_engine, RN50Engine
-    mcfg = C.rn_tiny(rank=4, num_groups=2)
+    mcfg = GEOMS[tag](rank=4, num_groups=2)
     sd = synth.make_state_dict(mcfg, seed=seed, lora_init="random")
     batch = synth.make_batch(mcfg, BS, seed=1234)
     eng = create_engine(mcfg, sd, dtype=dtype, max_images=BS)
@@ -45,12 +48,15 @@ def to_dev(batch):
     return batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda()
 
 
+@pytest.mark.parametrize("TAG", list(GEOMS))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_rn_step_vs_oracle_and_golden(golden_dir, dtype):
+def test_rn_step_vs_oracle_and_golden(golden_dir, dtype, TAG):
     from oracle import fairlora_oracle as O
     gold = np.load(os.path.join(golden_dir, "rn_tiny.npz"))
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
-    mcfg, sd, batch, eng = setup(dtype)
+    mcfg, sd, batch, eng = setup(dtype, tag=TAG)
+    if TAG == "rn_tiny2_r4g2":
+        assert any(not b.has_down for b in eng.blocks), "no identity-skip block in this geometry"
     keys = synth.trainable_keys(mcfg)
     img, attr, label = to_dev(batch)
     out = eng.forward_backward(img, attr, label)
@@ -91,16 +97,17 @@ def test_rn_step_vs_oracle_and_golden(golden_dir, dtype):
             assert rel(bufs[k], ref_sd[k]) < (1e-5 if f32 else 2e-2), k
 
 
-def test_rn_trajectory_fp32(golden_dir):
+@pytest.mark.parametrize("TAG", list(GEOMS))
+def test_rn_trajectory_fp32(golden_dir, TAG):
     """Three SGD steps: loss trajectory, final trainable tensors and BatchNorm buffers vs the reference's."""
     gold = np.load(os.path.join(golden_dir, "rn_tiny.npz"))
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))
-    mcfg, sd, batch, eng = setup(torch.float32)
+    mcfg, sd, batch, eng = setup(torch.float32, tag=TAG)
     img, attr, label = to_dev(batch)
     eng.forward_backward(img, attr, label)      # make_golden.py takes logits / gradients first: one more BatchNorm update
     for ref in meta[f"{TAG}.traj"]:
         out = eng.forward_backward(img, attr, label)
-        eng.sgd_step(1e-3, 0.9, 5e-4)
+        eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)      # the reference's shared optimizer steps twice per batch (quirk 9)
         assert abs(float(out["loss"]) - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (float(out["loss"]), ref)
     for k in synth.trainable_keys(mcfg):
         assert rel(eng.params.view(k), gold[f"{TAG}.post.{k}"]) < 1e-4, k

@@ -265,3 +265,74 @@ def test_personalised_clients_over_two_ranks_equal_the_single_process_driver():
         ref = v.reshape(-1)
         assert torch.allclose(got[0]["flat"][o:o + ref.numel()], ref, rtol=1e-5, atol=1e-7), k
     assert all(abs(a - b) < 1e-6 for a, b in zip(got[0]["acc"], hist["acc"])), (got[0]["acc"], hist["acc"])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# (1) with an unseeded numpy generator every rank used to draw ITS OWN client subset; (2) each rank's StepLR
+# counted only its own client-epochs.  Rank 0's draw is now broadcast, and every rank positions the scheduler from the
+# global count of client-epochs, so both are independent of the world size.
+# ----------------------------------------------------------------------------------------------------------------
+class _SchedTrainer(_FlatTrainer):
+    """_FlatTrainer with the trainer's scheduler surface: one shared StepLR advanced `steps_per_update()` times per local
+    epoch (the reference's two registered names), train() logs where the schedule stood when each client started."""
+    max_epoch = 1
+
+    def __init__(self, users):
+        super().__init__(users)
+        from types import SimpleNamespace as NS
+        self.sched = NS(last_epoch=0, step_size=3, gamma=0.1)
+        self.log = []
+
+    def steps_per_update(self):
+        return 2
+
+    def set_lr_epoch(self, n):
+        self.sched.last_epoch = int(n)
+
+    def train(self, idx, global_epoch, is_fed, is_last_client):
+        self.log.append((global_epoch, idx, self.sched.last_epoch))
+        lr = self.sched.gamma ** (self.sched.last_epoch // self.sched.step_size)
+        self.engine.params.flat.mul_(1.0 + 0.01 * lr * (idx + 1))
+        self.sched.last_epoch += self.max_epoch * self.steps_per_update()
+
+
+def _sched_worker(rank, world, port, outdir, seeded):
+    import numpy as np
+    from fairfedmed_amd import federated as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    np.random.seed(1000 + rank)                       # the ranks' generators disagree unless args.seed aligns them
+    args = F.FedArgs(num_users=4, frac=0.5, round=4, shared_half_s=True, seed=5 if seeded else None)
+    tr = _SchedTrainer(4)
+    hist = F.run_fedotplora_ranks(tr, args, log=lambda *_: None)
+    torch.save({"flat": hist["global_flat"], "log": tr.log, "last_epoch": tr.sched.last_epoch,
+                "keys": {i: sorted(w) for i, w in hist["local_weights_per"].items()}},
+               os.path.join(outdir, f"s{int(seeded)}_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ranks_share_one_client_draw_and_one_lr_schedule():
+    from fairfedmed_amd import federated as F
+    with tempfile.TemporaryDirectory() as d:
+        for seeded in (False, True):
+            mp.spawn(_sched_worker, args=(2, _free_port(), d, seeded), nprocs=2, join=True)
+        un = [torch.load(os.path.join(d, f"s0_{r}.pt")) for r in range(2)]
+        se = [torch.load(os.path.join(d, f"s1_{r}.pt")) for r in range(2)]
+    # unseeded: both ranks still aggregate the SAME participants (rank 0's draw) and end with identical weights
+    assert torch.equal(un[0]["flat"], un[1]["flat"]) and un[0]["last_epoch"] == un[1]["last_epoch"]
+    for rnd in range(1, 4):
+        trained = sorted(i for r in un for (e, i, _) in r["log"] if e == rnd)
+        assert len(trained) == 2 and len(set(trained)) == 2, (rnd, trained)       # frac 0.5 of 4: two DISTINCT clients
+    # seeded: the schedule position every client started from equals the one-process driver's (one shared scheduler
+    # advanced by every client in turn), and so do the final weights
+    tr = _SchedTrainer(4)
+    hist = F.run_fedotplora(tr, F.FedArgs(num_users=4, frac=0.5, round=4, shared_half_s=True, seed=5), log=lambda *_: None)
+    both = sorted(se[0]["log"] + se[1]["log"])
+    assert both == sorted(tr.log), (both, tr.log)
+    assert se[0]["last_epoch"] == se[1]["last_epoch"] == tr.sched.last_epoch
+    p = tr.engine.params
+    for k, v in hist["global_weights"].items():
+        o, s = p.offsets[k]
+        assert torch.allclose(se[0]["flat"][o:o + v.numel()], v.reshape(-1), rtol=1e-5, atol=1e-7), k
+    # the per-client weights the CLI saves exist on every rank, for every client, under the trainable keys
+    assert sorted(se[0]["keys"]) == [0, 1, 2, 3] and se[0]["keys"][0] == sorted(p.offsets)

@@ -1,0 +1,112 @@
+"""BASELINE.json configs[3] and configs[4] AT THEIR STATED GEOMETRY against the oracle (configs_untested):
+
+  * configs[4]: the real RN50 trunk, stages (3, 4, 6, 3) with 12 identity-skip Bottlenecks (clip/model.py:41-60,
+    227-301), FairLoRA r = 8 on conv1 / conv3, G = 2 (gender), plain LoRA on the attention pool, train-mode BatchNorm;
+  * configs[3]: 3D OCT, ViT-B/16 FairLoRA r = 16, G = 3, DIM_PER_3D_SLICE = 8 -> a [1, 200, 224, 224] volume becomes
+    S = 25 ViT images through the trainable 5x5 slice convolution + per-image min-max (trainers/GLP_OT_SVLoRA.py:585-595,
+    681-693).
+
+The oracle's fp32 step runs here on the host (2-8 s each); tolerances as in test_engine_gpu.py / test_engine_rn_gpu.py.
+"""
+import copy
+import dataclasses
+
+import pytest
+import torch
+
+from fairfedmed_amd import config as C
+from fairfedmed_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def cos(got, ref):
+    got = torch.as_tensor(got).double().cpu().flatten()
+    ref = torch.as_tensor(ref).double().cpu().flatten()
+    return float(torch.dot(got, ref) / (got.norm() * ref.norm()).clamp_min(1e-300))
+
+
+def rel(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def to_dev(batch):
+    return batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_full_rn50_step_vs_oracle(dtype):
+    from fairfedmed_amd.engine_rn import create_engine, RN50Engine
+    from oracle import fairlora_oracle as O
+    mcfg = C.rn50(rank=8, num_groups=2)
+    assert tuple(mcfg.vision.layers) == (3, 4, 6, 3)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    bs = 4
+    batch = synth.make_batch(mcfg, bs, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    assert len(keys) == 215 and sum(sd[k].numel() for k in keys) == 466944
+    eng = create_engine(mcfg, sd, dtype=dtype, max_images=bs)
+    assert isinstance(eng, RN50Engine) and len(eng.blocks) == 16
+    assert sum(1 for b in eng.blocks if not b.has_down) == 12                        # identity-skip Bottlenecks
+    out = eng.forward_backward(*to_dev(batch))
+    torch.cuda.synchronize()
+    ref_sd = copy.deepcopy(sd)
+    loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
+    f32 = dtype == torch.float32
+    print("rn50", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
+    assert int(out["finite"]) == 1
+    assert abs(float(out["loss"]) - float(loss)) <= (1e-4 if f32 else 0.1) * abs(float(loss))
+    assert rel(out["logits"], logits) < (1e-4 if f32 else 0.3)
+    if f32:
+        worst, werr = 1.0, 0.0
+        for k in keys:
+            g, ref = eng.params.view(k, "grad"), grads[k]
+            if float(ref.abs().max()) == 0.0:
+                assert float(g.abs().max()) < 1e-12, k
+                continue
+            worst, werr = min(worst, cos(g, ref)), max(werr, rel(g, ref))
+            # near-zero ReLU inputs may take the other branch (see test_engine_rn_gpu.py): direction to 1e-4, size 2e-2
+            assert cos(g, ref) > 1 - 1e-4 and rel(g, ref) < 2e-2, (k, cos(g, ref), rel(g, ref))
+        print("rn50 f32: worst gradient cosine", worst, "worst rel err", werr)
+        bufs = eng.buffer_state()
+        for k in synth.buffer_keys(mcfg):
+            if k.endswith("num_batches_tracked"):
+                assert int(bufs[k]) == int(ref_sd[k]) == 1, k
+            else:
+                assert rel(bufs[k], ref_sd[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_full_size_3d_oct_step_vs_oracle(dtype):
+    from fairfedmed_amd.engine import FairLoRAEngine
+    from oracle import fairlora_oracle as O
+    mcfg = dataclasses.replace(C.vit_b16(rank=16), dim_per_3d_slice=8)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    B, S = 1, 25
+    batch = synth.make_batch(mcfg, B, seed=3, slices=S, signal=0.2)
+    assert tuple(batch["img"].shape) == (1, 200, 224, 224)
+    keys = synth.trainable_keys(mcfg)
+    assert sum(sd[k].numel() for k in keys) == 1480411
+    eng = FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=B * S)
+    out = eng.forward_backward(*to_dev(batch))
+    torch.cuda.synchronize()
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    f32 = dtype == torch.float32
+    print("oct3d", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
+    assert int(out["finite"]) == 1
+    assert abs(float(out["loss"]) - float(loss)) <= (1e-4 if f32 else 1e-2) * abs(float(loss))
+    assert rel(out["logits"], logits) < (1e-4 if f32 else 5e-2)
+    worst, werr = 1.0, 0.0
+    for k in keys:
+        g, ref = eng.params.view(k, "grad"), grads[k]
+        if float(ref.abs().max()) == 0.0:
+            assert float(g.abs().max()) < 1e-12, k
+            continue
+        worst, werr = min(worst, cos(g, ref)), max(werr, rel(g, ref))
+        if f32:
+            assert rel(g, ref) < 5e-3, (k, rel(g, ref))
+        else:
+            assert cos(g, ref) > 0.97, (k, cos(g, ref))
+    print("oct3d", dtype, "worst gradient cosine", worst, "worst rel err", werr)

@@ -212,10 +212,16 @@ def test_scores_from_counts_equal_the_sort_based_scores():
     pred = prob.argmax(-1)
     acc, err, f1, auc = M.basic_from_counts(tables[0])
     assert abs(acc - 100.0 * (pred == y).mean()) < 1e-12 and abs(err - (100 - acc)) < 1e-12
-    assert abs(f1 - 100.0 * M.macro_f1(pred, y, 2)) < 1e-12 and abs(auc - M.auc_macro_ovr(prob, y)) < 1e-12
+    assert abs(f1 - 100.0 * M.macro_f1(pred, y, 2)) < 1e-12 and abs(auc - 100.0 * M.auc_macro_ovr(prob, y)) < 1e-10
     # a single-class set reports AUC 1 (trainers/GLP_OT_SVLoRA.py:965-967)
     one = _brute_counts(prob, np.ones(N, np.int64), a0, 8)
-    assert M.basic_from_counts(one)[3] == 1.0
+    res = M.basic_from_counts(one)
+    assert res[3] == 100.0
+    # macro-F1 runs over the classes present in the labels only (f1_score(labels=np.unique(y_true)),
+    # evaluation/evaluator_oph.py:70-75): with one class present it is that class's F1, not half of it
+    assert abs(res[2] - 100.0 * M.macro_f1(pred, np.ones(N, np.int64), 2)) < 1e-12
+    tp, fn = float((pred == 1).sum()), float((pred == 0).sum())
+    assert abs(res[2] - 100.0 * 2 * tp / (2 * tp + fn)) < 1e-12
 
 
 def test_cli_flags_config_tree_and_scope(tmp_path):

@@ -62,7 +62,7 @@ def test_ot_head_step_vs_reference_golden_and_oracle(golden_dir, ot, top, dtype)
     if f32:                                                            # three SGD steps on the reference's trajectory
         for i, ref in enumerate(meta[f"{tag}.traj"]):
             o = out if i == 0 else eng.forward_backward(*to_dev(batch))
-            eng.sgd_step(1e-3, 0.9, 5e-4)
+            eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)                   # shared optimizer, two names (quirk 9)
             assert abs(float(o["loss"]) - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (i, float(o["loss"]), ref)
 
 

@@ -178,7 +178,8 @@ def test_trainer_reproduces_reference_trajectory(golden_dir):
 
 
 def test_trainer_round_api_and_lr_schedule(tmp_path):
-    """train()/test()/state_dict round trip as federated_main.py uses them; StepLR once per local epoch."""
+    """train()/test()/state_dict round trip as federated_main.py uses them; the shared StepLR is stepped once per
+    registered model name, i.e. twice per local epoch (Dassl/dassl/engine/trainer.py:253-258)."""
     from fairfedmed_amd.trainer import GLP_OT_SVLoRA, SyntheticFedData
     mcfg = C.vit_tiny(rank=4)
     cfg = make_cfg(prec="bf16")
@@ -195,9 +196,12 @@ def test_trainer_round_api_and_lr_schedule(tmp_path):
             tr.model.load_state_dict(global_weights, strict=False)
             tr.train(idx=idx, global_epoch=rnd, is_fed=True)
             lrs.append(tr.get_current_lr())
-    assert lrs[0] == 1e-3 and abs(lrs[1] - 1e-4) < 1e-12 and abs(lrs[-1] - 1e-6) < 1e-15   # gamma .1 every 2 epochs
+    # StepLR(step_size 2, gamma .1) advanced by 2 per client-epoch: one decade per client-epoch
+    assert abs(lrs[0] - 1e-4) < 1e-12 and abs(lrs[1] - 1e-5) < 1e-13 and abs(lrs[-1] - 1e-9) < 1e-17
+    assert tr.sched.last_epoch == 12
     res = tr.test(idx=0, current_epoch=0)
-    assert len(res) == 4 and 0 <= res[3] <= 1 and abs(res[0] + res[1] - 100) < 1e-9
+    assert len(res) == 4 and 0 <= res[3] <= 100 and abs(res[0] + res[1] - 100) < 1e-9
+    assert res[3] > 1.0 or res[3] == 0.0                             # percent, like the reference's evaluator
     assert os.path.exists(os.path.join(str(tmp_path), "epoch2_client1.pth"))
     saved = torch.load(os.path.join(str(tmp_path), "epoch2_client1.pth"))
     assert "prompt_learner.ctx" in saved and "prompt_learner.token_prefix" in saved
@@ -405,7 +409,8 @@ def test_cli_runs_the_fairlora_script_on_files(tmp_path):
     for idx in range(3):
         w = torch.load(out / f"global_client{idx}_final.pth")
         assert "prompt_learner.ctx" in w and any("lora_S" in k for k in w)
-        assert not any("original_linear" in k for k in w)
+        # the reference saves every client's FULL state_dict (federated_main.py:771-774): same keys, same order
+        assert list(w.keys()) == list(synth.manifest(C.vit_tiny(rank=4)).keys())
     assert any("Global test acc" in ln for ln in lines) and any("maximum test acc" in ln for ln in lines)
     # --eval-only --model-dir: evaluate every client with weights loaded through the trainer's load_model hook
     from fairfedmed_amd.registry import build_trainer  # noqa: F401
@@ -472,7 +477,7 @@ def test_svlora_linear_vs_reference_golden(golden_dir, dtype):
 def test_cli_under_torch_distributed_run_two_ranks(tmp_path):
     """The command line launched as `python -m torch.distributed.run --nproc-per-node 2 -m fairfedmed_amd.federated_main`
     (one client per rank; here both ranks share the test box's GPU over gloo, FFM_ONE_DEVICE=1): rounds run, ranks agree,
-    rank 0 writes the final global buffer."""
+    rank 0 writes global_client{idx}_final.pth."""
     import subprocess
     import sys
     from fairfedmed_amd import data as D
@@ -491,8 +496,12 @@ def test_cli_under_torch_distributed_run_two_ranks(tmp_path):
     r = subprocess.run(cmd, cwd=root, env=dict(os.environ, FFM_ONE_DEVICE="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "global_test_acc_list:" in r.stdout and "round 1:" in r.stdout
-    flat = torch.load(out / "global_flat_final.pth")
-    assert flat.dim() == 1 and flat.numel() > 1000 and bool(torch.isfinite(flat).all())
+    # rank 0 writes the reference's per-client files here too (full state_dicts rebuilt from the flat buffers)
+    for idx in range(2):
+        w = torch.load(out / f"global_client{idx}_final.pth")
+        assert list(w.keys()) == list(synth.manifest(C.vit_tiny(rank=4)).keys())
+        assert all(bool(torch.isfinite(v.float()).all()) for v in w.values())
+    assert not (out / "global_flat_final.pth").exists()
 
 
 def test_rn_state_dict_keys_order_dtypes_and_live_buffers():
