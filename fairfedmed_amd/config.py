@@ -83,6 +83,13 @@ class LoraCfg:
     alpha: float = 2.0
     num_groups: int = 3       # G = len(retrieval_attributes(ATTRIBUTE_TYPE))
     lambda_group: float = 0.7  # trainers/GLP_OT_SVLoRA.py:459
+    # TRAINER.GLP_OT_LORA.TYPE (trainers/GLP_OT_SVLoRA.py:516-540): 'FairLoRA' (every script), 'SVLoRA' (one shared
+    # diagonal, lora_S is a 1-D [r] tensor after reset_parameters) or 'LoRA' (no lora_S).  The last two ignore the
+    # attribute: set num_groups = 1.
+    lora_type: str = "FairLoRA"
+    # TRAINER.GLP_OT_LORA.GLOBAL_S: one more trainable vector lora_S_global [r] (1-D after reset_parameters,
+    # :418-422 / :300-304) added to every sample's singular values: s_b = pi_b S + S_global
+    global_s: bool = False
 
     @property
     def scaling(self) -> float:  # trainers/GLP_OT_SVLoRA.py:346
@@ -172,3 +179,12 @@ def rn_tiny2(rank: int = 4, alpha: float = 2.0, num_groups: int = 2) -> ModelCfg
     import dataclasses
     base = rn_tiny(rank=rank, alpha=alpha, num_groups=num_groups)
     return dataclasses.replace(base, vision=dataclasses.replace(base.vision, layers=(2, 1, 2, 1)))
+
+
+def vit_tiny_lora(lora_type: str = "FairLoRA", global_s: bool = False, rank: int = 4) -> ModelCfg:
+    """vit_tiny with another adapter type of apply_lora_to_model (trainers/GLP_OT_SVLoRA.py:516-540) and / or GLOBAL_S;
+    LoRA and SVLoRA have no demographic groups (num_groups = 1)."""
+    import dataclasses
+    base = vit_tiny(rank=rank)
+    G = base.lora.num_groups if lora_type == "FairLoRA" else 1
+    return dataclasses.replace(base, lora=dataclasses.replace(base.lora, lora_type=lora_type, global_s=global_s, num_groups=G))

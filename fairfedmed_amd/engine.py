@@ -74,6 +74,71 @@ class FlatParams:
                             dtype=torch.int64, device=self.flat.device)
 
 
+class SOperands:
+    """The singular-value operand S [Geff, r] (and the tensor that receives dS) of every adapter, by prefix
+    ('...mlp.c_fc.'), for the adapter types of apply_lora_to_model (trainers/GLP_OT_SVLoRA.py:516-540):
+
+      FairLoRA            lora_S [G, r] itself (a view of the flat buffer), gradient straight into its grad view;
+      SVLoRA              lora_S [r] viewed as one group [1, r] (one diagonal shared by all samples, :307-311);
+      LoRA                a constant row of ones (:241-242), dS discarded;
+      ... + GLOBAL_S      s_b = pi_b S + S_global (:300-304, 418-422, 467-468).  The group mix sums to one, so this is
+                          the same kernel call on S_eff[g] = S[g] + S_global, with dS[g] = dS_eff[g] and
+                          dS_global = sum_g dS_eff[g]: S_eff is refreshed once per step (`prepare`) and the two gradients
+                          are scattered after the reduction (`finish`), three small launches for all adapters together.
+    """
+
+    def __init__(self, params: FlatParams, prefixes: List[str], cfg: ModelCfg, device):
+        lo = cfg.lora
+        self.params, self.r = params, lo.rank
+        self.type, self.glob = getattr(lo, "lora_type", "FairLoRA"), bool(getattr(lo, "global_s", False))
+        if self.type not in ("FairLoRA", "SVLoRA", "LoRA"):
+            raise NotImplementedError(self.type)                   # trainers/GLP_OT_SVLoRA.py:533-534
+        if self.type != "FairLoRA" and lo.num_groups != 1:
+            raise ValueError(f"lora_type {self.type} has no demographic groups: set num_groups = 1")
+        self.G = lo.num_groups
+        self.glob = self.glob and self.type != "LoRA"
+        self.index = {p: i for i, p in enumerate(prefixes)}
+        n, G, r = len(prefixes), self.G, self.r
+        f32 = torch.float32
+        if self.type == "LoRA":
+            self.ones = torch.ones(1, r, device=device, dtype=f32)
+            self.scratch = torch.zeros(n, 1, r, device=device, dtype=f32)
+        if self.glob:
+            base = torch.arange(G * r, device=device)
+            self.idx_S = torch.stack([params.offsets[p + "lora_S.weight"][0] + base for p in prefixes])       # [n, G*r]
+            self.idx_G = torch.stack([params.offsets[p + "lora_S_global.weight"][0] + base[:r] for p in prefixes])
+            self.eff = torch.zeros(n, G, r, device=device, dtype=f32)
+            self.deff = torch.zeros(n, G, r, device=device, dtype=f32)
+        self.prefixes = prefixes
+
+    def op(self, prefix: str) -> Tensor:
+        i = self.index[prefix]
+        if self.type == "LoRA":
+            return self.ones
+        if self.glob:
+            return self.eff[i]
+        return self.params.view(prefix + "lora_S.weight").view(self.G, self.r)
+
+    def grad(self, prefix: str) -> Tensor:
+        i = self.index[prefix]
+        if self.type == "LoRA":
+            return self.scratch[i]
+        if self.glob:
+            return self.deff[i]
+        return self.params.view(prefix + "lora_S.weight", "grad").view(self.G, self.r)
+
+    def prepare(self) -> None:
+        if self.glob:
+            flat = self.params.flat
+            torch.add(flat[self.idx_S].view(-1, self.G, self.r), flat[self.idx_G].view(-1, 1, self.r), out=self.eff)
+
+    def finish(self) -> None:
+        if self.glob:
+            g = self.params.grad
+            g[self.idx_S.view(-1)] = self.deff.view(-1)
+            g[self.idx_G.view(-1)] = self.deff.sum(1).view(-1)
+
+
 def _ds_rows(rows: int, N: int, K: int, rank: int, dtype, packed: Optional[bool] = None, dgelu: bool = False) -> int:
     """dS partial rows a FairLoRA dX GEMM writes (packed=None: the larger of the kernels ffm_gemm_nt may pick)."""
     fl = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_RANKOP | (L.EPI_DGELU if dgelu else 0)
@@ -268,6 +333,9 @@ class FairLoRAEngine:
         cfg, v, dtype, dev = self.cfg, self.cfg.vision, self.dtype, self.device
         # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
         self.fused_rank = 0 < cfg.lora.rank <= 16
+        ie = "image_encoder.transformer.resblocks."
+        self.sops = SOperands(self.params, [f"{ie}{i}.mlp.c_{n}." for i in range(v.layers) for n in ("fc", "proj")],
+                              cfg, dev)
         if self.fused_rank:
             w = v.width
             ent = []
@@ -371,6 +439,12 @@ class FairLoRAEngine:
     def _lora_view(self, blk: _Block, role: str) -> Tensor:
         return self.params.view(blk.lora[role])
 
+    def _S(self, layer: int, which: str) -> Tensor:
+        return self.sops.op(f"image_encoder.transformer.resblocks.{layer}.mlp.c_{which}.")
+
+    def _dS(self, layer: int, which: str) -> Tensor:
+        return self.sops.grad(f"image_encoder.transformer.resblocks.{layer}.mlp.c_{which}.")
+
     def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
                        save: bool = True) -> Tensor:
         """x[0][:rows] holds the tower input; returns the tower output view."""
@@ -387,20 +461,20 @@ class FairLoRAEngine:
             ops.gemm_nt(o, blk.w_out, xm, bias=blk.b_out, res=x, b_packed=blk.pk("w_out"))
             ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
             if r and self.fused_rank:
-                ro = ops.RankOp(self.rk[i]["fc_A"], self._lora_view(blk, "fc_S"), attr, rows_per_sample, lo.scaling,
+                ro = ops.RankOp(self.rk[i]["fc_A"], self._S(i, "fc"), attr, rows_per_sample, lo.scaling,
                                 lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i])
                 ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
                             b_packed=blk.pk("w_fc"))
-                ro = ops.RankOp(self.rk[i]["proj_A"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
+                ro = ops.RankOp(self.rk[i]["proj_A"], self._S(i, "proj"), attr, rows_per_sample,
                                 lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i])
                 ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
                             res=xm, rankop=ro, b_packed=blk.pk("w_proj"))
             elif r:
-                ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._lora_view(blk, "fc_S"), attr, r, G,
+                ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._S(i, "fc"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
                 ops.gemm_nt(h2, blk.w_fc, pre, bias=blk.b_fc, ts=st.ts1[i], lw=self._lora_view(blk, "fc_B"),
                             gelu_out=act)
-                ops.lora_down(act, self._lora_view(blk, "proj_A"), False, self._lora_view(blk, "proj_S"), attr, r, G,
+                ops.lora_down(act, self._lora_view(blk, "proj_A"), False, self._S(i, "proj"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t2[i], st.ts2[i])
                 ops.gemm_nt(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, ts=st.ts2[i],
                             lw=self._lora_view(blk, "proj_B"), res=xm)
@@ -432,23 +506,23 @@ class FairLoRAEngine:
                 # ---- critical path: u = g B^T and dX (+ LoRA dx term), dS partials
                 fused = self.fused_rank
                 if fused:
-                    ro = ops.RankOp(self.rk[i]["proj_B"], self._lora_view(blk, "proj_S"), attr, rows_per_sample,
+                    ro = ops.RankOp(self.rk[i]["proj_B"], self._S(i, "proj"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"])
                     ops.gemm_nt(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                                 dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"))
                 else:
-                    ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._lora_view(blk, "proj_S"), attr, r, G,
+                    ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._S(i, "proj"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
                     ops.gemm_nt(gi, blk.w_proj_t, dpre, ts=us2, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                                 dgelu_aux=pre)
                 if fused and not last:
                     # u1 = dpre B_fc^T rides inside the dX GEMM of c_fc
-                    ro = ops.RankOp(self.rk[i]["fc_B"], self._lora_view(blk, "fc_S"), attr, rows_per_sample,
+                    ro = ops.RankOp(self.rk[i]["fc_B"], self._S(i, "fc"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"])
                     ops.gemm_nt(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
                                 rankop=ro, b_packed=blk.pk("w_fc_t"))
                 else:
-                    ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._lora_view(blk, "fc_S"), attr, r, G,
+                    ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._S(i, "fc"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
                 self._ev_record(self.ev_layer[i], main)
@@ -477,6 +551,8 @@ class FairLoRAEngine:
         if r:
             with self._on(self.grad_stream):
                 self._reduce_plan(st, rows, need_input_grad).run()
+            if self.sops.glob:
+                self._glue(self.sops.finish, self.grad_stream)     # dS_eff -> dS, dS_global
             self._ev_record(self.ev_grads, self.grad_stream)
             self._ev_wait(main, self.ev_grads)
         return g
@@ -498,7 +574,7 @@ class FairLoRAEngine:
                     else ops.lora_down_blocks(rows, w, r, self.dtype)
                 nb_f = _ds_rows(rows, w, 4 * w, r, self.dtype, pk) if (self.fused_rank and (li > 0 or full_bwd)) \
                     else ops.lora_down_blocks(rows, 4 * w, r, self.dtype)
-                ent += [(pt["proj_S"], nb_p, G * r, gv("proj_S"), 0, 0), (pt["fc_S"], nb_f, G * r, gv("fc_S"), 0, 0),
+                ent += [(pt["proj_S"], nb_p, G * r, self._dS(li, "proj"), 0, 0), (pt["fc_S"], nb_f, G * r, self._dS(li, "fc"), 0, 0),
                         (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),
                         (pt["fc_B"], nsp, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
             st.plans[key] = ops.ReducePlan(ent, self.device)
@@ -655,6 +731,8 @@ class FairLoRAEngine:
         a32 = self.attr_i32[:b] if has_attr else None
         if self.fused_rank:
             self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
+        if self.sops.glob:
+            self._glue(self.sops.prepare)             # S_eff = S + S_global
         ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
                         self.vis.x[0][:rows], images, L)
@@ -708,6 +786,8 @@ class FairLoRAEngine:
     @torch.no_grad()
     def forward(self, image: Tensor, attr: Optional[Tensor] = None) -> Tensor:
         """CustomCLIP.forward(image, attr) -> logits [B, n_cls] (inference)."""
+        if self.sops.type != "FairLoRA":
+            attr = None                               # LoRALinear / SVLoRALinear.forward ignore attr (:241, :307)
         b, S = self._load_inputs(image, attr, None)
         self._text_forward(False)
         self._vision_forward(b, S, attr is not None)
@@ -740,6 +820,8 @@ class FairLoRAEngine:
         """Forward, CE loss, backward; gradients of every trainable tensor land in params.grad.
         Returns device tensors (no host sync): loss [1], logits [B,n_cls], prob [B,n_cls], finite [1].
         The first call for a batch shape records the step's launch plan; later calls replay it."""
+        if self.sops.type != "FairLoRA":
+            attr = None
         with torch.no_grad():
             b, S = self._load_inputs(image, attr, label)
             key = (b, S, attr is not None, torch.cuda.current_stream(self.device).cuda_stream)

@@ -33,6 +33,7 @@ class _Lora:
         self.eng, self.K, self.N, self.fair = eng, K, N, fair
         self.kA, self.kB = prefix + "lora_A.weight", prefix + "lora_B.weight"
         self.kS = prefix + "lora_S.weight" if fair else None
+        self.prefix = prefix
         lo, dt = eng.cfg.lora, eng.dtype
         r = lo.rank
         f = lambda *s: torch.zeros(*s, device=eng.device, dtype=torch.float32)
@@ -58,7 +59,7 @@ class _Lora:
 
     def _s(self) -> Tuple[Tensor, int]:
         e = self.eng
-        return (e.params.view(self.kS), e.cfg.lora.num_groups) if self.fair else (e.ones_s, 1)
+        return (e.sops.op(self.prefix), e.cfg.lora.num_groups) if self.fair else (e.ones_s, 1)
 
     def fwd(self, x: Tensor, W: Tensor, out: Tensor, attr: Optional[Tensor], rps: int, bias=None, res=None) -> None:
         e, lo = self.eng, self.eng.cfg.lora
@@ -97,7 +98,7 @@ class _Lora:
         ent = [(self.pB, nsp, self.N * r, gv(self.kB), self.N, r), (self.pA, nsp, self.K * r, gv(self.kA), 0, 0)]
         if self.fair:
             nb = self._tiles(rows) if self.fused else ops.lora_down_blocks(rows, self.N, r, e.dtype)
-            ent.append((self.pS, nb, lo.num_groups * r, gv(self.kS), 0, 0))
+            ent.append((self.pS, nb, lo.num_groups * r, e.sops.grad(self.prefix), 0, 0))
         return ent
 
 
@@ -288,6 +289,11 @@ class RN50Engine(FairLoRAEngine):
         self.nbt = torch.zeros(len(self.bns), device=dev, dtype=torch.int64)
 
     def _init_vision_late(self) -> None:
+        from .engine import SOperands
+        if getattr(self.cfg.lora, "lora_type", "FairLoRA") != "FairLoRA":
+            raise NotImplementedError(self.cfg.lora.lora_type)    # trainers/GLP_OT_SVLoRA.py:561-567: ResNet knows FairLoRA only
+        self.sops = SOperands(self.params, [site.prefix for blk in self.blocks for site, _ in blk.loras()], self.cfg,
+                              self.device)
         self.fused_rank = 0 < self.cfg.lora.rank <= 16
         self.pack_plan = ops.PackPlan(self.pack_entries, self.dtype, self.device) if self.fused_rank else None
 
@@ -403,6 +409,8 @@ class RN50Engine(FairLoRAEngine):
         sz, sa = [t[:r1] for t in self.sz], [t[:r1] for t in self.sa]
         if self.pack_plan is not None:
             self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
+        if self.sops.glob:
+            self._glue(self.sops.prepare)             # S_eff = S + S_global (GLOBAL_S)
         ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0])
         self.sbn[0].fwd(sz[0], sa[0], True)
         for i, wn in ((1, "s2"), (2, "s3")):
@@ -456,6 +464,8 @@ class RN50Engine(FairLoRAEngine):
         ops.conv3x3(dsz[1], W["s2b"], dsa[0], b, H1, H1, self.zero16)
         self.sbn[0].bwd(dsa[0], sa[0], sz[0], dsz[0])
         self._reduce(b).run()
+        if self.sops.glob:
+            self._glue(self.sops.finish)
 
     def _reduce(self, b: int) -> "ops.ReducePlan":
         if b not in self.rn_plans:

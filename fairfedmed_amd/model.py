@@ -142,8 +142,6 @@ class FairLoRALinear(nn.Module):
                  num_attrs: int = 1):
         super().__init__()
         assert num_attrs > 0, "Number of attributes must be provided!"
-        if global_s:
-            raise NotImplementedError("GLOBAL_S is False in every FairLoRA script; not built")
         self.is_1x1_conv = isinstance(original_linear, nn.Conv2d)
         if self.is_1x1_conv:
             # RN50 form (trainers/GLP_OT_SVLoRA.py:344-352, 469-480): a 1x1 convolution is the same product on the
@@ -156,7 +154,10 @@ class FairLoRALinear(nn.Module):
         self.original_linear = original_linear
         self.rank, self.alpha, self.scaling = rank, alpha, alpha / rank
         self.global_s, self.num_attrs = global_s, num_attrs
-        self.lora_A, self.lora_S, self.lora_B = _Emb(fin, rank), _Emb(num_attrs, rank), _Emb(rank, fout)
+        self.lora_A, self.lora_S = _Emb(fin, rank), _Emb(num_attrs, rank)
+        if global_s:
+            self.lora_S_global = _Emb(1, rank)                     # registered between lora_S and lora_B (:359-363)
+        self.lora_B = _Emb(rank, fout)
         dev = original_linear.weight.device
         self.to(dev)
         for p in self.original_linear.parameters():
@@ -168,7 +169,32 @@ class FairLoRALinear(nn.Module):
         """A = 0, B ~ N(0,1), S 'same+cycle' (trainers/GLP_OT_SVLoRA.py:380-423)."""
         nn.init.zeros_(self.lora_A.weight)
         self.lora_S.weight.data.copy_(lora_s_init(self.rank, self.num_attrs))
+        if self.global_s:                                          # a 1-D [r] tensor replaces the [1, r] weight (:418-422)
+            self.lora_S_global.weight.data = torch.linspace(1, 0.1, steps=self.rank, device=self.lora_S.weight.device)
         nn.init.normal_(self.lora_B.weight)
+
+    def _s(self) -> Tensor:
+        """[G, r] singular values the kernels mix per sample; under GLOBAL_S s_b = pi_b S + S_global = pi_b (S + S_global)
+        because the mix sums to one (autograd splits the gradient between the two tensors)."""
+        return self.lora_S.weight + self.lora_S_global.weight[None] if self.global_s else self.lora_S.weight
+
+    def weight(self, x: Tensor, attr: Optional[Tensor] = None) -> Tensor:
+        """Per-sample dense weights W + scaling (A diag(s_b) B)^T, [x.shape[1], out, in]
+        (trainers/GLP_OT_SVLoRA.py:425-445).  As in the reference this mixes with the PLAIN one-hot (s_b = S[attr_b], or
+        the uniform mean without attr), not with forward()'s 0.7 / 0.3 mix, and it is differentiable in the LoRA
+        factors.  A materialisation helper off the hot path (the reference itself only consumes LoRALinear.weight(),
+        in the attention pool): plain tensor algebra on whatever device the parameters live on."""
+        if attr is not None:
+            pi = torch.nn.functional.one_hot(attr, num_classes=self.num_attrs).to(x.device, x.dtype)
+        else:
+            pi = torch.ones(1, self.num_attrs, device=x.device, dtype=x.dtype) / self.num_attrs
+        s = pi @ self.lora_S.weight
+        if self.global_s:
+            s = s + self.lora_S_global.weight[None]
+        s = s[:, None].repeat(1, x.shape[1] // s.shape[0], 1).flatten(0, 1)          # every sample's slices (:437-438)
+        dw = (self.lora_A.weight[None] * s[:, None, :]) @ self.lora_B.weight          # [rows, in, out]
+        w = self.original_linear.weight
+        return w.reshape(w.shape[0], -1)[None] + self.scaling * dw.permute(0, 2, 1)
 
     def bias(self):
         return self.original_linear.bias
@@ -192,7 +218,7 @@ class FairLoRALinear(nn.Module):
             x2d = x.permute(0, 2, 3, 1).reshape(Bn * H * Wd, fin).contiguous()
             bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
             a32 = None if attr is None else attr.to(torch.int32).contiguous()
-            y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight, self.lora_B.weight, a32,
+            y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self._s(), self.lora_B.weight, a32,
                                   H * Wd * (Bn // b), self.scaling, 0.7)
             return y.reshape(Bn, H, Wd, -1).permute(0, 3, 1, 2)
         L, Bn, fin = x.shape
@@ -202,7 +228,7 @@ class FairLoRALinear(nn.Module):
         x2d = x.permute(1, 0, 2).reshape(Bn * L, fin).contiguous()          # image-major rows
         bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
         a32 = None if attr is None else attr.to(torch.int32).contiguous()
-        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight, self.lora_B.weight, a32,
+        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self._s(), self.lora_B.weight, a32,
                               L * S, self.scaling, 0.7)
         return y.reshape(Bn, L, -1).permute(1, 0, 2)
 
@@ -255,12 +281,12 @@ class SVLoRALinear(nn.Module):
 
     def __init__(self, original_linear: nn.Linear, rank: int = 4, alpha: float = 0.4, global_s: bool = False):
         super().__init__()
-        if global_s:
-            raise NotImplementedError("GLOBAL_S is False in every script; not built")
         self.original_linear = original_linear
         self.rank, self.alpha, self.scaling, self.global_s = rank, alpha, alpha / rank, global_s
-        self.lora_A, self.lora_B = _Emb(original_linear.in_features, rank), _Emb(rank, original_linear.out_features)
-        self.lora_S = _Emb(rank, 1)
+        self.lora_A, self.lora_S = _Emb(original_linear.in_features, rank), _Emb(rank, 1)
+        if global_s:
+            self.lora_S_global = _Emb(rank, 1)                     # :272-273
+        self.lora_B = _Emb(rank, original_linear.out_features)
         self.to(original_linear.weight.device)
         for p in self.original_linear.parameters():
             p.requires_grad = False
@@ -270,6 +296,8 @@ class SVLoRALinear(nn.Module):
     def reset_parameters(self):
         nn.init.zeros_(self.lora_A.weight)
         self.lora_S.weight.data = torch.linspace(1, 0.1, steps=self.rank, device=self.lora_S.weight.device)
+        if self.global_s:                                          # :300-304
+            self.lora_S_global.weight.data = torch.linspace(1, 0.1, steps=self.rank, device=self.lora_S.weight.device)
         nn.init.normal_(self.lora_B.weight)
 
     _frozen = FairLoRALinear._frozen
@@ -281,7 +309,8 @@ class SVLoRALinear(nn.Module):
         W, Wt = self._frozen(x.dtype)
         x2d = x.reshape(-1, fin).contiguous()
         bias = None if self.original_linear.bias is None else self.original_linear.bias.detach().float()
-        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, self.lora_S.weight.view(1, -1), self.lora_B.weight,
+        s = self.lora_S.weight + self.lora_S_global.weight if self.global_s else self.lora_S.weight     # :307-309
+        y = _FairLoRAFn.apply(x2d, W, Wt, bias, self.lora_A.weight, s.view(1, -1), self.lora_B.weight,
                               None, x2d.shape[0], self.scaling, 0.7)
         return y.reshape(*lead, -1)
 

@@ -58,7 +58,7 @@ def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
             m[q + "original_linear.weight"] = (fout, fin)
             m[q + "original_linear.bias"] = (fout,)
             m[q + "lora_A.weight"] = (fin, lo.rank)
-            m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+            _manifest_s(m, q, lo)
             m[q + "lora_B.weight"] = (lo.rank, fout)
         m[p + "ln_2.weight"] = (v.width,)
         m[p + "ln_2.bias"] = (v.width,)
@@ -66,6 +66,21 @@ def manifest(cfg: ModelCfg) -> "OrderedDict[str, Tuple[int, ...]]":
     m[ie + "ln_post.bias"] = (v.width,)
     _manifest_text(m, cfg)
     return m
+
+
+def _manifest_s(m, q: str, lo) -> None:
+    """lora_S (and lora_S_global) of one adapter, in the reference's registration order (A, S, S_global, B).  SVLoRA's
+    lora_S and both types' lora_S_global are 1-D [r]: reset_parameters replaces the Embedding weight by a linspace
+    (trainers/GLP_OT_SVLoRA.py:294-304, 418-422)."""
+    lt = getattr(lo, "lora_type", "FairLoRA")
+    if lt == "FairLoRA":
+        m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+    elif lt == "SVLoRA":
+        m[q + "lora_S.weight"] = (lo.rank,)
+    elif lt != "LoRA":
+        raise NotImplementedError(lt)
+    if getattr(lo, "global_s", False) and lt != "LoRA":
+        m[q + "lora_S_global.weight"] = (lo.rank,)
 
 
 def _bn(m, p: str, c: int) -> None:
@@ -97,7 +112,7 @@ def _manifest_resnet(m, cfg: ModelCfg) -> None:
                 q = p + name + "."
                 m[q + "original_linear.weight"] = (cout, cin, 1, 1)
                 m[q + "lora_A.weight"] = (cin, lo.rank)
-                m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+                _manifest_s(m, q, lo)
                 m[q + "lora_B.weight"] = (lo.rank, cout)
             _bn(m, p + "bn1.", planes)
             m[p + "conv2.weight"] = (planes, planes, 3, 3)
@@ -105,7 +120,7 @@ def _manifest_resnet(m, cfg: ModelCfg) -> None:
             q = p + "conv3."
             m[q + "original_linear.weight"] = (planes * 4, planes, 1, 1)
             m[q + "lora_A.weight"] = (planes, lo.rank)
-            m[q + "lora_S.weight"] = (lo.num_groups, lo.rank)
+            _manifest_s(m, q, lo)
             m[q + "lora_B.weight"] = (lo.rank, planes * 4)
             _bn(m, p + "bn3.", planes * 4)
             if stride > 1 or inpl != planes * 4:
@@ -255,8 +270,13 @@ def make_state_dict(cfg: ModelCfg, seed: int = 1, lora_init: str = "reference") 
                 x = g.standard_normal(shape, dtype=np.float32) * 0.05
         elif key.endswith("lora_B.weight"):
             x = g.standard_normal(shape, dtype=np.float32)
-        elif key.endswith("lora_S.weight"):
+        elif key.endswith("lora_S.weight") and len(shape) == 2:
             x = lora_s_init(lo.rank, lo.num_groups).numpy().astype(np.float32)
+            if lora_init != "reference":
+                x = x + g.standard_normal(shape, dtype=np.float32) * 0.05
+        elif key.endswith("lora_S.weight") or key.endswith("lora_S_global.weight"):
+            # SVLoRA's shared diagonal and GLOBAL_S: linspace(1, 0.1, r) (trainers/GLP_OT_SVLoRA.py:294-304, 418-422)
+            x = np.linspace(1.0, 0.1, lo.rank, dtype=np.float32)
             if lora_init != "reference":
                 x = x + g.standard_normal(shape, dtype=np.float32) * 0.05
         else:

@@ -132,10 +132,11 @@ class GLP_OT_SVLoRA:
     def model_cfg(self) -> C.ModelCfg:
         cfg = self.cfg
         lora = cfg.TRAINER.GLP_OT_LORA
-        if lora.TYPE != "FairLoRA":
-            raise NotImplementedError(lora.TYPE)
+        if lora.TYPE not in ("FairLoRA", "SVLoRA", "LoRA"):
+            raise NotImplementedError(lora.TYPE)                       # trainers/GLP_OT_SVLoRA.py:533-534
         disable = getattr(lora, "DISABLE_ATTR", False)
-        G = 1 if disable else len(self.retrieval_attributes(cfg.DATASET.ATTRIBUTE_TYPE))
+        # LoRA / SVLoRA carry no per-group singular values: one group, the attribute is ignored by their forward
+        G = 1 if (disable or lora.TYPE != "FairLoRA") else len(self.retrieval_attributes(cfg.DATASET.ATTRIBUTE_TYPE))
         names = list(self.dm.dataset.classnames)
         got = cfg.TRAINER.GLP_OT
         if str(got.OT) not in ("None", "Sinkhorn", "COT"):
@@ -150,7 +151,8 @@ class GLP_OT_SVLoRA:
         # 3D modalities go through the trainable per-slice conv (trainers/GLP_OT_SVLoRA.py:584-586)
         is_3d = getattr(cfg.DATASET, "MODALITY_TYPE", "slo_fundus") in MODALITIES_3D
         return C.ModelCfg(vision=base.vision, text=base.text,
-                          lora=C.LoraCfg(rank=lora.RANK, alpha=lora.ALPHA, num_groups=G),
+                          lora=C.LoraCfg(rank=lora.RANK, alpha=lora.ALPHA, num_groups=G, lora_type=lora.TYPE,
+                                         global_s=bool(getattr(lora, "GLOBAL_S", False))),
                           n_prompts=cfg.TRAINER.GLP_OT.N, n_ctx=cfg.TRAINER.GLP_OT.N_CTX, n_cls=len(names), eot=eot,
                           pixel_mean=tuple(cfg.INPUT.PIXEL_MEAN), pixel_std=tuple(cfg.INPUT.PIXEL_STD),
                           dim_per_3d_slice=cfg.DATASET.DIM_PER_3D_SLICE if is_3d else 0,

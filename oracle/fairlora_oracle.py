@@ -52,16 +52,18 @@ def group_mix(attr: Optional[Tensor], num_groups: int, lambda_group: float = 0.7
     return onehot * lambda_group + (1 - onehot) * (1 - lambda_group) / (num_groups - 1)
 
 
-def fairlora_linear(x: Tensor, W: Tensor, b: Optional[Tensor], A: Tensor, S: Tensor, Bm: Tensor,
-                    attr: Optional[Tensor], scaling: float) -> Tensor:
-    """y = x W^T + b + scaling * ((x A) * s_b) B,  s_b = pi_b S.
+def fairlora_linear(x: Tensor, W: Tensor, b: Optional[Tensor], A: Tensor, S: Optional[Tensor], Bm: Tensor,
+                    attr: Optional[Tensor], scaling: float, S_global: Optional[Tensor] = None) -> Tensor:
+    """y = x W^T + b + scaling * ((x A) * s_b) B,  s_b = pi_b S (+ S_global under GLOBAL_S, :467-468).
+
+    S [G, r]: FairLoRALinear.  S [r] (1-D): SVLoRALinear, one diagonal shared by all samples, the attribute is
+    ignored (:307-311).  S None: LoRALinear, s = 1 (:241-242).
 
     x is [L, Bn, in] (token-major like the reference, clip/model.py:438) or,
     for a 1x1 conv, [b, c_in, h, w] viewed as [hw, b, c_in]
     (trainers/GLP_OT_SVLoRA.py:469-471).  Each sample's s_b is repeated over
     its slices when x carries Bn = b*S rows (:474-475).
     """
-    G = S.shape[0]
     conv = W.dim() == 4
     if conv:
         y = F.conv2d(x, W, b)
@@ -69,7 +71,14 @@ def fairlora_linear(x: Tensor, W: Tensor, b: Optional[Tensor], A: Tensor, S: Ten
         x = x.reshape(bb, c_in, h * w).permute(2, 0, 1)
     else:
         y = F.linear(x, W, b)
-    s = group_mix(attr, G, dtype=x.dtype) @ S                       # [b, r]
+    if S is None:
+        s = torch.ones(1, A.shape[1], dtype=x.dtype)
+    elif S.dim() == 1:
+        s = S[None]
+    else:
+        s = group_mix(attr, S.shape[0], dtype=x.dtype) @ S          # [b, r]
+    if S_global is not None:
+        s = s + S_global[None]
     num_slices = x.shape[1] // s.shape[0]
     s = s[:, None, :].repeat(1, num_slices, 1).flatten(0, 1)        # [Bn, r]
     t = x @ A                                                      # [L, Bn, r]
@@ -77,6 +86,24 @@ def fairlora_linear(x: Tensor, W: Tensor, b: Optional[Tensor], A: Tensor, S: Ten
     if conv:
         dy = dy.reshape(h, w, bb, -1).permute(2, 3, 0, 1)
     return y + dy
+
+
+def fairlora_dense_weight(W: Tensor, A: Tensor, S: Tensor, Bm: Tensor, attr: Optional[Tensor], scaling: float,
+                          num_rows: int, S_global: Optional[Tensor] = None) -> Tensor:
+    """FairLoRALinear.weight(x, attr) (trainers/GLP_OT_SVLoRA.py:425-445): per-sample dense weights
+    W + scaling (A diag(s_b) B)^T, [num_rows, out, in] with num_rows = x.shape[1].  NOTE the reference's weight() mixes
+    with the PLAIN one-hot (s_b = S[attr_b]; uniform 1/G without attr), not with the 0.7 / 0.3 mix of forward()."""
+    G = S.shape[0]
+    if attr is not None:
+        pi = F.one_hot(attr.long(), num_classes=G).to(W.dtype)
+    else:
+        pi = torch.full((1, G), 1.0 / G, dtype=W.dtype)
+    s = pi @ S
+    if S_global is not None:
+        s = s + S_global[None]
+    s = s[:, None, :].repeat(1, num_rows // s.shape[0], 1).flatten(0, 1)          # [rows, r]
+    dw = (A[None] * s[:, None, :]) @ Bm                                            # [rows, in, out]
+    return W[None] + scaling * dw.permute(0, 2, 1)
 
 
 def fairlora_backward(x: Tensor, g: Tensor, W: Tensor, A: Tensor, S: Tensor, Bm: Tensor,
@@ -152,8 +179,8 @@ def vision_block(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int, attr: Opt
     def lora(name, inp):
         q = f"{p}mlp.{name}."
         return fairlora_linear(inp, sd[q + "original_linear.weight"], sd[q + "original_linear.bias"],
-                               sd[q + "lora_A.weight"], sd[q + "lora_S.weight"], sd[q + "lora_B.weight"],
-                               attr, scaling)
+                               sd[q + "lora_A.weight"], sd.get(q + "lora_S.weight"), sd[q + "lora_B.weight"],
+                               attr, scaling, sd.get(q + "lora_S_global.weight"))
 
     h = lora("c_fc", h)
     h = quick_gelu(h)
@@ -180,7 +207,8 @@ def bottleneck(sd: Dict[str, Tensor], p: str, x: Tensor, attr: Optional[Tensor],
     def lora_conv(name, inp):
         q = p + name + "."
         return fairlora_linear(inp, sd[q + "original_linear.weight"], None, sd[q + "lora_A.weight"],
-                               sd[q + "lora_S.weight"], sd[q + "lora_B.weight"], attr, scaling)
+                               sd[q + "lora_S.weight"], sd[q + "lora_B.weight"], attr, scaling,
+                               sd.get(q + "lora_S_global.weight"))
 
     out = F.relu(batch_norm(sd, p + "bn1.", lora_conv("conv1", x), training))
     out = F.relu(batch_norm(sd, p + "bn2.", F.conv2d(out, sd[p + "conv2.weight"], None, padding=1), training))

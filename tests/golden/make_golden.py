@@ -116,8 +116,8 @@ def build_reference_model(M, CLIP, mcfg: C.ModelCfg, sd):
     for n, p in model.named_parameters():
         # the freeze loop of GLP_OT_SVLoRA.build_model (:822-829): prompts, the 3D conv and BatchNorm2d stay trainable
         p.requires_grad_("prompt_learner" in n or "proj_per_3d_slice" in n or id(p) in bn_params)
-    M.apply_lora_to_model(model, True, rank=mcfg.lora.rank, alpha=mcfg.lora.alpha, lora_type="FairLoRA",
-                          global_s=False, num_attrs=mcfg.lora.num_groups)
+    M.apply_lora_to_model(model, True, rank=mcfg.lora.rank, alpha=mcfg.lora.alpha, lora_type=mcfg.lora.lora_type,
+                          global_s=mcfg.lora.global_s, num_attrs=mcfg.lora.num_groups)
     ref_sd = model.state_dict()
     man = synth.manifest(mcfg)
     assert list(ref_sd.keys()) == list(man.keys()), (
@@ -198,6 +198,24 @@ def golden_layers(M, out):
         out[f"layer.{name}.dS"] = layer.lora_S.weight.grad.numpy()
         out[f"layer.{name}.dB"] = layer.lora_B.weight.grad.numpy()
         print("layer", name, "y", tuple(y.shape), "|dA|", float(layer.lora_A.weight.grad.norm()))
+        if name == "fc_small":
+            # FairLoRALinear.weight(x, attr) (:425-445; plain one-hot mix) with and without the attribute
+            out[f"layer.{name}.weight_attr"] = layer.weight(xin.detach(), attr).detach().numpy()
+            out[f"layer.{name}.weight_noattr"] = layer.weight(xin.detach(), None).detach().numpy()
+            # GLOBAL_S: one more trainable vector added to every sample's singular values (:359-363, 418-422, 467-468)
+            lg = M.FairLoRALinear(lin, rank=r, alpha=2.0, global_s=True, num_attrs=G)
+            out[f"layer.{name}.gs.sg_init"] = lg.lora_S_global.weight.detach().numpy().copy()
+            lg.lora_A.weight.data, lg.lora_S.weight.data, lg.lora_B.weight.data = A.clone(), Sm.clone(), Bm.clone()
+            lg.lora_S_global.weight.data = lg.lora_S_global.weight.data * (1.0 + 0.1 * rng_tensor(name + ".Sg", (r,)))
+            out[f"layer.{name}.gs.Sg"] = lg.lora_S_global.weight.detach().numpy().copy()
+            x2 = x.clone().requires_grad_(True)
+            y2 = lg(x2, attr)
+            y2.backward(g)
+            out[f"layer.{name}.gs.y"] = y2.detach().numpy()
+            out[f"layer.{name}.gs.dx"] = x2.grad.numpy()
+            for nm in ("A", "S", "B", "S_global"):
+                out[f"layer.{name}.gs.d{nm}"] = getattr(lg, "lora_" + nm).weight.grad.numpy()
+            out[f"layer.{name}.gs.weight_attr"] = lg.weight(x2.detach(), attr).detach().numpy()
 
 
 def golden_lora_plain(M, out):
@@ -477,6 +495,13 @@ def main():
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_r4", 8, 3, out, meta)
     golden_model(M, CLIP, C.vit_tiny(rank=8, num_groups=2), "tiny_r8g2", 6, 2, out, meta)
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_refinit", 8, 3, out, meta, lora_init="reference")
+    # the other adapter types of apply_lora_to_model (:516-540) and GLOBAL_S, through the reference's trainer
+    import dataclasses as _dc
+    base = C.vit_tiny(rank=4)
+    for tag, lt, gs, G in (("tiny_globals", "FairLoRA", True, 3), ("tiny_svlora", "SVLoRA", False, 1),
+                           ("tiny_svlora_globals", "SVLoRA", True, 1), ("tiny_lora", "LoRA", False, 1)):
+        mc = _dc.replace(base, lora=_dc.replace(base.lora, lora_type=lt, global_s=gs, num_groups=G))
+        golden_model(M, CLIP, mc, tag, 8, 3, out, meta)
     # two local epochs of two batches with StepLR(step_size=2): the scheduler is stepped twice per epoch, so the
     # second epoch already runs at lr * gamma
     golden_model(M, CLIP, C.vit_tiny(rank=4), "tiny_sched", 8, 4, out, meta, num_batches=2, step_size=2)

@@ -132,7 +132,7 @@ def test_trainer_error_conventions_and_single_class_batch():
     with pytest.raises(FloatingPointError, match="Loss is infinite or NaN!"):
         tr.forward_backward(bad)
     cfg2 = make_cfg()
-    cfg2.TRAINER.GLP_OT_LORA.TYPE = "SVLoRA"
+    cfg2.TRAINER.GLP_OT_LORA.TYPE = "DoRA"                            # trainers/GLP_OT_SVLoRA.py:533-534
     with pytest.raises(NotImplementedError):
         GLP_OT_SVLoRA(cfg2, data=SyntheticFedData(mcfg, 1, 1, 1, 8))
     cfg3 = make_cfg()

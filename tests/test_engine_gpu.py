@@ -52,6 +52,10 @@ def to_dev(batch):
     ("tiny_r8g2", C.vit_tiny(rank=8, num_groups=2), 6, "random"),
     ("tiny_refinit", C.vit_tiny(rank=4), 8, "reference"),
     ("tiny3d_r4", C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random"),   # 3D OCT: 6 samples x 2 slice groups
+    ("tiny_globals", C.vit_tiny_lora("FairLoRA", True), 8, "random"),        # GLOBAL_S
+    ("tiny_svlora", C.vit_tiny_lora("SVLoRA", False), 8, "random"),          # lora_type SVLoRA / LoRA: one group,
+    ("tiny_svlora_globals", C.vit_tiny_lora("SVLoRA", True), 8, "random"),   # the attribute is ignored
+    ("tiny_lora", C.vit_tiny_lora("LoRA", False), 8, "random"),
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
@@ -95,9 +99,18 @@ def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
     assert rel(eng.forward(img, attr), out["logits"]) < 1e-6
 
 
+OTHER_ADAPTERS = [   # apply_lora_to_model's other types (trainers/GLP_OT_SVLoRA.py:516-540) and GLOBAL_S
+    ("tiny_globals", C.vit_tiny_lora("FairLoRA", True), 8, "random"),
+    ("tiny_svlora", C.vit_tiny_lora("SVLoRA", False), 8, "random"),
+    ("tiny_svlora_globals", C.vit_tiny_lora("SVLoRA", True), 8, "random"),
+    ("tiny_lora", C.vit_tiny_lora("LoRA", False), 8, "random"),
+]
+
+
 @pytest.mark.parametrize("tag,mcfg,bs,init", [("tiny_r4", C.vit_tiny(rank=4), 8, "random"),
                                               ("tiny_refinit", C.vit_tiny(rank=4), 8, "reference"),
-                                              ("tiny3d_r4", C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random")])
+                                              ("tiny3d_r4", C.vit_tiny_3d(rank=4, dim_per_3d_slice=4), 6, "random")]
+                         + OTHER_ADAPTERS)
 def test_tiny_trajectory_fp32(golden_dir, tag, mcfg, bs, init):
     """K SGD steps: loss trajectory and final trainable tensors vs the reference's forward_backward."""
     gold = np.load(os.path.join(golden_dir, gold_file(mcfg)))

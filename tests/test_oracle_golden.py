@@ -57,6 +57,51 @@ def test_fairlora_layer(unit, case):
     close(dB.numpy(), unit[f"layer.{name}.dB"], rtol=2e-5, atol=2e-6, what="dB")
 
 
+def test_fairlora_weight_and_global_s(unit):
+    """FairLoRALinear.weight(x, attr) (trainers/GLP_OT_SVLoRA.py:425-445; plain one-hot mix) and GLOBAL_S (one more
+    vector added to every sample's singular values, :359-363, 418-422, 467-468): the oracle's restatement AND the
+    product's module-level weight() (plain tensor algebra, runs on the CPU) against the imported reference layer."""
+    import torch.nn as nn
+    from fairfedmed_amd.model import FairLoRALinear
+    case = LAYER_CASES[0]
+    name, L, Bn, fin, fout, r, G, S, hw = case
+    x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+    sc = 2.0 / r
+    close(O.fairlora_dense_weight(W, A, Sm, Bm, attr, sc, Bn).numpy(), unit[f"layer.{name}.weight_attr"],
+          rtol=2e-5, atol=2e-6, what="weight(attr)")
+    close(O.fairlora_dense_weight(W, A, Sm, Bm, None, sc, Bn).numpy(), unit[f"layer.{name}.weight_noattr"],
+          rtol=2e-5, atol=2e-6, what="weight(None)")
+    # GLOBAL_S
+    np.testing.assert_allclose(unit[f"layer.{name}.gs.sg_init"], np.linspace(1, 0.1, r, dtype=np.float32), atol=1e-7)
+    Sg = torch.from_numpy(unit[f"layer.{name}.gs.Sg"])
+    leaves = [t.clone().requires_grad_(True) for t in (x, A, Sm, Bm, Sg)]
+    y = O.fairlora_linear(leaves[0], W, bias, leaves[1], leaves[2], leaves[3], attr, sc, S_global=leaves[4])
+    y.backward(g)
+    close(y.detach().numpy(), unit[f"layer.{name}.gs.y"], rtol=2e-5, atol=2e-6, what="gs.y")
+    for t, nm in zip(leaves, ("dx", "dA", "dS", "dB", "dS_global")):
+        close(t.grad.numpy(), unit[f"layer.{name}.gs.{nm}"], rtol=2e-5, atol=2e-6, what="gs." + nm)
+    close(O.fairlora_dense_weight(W, A, Sm, Bm, attr, sc, Bn, S_global=Sg).numpy(), unit[f"layer.{name}.gs.weight_attr"],
+          rtol=2e-5, atol=2e-6, what="gs.weight")
+    # the product's module: constructor surface, initial values and weight()
+    lin = nn.Linear(fin, fout)
+    lin.weight.data, lin.bias.data = W.clone(), bias.clone()
+    for gs in (False, True):
+        layer = FairLoRALinear(lin, rank=r, alpha=2.0, global_s=gs, num_attrs=G)
+        names = [n for n, _ in layer.named_parameters()]
+        assert names == ["original_linear.weight", "original_linear.bias", "lora_A.weight", "lora_S.weight"] + \
+            (["lora_S_global.weight"] if gs else []) + ["lora_B.weight"]
+        if gs:
+            assert tuple(layer.lora_S_global.weight.shape) == (r,)
+            np.testing.assert_allclose(layer.lora_S_global.weight.detach().numpy(), unit[f"layer.{name}.gs.sg_init"], atol=1e-7)
+            layer.lora_S_global.weight.data = Sg.clone()
+        layer.lora_A.weight.data, layer.lora_S.weight.data, layer.lora_B.weight.data = A.clone(), Sm.clone(), Bm.clone()
+        key = f"layer.{name}.gs.weight_attr" if gs else f"layer.{name}.weight_attr"
+        close(layer.weight(x, attr).detach().numpy(), unit[key], rtol=2e-5, atol=2e-6, what="module weight()")
+        if not gs:
+            close(layer.weight(x, None).detach().numpy(), unit[f"layer.{name}.weight_noattr"], rtol=2e-5, atol=2e-6)
+        assert layer.bias() is lin.bias
+
+
 def test_lora_plain_layer(unit):
     """LoRALinear (plain LoRA) == the FairLoRA product with one group and s = 1; weight() is W + scaling (A B)^T."""
     L, Bn, fin, fout, r = 50, 4, 128, 192, 8
@@ -130,6 +175,11 @@ TINY = {
     "rn_tiny_r4g2": (C.rn_tiny(rank=4, num_groups=2), 6, "random"),             # RN50 trunk (§8 a12)
     "rn_tiny2_r4g2": (C.rn_tiny2(rank=4, num_groups=2), 6, "random"),           # ... with identity-skip Bottlenecks
     "tiny_sched": (C.vit_tiny(rank=4), 8, "random"),                            # 2 epochs x 2 batches, StepLR(2)
+    # the other adapter types of apply_lora_to_model (trainers/GLP_OT_SVLoRA.py:516-540) and GLOBAL_S
+    "tiny_globals": (C.vit_tiny_lora("FairLoRA", True), 8, "random"),
+    "tiny_svlora": (C.vit_tiny_lora("SVLoRA", False), 8, "random"),
+    "tiny_svlora_globals": (C.vit_tiny_lora("SVLoRA", True), 8, "random"),
+    "tiny_lora": (C.vit_tiny_lora("LoRA", False), 8, "random"),
 }
 
 

@@ -83,6 +83,35 @@ def test_fairlora_linear_vs_reference_golden(golden_dir, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fairlora_linear_global_s_vs_reference_golden(golden_dir, dtype):
+    """FairLoRALinear(global_s=True): lora_S_global [r] is added to every sample's singular values
+    (trainers/GLP_OT_SVLoRA.py:359-363, 418-422, 467-468); forward, all five gradients and weight() vs the reference."""
+    from fairfedmed_amd.model import FairLoRALinear
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    case = LAYER_CASES[0]
+    name, L, Bn, fin, fout, r, G, S, hw = case
+    x, g, W, bias, A, Sm, Bm, attr = layer_inputs(*case)
+    lin = torch.nn.Linear(fin, fout)
+    lin.weight.data, lin.bias.data = W.clone(), bias.clone()
+    layer = FairLoRALinear(lin.cuda(), rank=r, alpha=2.0, global_s=True, num_attrs=G)
+    assert tuple(layer.lora_S_global.weight.shape) == (r,) and layer.lora_S_global.weight.is_cuda
+    assert rel(layer.lora_S_global.weight.detach(), unit[f"layer.{name}.gs.sg_init"]) < 1e-7
+    layer.lora_A.weight.data.copy_(A)
+    layer.lora_S.weight.data.copy_(Sm)
+    layer.lora_B.weight.data.copy_(Bm)
+    layer.lora_S_global.weight.data.copy_(torch.from_numpy(unit[f"layer.{name}.gs.Sg"]))
+    xin = x.cuda().to(dtype).requires_grad_(True)
+    y = layer(xin, attr.cuda())
+    y.backward(g.cuda().to(dtype))
+    t1, t2 = (3e-5, 1e-4) if dtype == torch.float32 else (1.5e-2, 4e-2)
+    assert rel(y.detach().float().cpu(), unit[f"layer.{name}.gs.y"]) < t1
+    assert rel(xin.grad.float().cpu(), unit[f"layer.{name}.gs.dx"]) < t1
+    for nm in ("A", "S", "B", "S_global"):
+        assert rel(getattr(layer, "lora_" + nm).weight.grad, unit[f"layer.{name}.gs.d{nm}"]) < t2, nm
+    assert rel(layer.weight(xin.detach().float(), attr.cuda()).detach(), unit[f"layer.{name}.gs.weight_attr"]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_lora_linear_vs_reference_golden(golden_dir, dtype):
     """LoRALinear (plain LoRA of the RN50 attention pool) on the HIP kernels vs the imported reference layer."""
     from fairfedmed_amd.model import LoRALinear
@@ -175,6 +204,43 @@ def test_trainer_reproduces_reference_trajectory(golden_dir):
         assert abs(s["acc"] - ref["acc"]) < 1e-3 and abs(s["auc"] - ref["auc"]) < 1e-9
     assert tr.fed_train_loader_x_dict[0].dataset.count_by_attribute("race") == \
         np.bincount(batch["attrs"][:, 0].numpy(), minlength=3).tolist()
+
+
+@pytest.mark.parametrize("tag,ltype,gs", [("tiny_globals", "FairLoRA", True), ("tiny_svlora", "SVLoRA", False),
+                                          ("tiny_svlora_globals", "SVLoRA", True), ("tiny_lora", "LoRA", False)])
+def test_trainer_other_adapter_types_and_global_s(golden_dir, tag, ltype, gs):
+    """TRAINER.GLP_OT_LORA.TYPE in {LoRA, SVLoRA} and GLOBAL_S through the registry-built trainer
+    (trainers/GLP_OT_SVLoRA.py:516-540, 838-840): state_dict keys / shapes / order of the reference, its
+    forward_backward trajectory and final weights."""
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData, _ListDataset, _Loader
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    gold = np.load(os.path.join(golden_dir, "tiny.npz"))
+    mcfg = C.vit_tiny_lora(ltype, gs)
+    cfg = make_cfg()
+    cfg.TRAINER.GLP_OT_LORA.TYPE, cfg.TRAINER.GLP_OT_LORA.GLOBAL_S = ltype, gs
+    data = SyntheticFedData(mcfg, 1, 1, 1, 8)
+    batch = synth.make_batch(mcfg, 8, seed=1234)
+    data.fed_train_loader_x_dict[0] = _Loader(_ListDataset([batch], ["race"], {"race": 3}))
+    cfg.DATA = data
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    tr = build_trainer(cfg)
+    sd = tr.model.state_dict()
+    assert list(sd.keys()) == list(synth.manifest(mcfg).keys())     # make_golden asserts manifest == reference's keys
+    assert sum(p.numel() for p in tr.model.parameters() if p.requires_grad) == meta[f"{tag}.trainable_elems"]
+    k0 = "image_encoder.transformer.resblocks.0.mlp.c_fc."
+    assert (k0 + "lora_S_global.weight" in sd) == gs and (k0 + "lora_S.weight" in sd) == (ltype != "LoRA")
+    if ltype == "SVLoRA":
+        assert tuple(sd[k0 + "lora_S.weight"].shape) == (4,)
+    tr.num_batches = 10 ** 9
+    for i, ref in enumerate(meta[f"{tag}.traj"]):
+        tr.batch_idx = i
+        s = tr.forward_backward(batch)
+        assert abs(s["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (i, s, ref)
+        assert abs(s["acc"] - ref["acc"]) < 1e-3 and abs(s["auc"] - ref["auc"]) < 1e-9
+    sd = tr.model.state_dict()
+    for k in synth.trainable_keys(mcfg):
+        assert rel(sd[k], gold[f"{tag}.post.{k}"]) < 1e-4, k
 
 
 def test_trainer_round_api_and_lr_schedule(tmp_path):
