@@ -46,11 +46,34 @@ def _register(root: nn.Module, key: str, tensor: Tensor, trainable: bool, buffer
 
 
 class CustomCLIP(nn.Module):
-    """CLIP image encoder (+FairLoRA) + prompt learner + text encoder + OT='None' head."""
+    """CLIP image encoder (+FairLoRA) + prompt learner + text encoder + logits head.
 
-    def __init__(self, cfg: ModelCfg, state_dict: Dict[str, Tensor], dtype=torch.bfloat16, max_images: int = 32,
-                 device: str = "cuda:0"):
+    Two constructor forms:
+      CustomCLIP(ModelCfg, state_dict, dtype=, max_images=, device=)   geometry + a state_dict with CustomCLIP's keys;
+      CustomCLIP(cfg, classnames, clip_model, ...)                     the reference's signature
+          (trainers/GLP_OT_SVLoRA.py:575-613): a yacs-style config tree, the class names and a CLIP model; see
+          fairfedmed_amd/clip_adapter.py.  dtype defaults to the config's TRAINER.GLP_OT.PREC then (fp32 / amp -> float32,
+          otherwise bf16), max_images to max(train, test batch size) when the config names them."""
+
+    def __init__(self, cfg, state_dict, clip_model=None, dtype=None, max_images: Optional[int] = None,
+                 device: str = "cuda:0", tokenize=None):
         super().__init__()
+        if not isinstance(cfg, ModelCfg):
+            from .clip_adapter import from_reference_args
+            if clip_model is None:
+                raise TypeError("CustomCLIP(cfg, classnames, clip_model): clip_model is missing")
+            ref_cfg, classnames = cfg, list(state_dict)
+            cfg, state_dict, self.tokenized_prompts = from_reference_args(ref_cfg, classnames, clip_model, tokenize)
+            if dtype is None:
+                dtype = torch.float32 if ref_cfg.TRAINER.GLP_OT.PREC in ("fp32", "amp") else torch.bfloat16
+            if max_images is None:
+                try:
+                    max_images = max(ref_cfg.DATALOADER.TRAIN_X.BATCH_SIZE, ref_cfg.TEST.BATCH_SIZE)
+                except AttributeError:
+                    max_images = 32
+            self.n_cls, self.N = len(classnames), cfg.n_prompts
+        dtype = torch.bfloat16 if dtype is None else dtype
+        max_images = 32 if max_images is None else max_images
         self.cfg = cfg
         from .engine_rn import create_engine
         self.engine = create_engine(cfg, state_dict, dtype=dtype, max_images=max_images, device=device)
@@ -323,6 +346,20 @@ def apply_lora_to_model(model: nn.Module, unfreeze_image_encoder: bool, rank: in
     of 'attnpool' a plain LoRALinear."""
     if lora_type not in ("LoRA", "SVLoRA", "FairLoRA"):
         raise NotImplementedError(lora_type)
+    if isinstance(model, CustomCLIP):
+        # the engine-backed CustomCLIP carries its adapters from construction (its image encoder is a sequence of HIP
+        # launches, not nn.Linear modules to wrap): the reference's call sequence CustomCLIP(...) ->
+        # apply_lora_to_model(model, ...) is honoured by checking that the request matches what was built
+        lo = model.cfg.lora
+        want = (int(rank), float(alpha), lora_type, bool(global_s) and lora_type != "LoRA",
+                int(num_attrs) if lora_type == "FairLoRA" else 1)
+        have = (lo.rank, float(lo.alpha), lo.lora_type, bool(lo.global_s), lo.num_groups)
+        if not unfreeze_image_encoder:
+            raise NotImplementedError("unfreeze_image_encoder=False: the engine always carries the adapters")
+        if want != have:
+            raise ValueError(f"apply_lora_to_model asks for (rank, alpha, type, global_s, groups) = {want}, the model "
+                             f"was built with {have}: set cfg.TRAINER.GLP_OT_LORA accordingly")
+        return
     for name, module in dict(model.named_modules()).items():
         if not (unfreeze_image_encoder and name.startswith("image_encoder.")):
             continue

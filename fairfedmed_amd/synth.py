@@ -320,3 +320,43 @@ def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0,
         "label": torch.from_numpy(label),
         "attrs": torch.from_numpy(attr[:, None].copy()),
     }
+
+
+# --------------------------------------------------------------------------
+# A CLIP-shaped model for the reference-signature constructor CustomCLIP(cfg, classnames, clip_model)
+# --------------------------------------------------------------------------
+def clip_state_dict(cfg: ModelCfg, seed: int = 1, vocab: int = 49408) -> "OrderedDict[str, torch.Tensor]":
+    """The tensors of make_state_dict(cfg, seed) under clip.model.CLIP's keys (visual.*, transformer.*,
+    positional_embedding, ln_final.*, text_projection, logit_scale; clip/model.py:453-531) plus a token embedding
+    [vocab, width] ~ N(0, 0.02) (:539)."""
+    sd = make_state_dict(cfg, seed=seed, lora_init="reference")
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in sd.items():
+        if ".lora_" in k or k.startswith("prompt_learner.") or k.startswith("proj_per_3d_slice."):
+            continue
+        if k.startswith("image_encoder."):
+            out["visual." + k[len("image_encoder."):].replace(".original_linear.", ".")] = v
+        elif k.startswith("text_encoder."):
+            out[k[len("text_encoder."):]] = v
+        else:
+            out[k] = v                                              # logit_scale
+    g = _rng("token_embedding.weight", seed)
+    out["token_embedding.weight"] = torch.from_numpy(
+        g.standard_normal((vocab, cfg.text.width), dtype=np.float32) * np.float32(0.02))
+    return out
+
+
+def make_clip_model(cfg: ModelCfg, seed: int = 1):
+    """An nn.Module with clip.model.CLIP's state_dict and the attributes CustomCLIP.__init__ / PromptLearner.__init__
+    read from it (trainers/GLP_OT_SVLoRA.py:69-128, 575-613): dtype, visual.input_resolution, ln_final.weight,
+    token_embedding(ids), logit_scale."""
+    import torch.nn as nn
+    from .model import _Node, _register
+    root = _Node()
+    for k, v in clip_state_dict(cfg, seed).items():
+        _register(root, k, v.clone(), trainable=False, buffer=k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    root.visual.input_resolution = cfg.vision.image_size
+    root.dtype = torch.float32
+    emb = root.token_embedding.weight
+    root.token_embedding.forward = lambda ids, _w=emb: _w[ids]
+    return root

@@ -369,6 +369,47 @@ def golden_model(M, CLIP, mcfg, tag, batch_size, steps, out, meta, lora_init="ra
     return model
 
 
+def golden_adapter(M, CLIP, out, meta):
+    """CustomCLIP(cfg, classnames, clip_model) (trainers/GLP_OT_SVLoRA.py:575-613) + apply_lora_to_model on a CLIP model
+    that holds synth.clip_state_dict's tensors: the tokenised prompts, the token_prefix / token_suffix buffers the
+    PromptLearner builds from CLIP's token embedding, the state_dict keys, and the logits once ctx / adapters are set
+    to known values.  Both class-name pairs on the path (FairFedMed, FedChexMimic)."""
+    import clip.clip as clipmod
+    dd = {"trainer": "GLP_OT", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0, "language_ctx": 0}
+    for tag, mcfg, names in (("adapter_vit", C.vit_tiny(rank=4), ["NOT Glaucoma", "Glaucoma"]),
+                             ("adapter_rn", C.rn_tiny(rank=4, num_groups=2), ["NOT Pleural Effusion", "Pleural Effusion"])):
+        v, t = mcfg.vision, mcfg.text
+        is_rn = isinstance(v, C.ResNetCfg)
+        clip_model = CLIP(v.out_dim, v.image_size, tuple(v.layers) if is_rn else v.layers, v.width,
+                          None if is_rn else v.patch, t.context_length, 49408, t.width, t.heads, t.layers, dd).float()
+        clip_model.load_state_dict(synth.clip_state_dict(mcfg, seed=1), strict=True)
+        cfg = ref_cfg(mcfg)
+        model = M.CustomCLIP(cfg, names, clip_model)
+        toks = model.tokenized_prompts
+        # the pinned token ids of fairfedmed_amd.clip_adapter equal the reference tokenizer's
+        from fairfedmed_amd import clip_adapter as A
+        assert torch.equal(toks, A.tokenize_prompts(names, mcfg.n_ctx).repeat(mcfg.n_prompts, 1)), names
+        out[f"{tag}.tokens"] = toks.numpy()
+        out[f"{tag}.token_prefix"] = model.prompt_learner.token_prefix.detach().numpy().copy()
+        out[f"{tag}.token_suffix"] = model.prompt_learner.token_suffix.detach().numpy().copy()
+        bn_params = {id(p) for mod in model.modules() if isinstance(mod, torch.nn.BatchNorm2d) for p in mod.parameters()}
+        for n, p in model.named_parameters():
+            p.requires_grad_("prompt_learner" in n or id(p) in bn_params)
+        M.apply_lora_to_model(model, True, rank=mcfg.lora.rank, alpha=mcfg.lora.alpha, lora_type="FairLoRA",
+                              global_s=False, num_attrs=mcfg.lora.num_groups)
+        meta[f"{tag}.keys"] = list(model.state_dict().keys())
+        meta[f"{tag}.ctx_std"] = float(model.prompt_learner.ctx.std())
+        # known values for everything the constructor draws at random (ctx, lora_B) and a non-trivial lora_A
+        known = synth.make_state_dict(mcfg, seed=3, lora_init="random")
+        model.load_state_dict({k: known[k] for k in synth.trainable_keys(mcfg) if not synth._is_bn_param(k)}, strict=False)
+        batch = synth.make_batch(mcfg, 6, seed=77)
+        model.eval()
+        with torch.no_grad():
+            logits = model(batch["img"], batch["attrs"].t()[0])
+        out[f"{tag}.logits"] = logits.numpy()
+        print(tag, "logits", logits[:2].tolist())
+
+
 def golden_fedavg(FU, out, meta):
     G, r = 3, 8
     keys = {"a.lora_S.weight": (G, r), "a.lora_A.weight": (16, r), "prompt_learner.ctx": (2, 4, 8),
@@ -489,6 +530,7 @@ def main():
     golden_fedavg(FU, out, meta)
     golden_auc(compute_auc, out, meta)
     golden_fairness(out, meta)
+    golden_adapter(M, CLIP, out, meta)
     np.savez_compressed(os.path.join(HERE, "unit.npz"), **out)
 
     out = {}

@@ -304,3 +304,53 @@ def test_bench_gpus_flag_builds_a_rank_launch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "only 1 GPU" in str(e.value.code)
+
+
+def _ref_style_cfg(mcfg, attribute="race", dataset="FairFedMed"):
+    from types import SimpleNamespace as NS
+    return NS(INPUT=NS(SIZE=(mcfg.vision.image_size,) * 2, PIXEL_MEAN=list(mcfg.pixel_mean), PIXEL_STD=list(mcfg.pixel_std)),
+              DATASET=NS(NAME=dataset, ATTRIBUTE_TYPE=attribute, MODALITY_TYPE="slo_fundus", DIM_PER_3D_SLICE=0),
+              DATALOADER=NS(TRAIN_X=NS(BATCH_SIZE=6)), TEST=NS(BATCH_SIZE=6),
+              TRAINER=NS(GLP_OT=NS(N=mcfg.n_prompts, N_CTX=mcfg.n_ctx, PREC="fp32", OT="None", CTX_INIT=False, CSC=False,
+                                   CLASS_TOKEN_POSITION="end"),
+                         GLP_OT_LORA=NS(RANK=mcfg.lora.rank, ALPHA=mcfg.lora.alpha, TYPE="FairLoRA", GLOBAL_S=False,
+                                        UNFREEZE_IMAGE_ENCODER=True, DISABLE_ATTR=False)))
+
+
+@pytest.mark.parametrize("tag,mk,names,attribute,dataset", [
+    ("adapter_vit", lambda: C.vit_tiny(rank=4), ["NOT Glaucoma", "Glaucoma"], "race", "FairFedMed"),
+    ("adapter_rn", lambda: C.rn_tiny(rank=4, num_groups=2), ["NOT Pleural Effusion", "Pleural Effusion"], "gender", "FedChexMimic")])
+def test_reference_constructor_arguments_to_engine_inputs(golden_dir, tag, mk, names, attribute, dataset):
+    """CustomCLIP(cfg, classnames, clip_model)'s host side (fairfedmed_amd/clip_adapter.py): geometry from CLIP's tensor
+    shapes, tokenised prompts, token_prefix / token_suffix from CLIP's token embedding, keys and initial adapter values -
+    against what the imported reference's CustomCLIP + apply_lora_to_model produced from the same CLIP tensors."""
+    from fairfedmed_amd import clip_adapter as A
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    mcfg = mk()
+    clip_model = synth.make_clip_model(mcfg, seed=1)
+    torch.manual_seed(0)
+    got, sd, toks = A.from_reference_args(_ref_style_cfg(mcfg, attribute, dataset), names, clip_model)
+    import dataclasses
+    eot = (9, 8) if names[1] == "Glaucoma" else (11, 10)               # EOT positions (SURVEY.md section 8(c) (iii))
+    assert got == dataclasses.replace(mcfg, eot=eot)
+    assert np.array_equal(toks.numpy(), unit[f"{tag}.tokens"])
+    assert list(sd.keys()) == meta[f"{tag}.keys"]
+    assert np.array_equal(sd["prompt_learner.token_prefix"].numpy(), unit[f"{tag}.token_prefix"])
+    assert np.array_equal(sd["prompt_learner.token_suffix"].numpy(), unit[f"{tag}.token_suffix"])
+    assert abs(float(sd["prompt_learner.ctx"].std()) - 0.02) < 0.004 and abs(meta[f"{tag}.ctx_std"] - 0.02) < 0.004
+    for k, v in sd.items():
+        if k.endswith("lora_A.weight"):
+            assert float(v.abs().max()) == 0.0
+        elif k.endswith("lora_S.weight"):
+            assert torch.equal(v, synth.lora_s_init(mcfg.lora.rank, mcfg.lora.num_groups))
+        elif k.endswith("lora_B.weight"):
+            assert 0.7 < float(v.std()) < 1.3
+    frozen = clip_model.state_dict()
+    assert torch.equal(sd["image_encoder.conv1.weight"], frozen["visual.conv1.weight"])
+    assert torch.equal(sd["text_encoder.text_projection"], frozen["text_projection"])
+    with pytest.raises(NotImplementedError, match="not pinned"):
+        A.tokenize_prompts(["Cardiomegaly"], 4)
+    # a caller-supplied tokenizer (the reference's clip.tokenize) serves any other class name
+    fake = lambda s: torch.tensor([[49406, 343, 343, 343, 343, 1000, 269, 49407] + [0] * 69])
+    assert A.tokenize_prompts(["Cardiomegaly"], 4, tokenize=fake).shape == (1, 77)

@@ -620,3 +620,33 @@ def test_save_model_load_model_round_trip(tmp_path):
     with pytest.raises(FileNotFoundError):
         fresh.load_model(str(tmp_path), epoch=9)
     fresh.load_model("")                                              # no directory: skipped, as in the reference
+
+
+@pytest.mark.parametrize("tag,mk,names,attribute,dataset", [
+    ("adapter_vit", lambda: C.vit_tiny(rank=4), ["NOT Glaucoma", "Glaucoma"], "race", "FairFedMed"),
+    ("adapter_rn", lambda: C.rn_tiny(rank=4, num_groups=2), ["NOT Pleural Effusion", "Pleural Effusion"], "gender", "FedChexMimic")])
+def test_custom_clip_reference_constructor(golden_dir, tag, mk, names, attribute, dataset):
+    """CustomCLIP(cfg, classnames, clip_model) followed by apply_lora_to_model(model, ...) - the reference's call
+    sequence (trainers/GLP_OT_SVLoRA.py:575-613, 820, 833-841) - on a CLIP-shaped model: state_dict contract, prompt
+    buffers and, with the constructor's random draws replaced by known tensors, the reference's eval logits."""
+    from fairfedmed_amd.model import CustomCLIP, apply_lora_to_model
+    from tests.test_host_cpu import _ref_style_cfg
+    unit = np.load(os.path.join(golden_dir, "unit.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    mcfg = mk()
+    cfg = _ref_style_cfg(mcfg, attribute, dataset)
+    model = CustomCLIP(cfg, names, synth.make_clip_model(mcfg, seed=1))
+    assert model.dtype == torch.float32 and model.engine.max_images == 6 and model.n_cls == 2
+    apply_lora_to_model(model, True, rank=4, alpha=2.0, lora_type="FairLoRA", global_s=False, num_attrs=mcfg.lora.num_groups)
+    with pytest.raises(ValueError, match="was built with"):
+        apply_lora_to_model(model, True, rank=8, alpha=2.0, lora_type="FairLoRA", num_attrs=mcfg.lora.num_groups)
+    sd = model.state_dict()
+    assert list(sd.keys()) == meta[f"{tag}.keys"]
+    assert np.array_equal(model.tokenized_prompts.numpy(), unit[f"{tag}.tokens"])
+    assert np.array_equal(sd["prompt_learner.token_suffix"].cpu().numpy(), unit[f"{tag}.token_suffix"])
+    assert {n for n, p in model.named_parameters() if p.requires_grad} == set(synth.trainable_keys(mcfg))
+    known = synth.make_state_dict(mcfg, seed=3, lora_init="random")
+    model.load_state_dict({k: known[k] for k in synth.trainable_keys(mcfg) if not synth._is_bn_param(k)}, strict=False)
+    batch = synth.make_batch(mcfg, 6, seed=77)
+    logits = model(batch["img"].cuda(), batch["attrs"].t()[0].cuda())
+    assert rel(logits, unit[f"{tag}.logits"]) < 3e-5, rel(logits, unit[f"{tag}.logits"])
