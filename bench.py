@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--rank", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trainer", action="store_true", help="skip the GLP_OT_SVLoRA.train() throughput entries")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[3] (3D OCT) / configs[4] (RN50) step times (child processes after the timed region)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="fold the side streams into the main stream for the timed steps (one kernel at a time): the "
@@ -113,8 +116,19 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(mcfg, budget_s=30.0):
-    """Oracle train step (fp32, bs 32) on the host cores: 1 warm-up + up to 3 timed steps."""
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(mcfg, budget_s=40.0):
+    """Oracle train step (fp32, bs 32) on the host cores: 1 warm-up + 5 timed steps, median (SURVEY.md section 8(d));
+    stops early past `budget_s` seconds so that the default run stays within minutes on a slow host."""
     from fairfedmed_amd import synth
     from oracle import fairlora_oracle as O
     cores = usable_cores()
@@ -126,7 +140,7 @@ def cpu_baseline(mcfg, budget_s=30.0):
     t_start = time.time()
     O.train_step(sd, opt, batch, mcfg, keys)                     # warm-up
     times = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.time()
         O.train_step(sd, opt, batch, mcfg, keys)
         times.append(time.time() - t0)
@@ -134,6 +148,7 @@ def cpu_baseline(mcfg, budget_s=30.0):
             break
     med = sorted(times)[len(times) // 2]
     return {"value": BATCH / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"{len(times)} timed steps (after 1 warm-up) of the oracle's fp32 train step, batch {BATCH}, "
                       f"same ViT-B/16 FairLoRA r=8 workload; median {med:.3f} s/step"}
 
@@ -159,6 +174,85 @@ def launch_ranks(n: int) -> int:
         sys.stdout.write(line)
         sys.stdout.flush()
     return proc.wait()
+
+
+TRAIN_STEPS = 32          # steps per round = 32 (1024 images per client-round)
+
+
+def build_bench_trainer(mcfg, sd, args, dev, rank):
+    """GLP_OT_SVLoRA through the registry with the reference's config field names: ViT-B/16, FairLoRA, race (3 groups),
+    one client with 32 resident batches of 32 (one client-round of the metric)."""
+    from types import SimpleNamespace as NS
+    from fairfedmed_amd import config as C
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData
+    import fairfedmed_amd.trainer  # noqa: F401  (registers GLP_OT_SVLoRA)
+    data = SyntheticFedData(mcfg, 1, train_batches=TRAIN_STEPS if not args.no_trainer else 1, test_batches=1,
+                            batch_size=BATCH, seed=1234 + 7919 * rank, device=dev)
+    cfg = NS(SEED=1, OUTPUT_DIR="", DEVICE=dev, VERBOSE=False,
+             INPUT=NS(SIZE=(224, 224), PIXEL_MEAN=list(C.CLIP_PIXEL_MEAN), PIXEL_STD=list(C.CLIP_PIXEL_STD)),
+             DATASET=NS(NAME="FairFedMed", ATTRIBUTES=["race"], ATTRIBUTE_TYPE="race", MODALITY_TYPE="slo_fundus",
+                        DIM_PER_3D_SLICE=0, USERS=1),
+             MODEL=NS(BACKBONE=NS(NAME="ViT-B/16"), STATE_DICT=sd),
+             TRAINER=NS(NAME="GLP_OT_SVLoRA", LAMBDA_FAIRNESS=0.0,
+                        GLP_OT=NS(N=2, N_CTX=4, PREC="bf16" if args.dtype == "bf16" else "fp32", OT="None"),
+                        GLP_OT_LORA=NS(RANK=args.rank, ALPHA=2.0, TYPE="FairLoRA", GLOBAL_S=False, DISABLE_ATTR=False,
+                                       UNFREEZE_IMAGE_ENCODER=True)),
+             OPTIM=NS(NAME="sgd", LR=1e-3, MOMENTUM=0.9, WEIGHT_DECAY=5e-4, LR_SCHEDULER="single_step", STEPSIZE=200,
+                      GAMMA=0.1, MAX_EPOCH=1),
+             DATALOADER=NS(TRAIN_X=NS(BATCH_SIZE=BATCH)), TEST=NS(BATCH_SIZE=BATCH, NO_TEST=True),
+             TRAIN=NS(METRICS_EVERY=1, CHECKPOINT_FREQ=0), DATA=data)
+    return build_trainer(cfg)
+
+
+def trainer_throughput(tr, use_dist):
+    """images/sec of GLP_OT_SVLoRA.train(idx=0): one local epoch of TRAIN_STEPS batches through run_epoch /
+    forward_backward / model_update / update_lr (TrainerX.run_epoch, Dassl/dassl/engine/trainer.py:685-741; the function
+    SURVEY.md section 8(d) defines the metric over).  Three settings of the per-step reporting:
+      default       the reference's summary dict every step, its values left on the GPU until read (one sync per epoch)
+      every_32      cfg.TRAIN.METRICS_EVERY = 32
+      sync_per_step the reference's literal behaviour: host sync + host-side (sklearn-equivalent) AUC every step"""
+    res = {}
+    modes = (("default", dict(METRICS_EVERY=1, SYNC_EVERY_STEP=False, HOST_METRICS=False)),
+             ("every_32", dict(METRICS_EVERY=TRAIN_STEPS, SYNC_EVERY_STEP=False, HOST_METRICS=False)),
+             ("sync_per_step", dict(METRICS_EVERY=1, SYNC_EVERY_STEP=True, HOST_METRICS=True)))
+    for name, knobs in modes:
+        for k, v in knobs.items():
+            setattr(tr.cfg.TRAIN, k, v)
+        tr.train(idx=0, global_epoch=0, is_fed=True)                  # warm-up epoch (records the launch plan)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t0 = time.perf_counter()
+        tr.train(idx=0, global_epoch=0, is_fed=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=tr.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        res[name] = {"images_per_sec_per_client": BATCH * TRAIN_STEPS / dt, "ms_per_step": dt / TRAIN_STEPS * 1e3}
+    for k, v in modes[0][1].items():
+        setattr(tr.cfg.TRAIN, k, v)
+    res["steps_per_round"] = TRAIN_STEPS
+    res["what"] = "wall time of GLP_OT_SVLoRA.train(idx) for one local epoch of 32 resident batches of 32, after one warm-up epoch"
+    return res
+
+
+def secondary_configs():
+    """Step times of BASELINE.json configs[3] (3D OCT, ViT-B/16 r=16, 4 volumes of 200x224x224 -> 100 ViT images) and
+    configs[4] (RN50 r=8 G=2, bs 32), each in a child process of its own (fresh HIP queues; this process is done
+    timing).  Never part of `value`."""
+    out = {}
+    for key, tool in (("configs[3]_oct3d_vitb16_r16_bf16", "bench_oct3d.py"), ("configs[4]_rn50_r8_g2_bf16", "bench_rn50.py")):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--json"], capture_output=True,
+                               text=True, timeout=600, cwd=ROOT)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[key] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:                                        # a failed side measurement never fails the bench
+            out[key] = {"error": repr(e)[:300]}
+    return out
 
 
 def main():
@@ -199,7 +293,11 @@ def main():
     mcfg = C.vit_b16(rank=args.rank)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
-    eng = FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=BATCH, device=dev)
+    # The engine is the one the registry-built trainer owns (build_trainer(cfg) -> GLP_OT_SVLoRA.build_model), so the
+    # headline steps and the trainer-level entries below run on the SAME engine, streams and hardware queues.
+    tr = build_bench_trainer(mcfg, sd, args, dev, rank)
+    eng = tr.engine
+    assert isinstance(eng, FairLoRAEngine)
     del sd
     batch = synth.make_batch(mcfg, BATCH, seed=1234 + rank)
     img, attr, label = batch["img"].to(dev), batch["attrs"].t()[0].contiguous().to(dev), batch["label"].to(dev)
@@ -308,6 +406,11 @@ def main():
                 "measured": "HIP events around every ffm_gemm_nt launch, second pass over the same K steps with the "
                             "side streams folded into the main stream (one kernel at a time); value comes from the "
                             "un-instrumented overlapped pass"}
+    trainer_res = None
+    if not args.no_trainer:
+        eng.set_overlap(True)
+        eng.use_replay = True
+        trainer_res = trainer_throughput(tr, use_dist)
     if use_dist:
         dist.barrier()
 
@@ -335,6 +438,10 @@ def main():
             res["config"]["fedavg_payload_bytes"] = eng.params.numel * 4
         if roof:
             res["roofline"] = roof
+        if trainer_res:
+            res["trainer"] = trainer_res
+        if world == 1 and not args.no_secondary:
+            res["secondary"] = secondary_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(mcfg)
         print(json.dumps(res), flush=True)

@@ -16,6 +16,7 @@ import os
 import time
 from collections import OrderedDict
 from types import SimpleNamespace as NS
+from collections.abc import Mapping
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -69,6 +70,38 @@ class _Loader:
 
 
 MODALITIES_3D = {"oct_bscans", "oct_bscans_3d", "mac_onh", "onh_mac"}
+
+
+class _DeviceSummary(Mapping):
+    """forward_backward's {"loss", "acc", "auc"} (trainers/GLP_OT_SVLoRA.py:959-970) with the values still on the GPU:
+    the loss, the batch's integer evaluator counts (ffm_eval_counts: accuracy and the exact rank AUC are ratios of
+    them) and the sticky finite flag.  Reading any entry copies ~100 bytes to the host once and yields the same floats
+    the reference computes with loss.item(), compute_accuracy and sklearn's roc_auc_score; until then the step costs
+    no host synchronisation (the reference pays three per step)."""
+
+    def __init__(self, trainer, loss: torch.Tensor, counts: torch.Tensor):
+        self._tr, self._loss, self._counts, self._vals = trainer, loss, counts, None
+
+    def _materialise(self) -> dict:
+        if self._vals is None:
+            self._tr.check_finite()
+            row = self._counts[-1].cpu().numpy()                         # the 'all' row
+            res = basic_from_counts(row[None])
+            self._vals = {"loss": float(self._loss), "acc": res[0], "auc": res[3] / 100.0}
+            self._loss = self._counts = None
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+    def __iter__(self):
+        return iter(("loss", "acc", "auc"))
+
+    def __len__(self):
+        return 3
+
+    def __repr__(self):
+        return repr(self._materialise())
 
 
 class SyntheticFedData:
@@ -176,6 +209,7 @@ class GLP_OT_SVLoRA:
             bs *= first["img"].shape[1] // mcfg.dim_per_3d_slice
         self.model = CustomCLIP(mcfg, sd, dtype=dtype, max_images=bs, device=str(self.device))
         self.engine = self.model.engine
+        self._finite_acc = torch.ones(1, device=self.device, dtype=torch.int32)
         o = cfg.OPTIM
         self.optim = NS(lr0=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY,
                         param_groups=[{"lr": o.LR}])
@@ -258,9 +292,12 @@ class GLP_OT_SVLoRA:
 
     # -------------------------------------------------------------- step --
     def forward_backward(self, batch, is_last_client=False):
-        """One SGD step; returns {"loss","acc","auc"} like the reference (:959-970).
-        Set cfg.TRAIN.METRICS_EVERY = N > 1 to pay the host sync for the metrics only every N steps
-        (the reference syncs three times per step; default 1 reproduces that)."""
+        """One SGD step; returns {"loss","acc","auc"} like the reference (:959-970).  For binary tasks the returned
+        mapping keeps its values on the GPU until they are read (_DeviceSummary): the reference's three host syncs per
+        step (loss.item(), accuracy, sklearn AUC) shrink to one small copy per summary that is actually looked at.
+        cfg.TRAIN.METRICS_EVERY = N > 1 skips the summary on the other steps altogether; TRAIN.SYNC_EVERY_STEP raises
+        a non-finite loss inside the call as the reference does; TRAIN.HOST_METRICS computes the metrics with the
+        host (numpy) versions."""
         image, label, _, attr = self.parse_batch_train(batch)
         # PREC 'amp': the reference's branch calls self.model(image) WITHOUT the attribute (uniform group mix) and has
         # no fairness term (trainers/GLP_OT_SVLoRA.py:890-898; SURVEY §5 quirk 5); autocast itself is not mirrored (fp32)
@@ -268,13 +305,23 @@ class GLP_OT_SVLoRA:
         out = self.engine.forward_backward(image, None if amp else attr, label)
         self.engine.sgd_step(self.get_current_lr(), self.optim.momentum, self.optim.weight_decay,
                              repeats=1 if amp else self.steps_per_update())     # amp: scaler.step(optim) once (:896)
-        every = getattr(getattr(self.cfg, "TRAIN", NS()), "METRICS_EVERY", 1)
+        train_cfg = getattr(self.cfg, "TRAIN", NS())
+        every = getattr(train_cfg, "METRICS_EVERY", 1)
         summary = {}
-        if every <= 1 or (self.batch_idx + 1) % every == 0 or (self.batch_idx + 1) == self.num_batches:
-            if int(out["finite"]) != 1:
-                raise FloatingPointError("Loss is infinite or NaN!")      # Dassl/dassl/engine/trainer.py:260-262
+        want = every <= 1 or (self.batch_idx + 1) % every == 0 or (self.batch_idx + 1) == self.num_batches
+        lam = getattr(self.cfg.TRAINER, "LAMBDA_FAIRNESS", 0.0)
+        # sticky finite flag on the device (the reference's detect_anomaly, Dassl/dassl/engine/trainer.py:260-262):
+        # raised when a summary is read, at the end of the epoch, or here with TRAIN.SYNC_EVERY_STEP
+        self._finite_acc.mul_(out["finite"])
+        if getattr(train_cfg, "SYNC_EVERY_STEP", False):
+            self.check_finite()
+        if want and out["prob"].shape[1] == 2 and (lam == 0.0 or attr is None or amp) \
+                and not getattr(train_cfg, "HOST_METRICS", False):
+            summary = _DeviceSummary(self, out["loss"].clone(),
+                                     ops.eval_counts(out["prob"], label.contiguous(), None, 0))
+        elif want:
+            self.check_finite()
             logits, prob = out["logits"], out["prob"]
-            lam = getattr(self.cfg.TRAINER, "LAMBDA_FAIRNESS", 0.0)
             loss = float(out["loss"])
             if lam != 0.0 and attr is not None and not amp:             # detached fairness term (:930-948)
                 correct = prob[torch.arange(len(label)), label]
@@ -295,7 +342,13 @@ class GLP_OT_SVLoRA:
             s = self.forward_backward(batch, is_last_client=is_last_client)
             if s:
                 last = s
+        self.check_finite()                                           # one host sync per local epoch
         return last
+
+    def check_finite(self) -> None:
+        if int(self._finite_acc) != 1:
+            self._finite_acc.fill_(1)
+            raise FloatingPointError("Loss is infinite or NaN!")      # Dassl/dassl/engine/trainer.py:260-262
 
     def train(self, idx=-1, global_epoch=0, is_fed=False, is_last_client=False, **_):
         self.time_start = time.time()

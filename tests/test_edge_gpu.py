@@ -129,8 +129,34 @@ def test_trainer_error_conventions_and_single_class_batch():
     bad = dict(batch)
     bad["img"] = batch["img"].clone()
     bad["img"][0, 0, 0, 0] = float("nan")
+    # the summary's values stay on the GPU until read (no host sync inside the step): the non-finite loss raises when
+    # the summary is read ...
+    lazy = tr.forward_backward(bad)
     with pytest.raises(FloatingPointError, match="Loss is infinite or NaN!"):
-        tr.forward_backward(bad)
+        lazy["loss"]
+    # ... or at the latest when the local epoch ends ...
+    tr2 = GLP_OT_SVLoRA(make_cfg(prec="fp32"), data=SyntheticFedData(mcfg, 1, 2, 1, 8))
+    tr2.fed_train_loader_x_dict[0].dataset.batches[1] = bad
+    with pytest.raises(FloatingPointError, match="Loss is infinite or NaN!"):
+        tr2.run_epoch(idx=0)
+    # ... and inside the call, as in the reference, with TRAIN.SYNC_EVERY_STEP
+    cfg_s = make_cfg(prec="fp32")
+    cfg_s.TRAIN.SYNC_EVERY_STEP = True
+    tr3 = GLP_OT_SVLoRA(cfg_s, data=SyntheticFedData(mcfg, 1, 2, 1, 8))
+    tr3.num_batches, tr3.batch_idx = 10, 0
+    with pytest.raises(FloatingPointError, match="Loss is infinite or NaN!"):
+        tr3.forward_backward(bad)
+    # the device summary equals the host (numpy / sklearn-equivalent) metrics
+    cfg_h = make_cfg(prec="fp32")
+    cfg_h.TRAIN.HOST_METRICS = True
+    trh = GLP_OT_SVLoRA(cfg_h, data=SyntheticFedData(mcfg, 1, 2, 1, 8))
+    trd = GLP_OT_SVLoRA(make_cfg(prec="fp32"), data=SyntheticFedData(mcfg, 1, 2, 1, 8))
+    good = synth.make_batch(mcfg, 8, seed=11, signal=0.3)
+    for t in (trh, trd):
+        t.num_batches, t.batch_idx = 10, 0
+    sh, sd_ = trh.forward_backward(good), trd.forward_backward(good)
+    assert isinstance(sh, dict) and not isinstance(sd_, dict) and set(sd_) == {"loss", "acc", "auc"}
+    assert abs(sh["loss"] - sd_["loss"]) < 1e-9 and abs(sh["acc"] - sd_["acc"]) < 1e-9 and abs(sh["auc"] - sd_["auc"]) < 1e-12
     cfg2 = make_cfg()
     cfg2.TRAINER.GLP_OT_LORA.TYPE = "DoRA"                            # trainers/GLP_OT_SVLoRA.py:533-534
     with pytest.raises(NotImplementedError):

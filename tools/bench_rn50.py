@@ -1,6 +1,9 @@
 """RN50 backbone (BASELINE.json configs[4]: RN50 FairLoRA r=8, gender = 2 groups): step time at full size.
-usage: python3 tools/bench_rn50.py [bs] [steps] [dtype] [--check]"""
-import copy, sys, time
+usage: python3 tools/bench_rn50.py [bs] [steps] [dtype] [--check] [--json]"""
+import copy, json, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+JSON = "--json" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--json"]
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from fairfedmed_amd import config as C, synth
@@ -16,8 +19,9 @@ args = (batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda()
 t0 = time.time()
 eng = create_engine(mcfg, sd, dtype=dtype, max_images=bs)
 torch.cuda.synchronize()
-print(f"engine built in {time.time() - t0:.1f}s, {torch.cuda.memory_allocated() / 2**30:.2f} GiB, "
-      f"{eng.params.numel} trainable elements")
+if not JSON:
+    print(f"engine built in {time.time() - t0:.1f}s, {torch.cuda.memory_allocated() / 2**30:.2f} GiB, "
+          f"{eng.params.numel} trainable elements")
 if "--check" in sys.argv:
     from oracle import fairlora_oracle as O
     keys = synth.trainable_keys(mcfg)
@@ -34,11 +38,16 @@ if "--check" in sys.argv:
     print("worst gradient cosine", worst)
     sys.exit(0)
 for _ in range(3):
-    eng.forward_backward(*args); eng.sgd_step(1e-3, 0.9, 5e-4)
+    eng.forward_backward(*args); eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(steps):
-    eng.forward_backward(*args); eng.sgd_step(1e-3, 0.9, 5e-4)
+    eng.forward_backward(*args); eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)
 torch.cuda.synchronize()
 ms = (time.time() - t0) / steps * 1e3
+if JSON:
+    print(json.dumps({"workload": f"RN50 (3,4,6,3) FairLoRA r=8 G=2, bs={bs}, 224x224x3, fwd+bwd+SGD", "ms_per_step": ms,
+                      "images_per_sec": bs / ms * 1e3, "steps": steps, "dtype": str(dtype).split(".")[-1],
+                      "trainable_elems": eng.params.numel, "final_loss": float(eng.loss)}))
+    sys.exit(0)
 print(f"RN50 r=8 G=2 bs={bs} {dtype}: {ms:.2f} ms/step, {bs / ms * 1e3:.0f} img/s, loss {float(eng.loss):.4f}")
