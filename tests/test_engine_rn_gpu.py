@@ -89,7 +89,9 @@ def test_rn_step_vs_oracle_and_golden(golden_dir, dtype, TAG):
             # different near-zero ReLU flips there (layer3.0: 1.9e-2 of conv3.lora_B's scale)
             assert rel(g, gold[f"{TAG}.grad.{k}"]) < 5e-2 and cos(g, gold[f"{TAG}.grad.{k}"]) > 1 - 1e-3, k
         else:
-            assert cos(g, ref) > 0.6, (k, cos(g, ref), e)          # direction only; kernels: test_rn_bf16_backward_*
+            # direction only (kernels: test_rn_bf16_backward_*); the 6-block geometry drifts further: its 8-element dS
+            # tensors reach 0.40
+            assert cos(g, ref) > (0.6 if TAG == "rn_tiny_r4g2" else 0.3), (k, cos(g, ref), e)
     print(TAG, dtype, "worst grad err", worst, "worst cosine", wcos)
     # BatchNorm running statistics moved exactly as nn.BatchNorm2d moves them (momentum 0.1, unbiased variance)
     bufs = eng.buffer_state()
@@ -152,12 +154,13 @@ def test_rn_replay_and_reload_keep_addresses():
     assert torch.equal(a, c) and torch.equal(g1, eng.params.grad)
 
 
-def test_rn_bf16_backward_on_fp32_activations():
+@pytest.mark.parametrize("TAG", list(GEOMS))
+def test_rn_bf16_backward_on_fp32_activations(TAG):
     """The bf16 backward kernels alone: both engines hold the SAME saved activations (the fp32 engine's, rounded),
     so what differs is the rounding inside the bf16 backward chain - 2 % rms on every dX, cosine > 0.998 on every
-    gradient (measured: 0.9995)."""
+    gradient (measured: 0.9995).  Both geometries: with and without identity-skip Bottlenecks."""
     from fairfedmed_amd.engine_rn import create_engine
-    mcfg = C.rn_tiny(rank=4, num_groups=2)
+    mcfg = GEOMS[TAG](rank=4, num_groups=2)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
     batch = synth.make_batch(mcfg, BS, seed=1234)
     e32 = create_engine(mcfg, sd, dtype=torch.float32, max_images=BS)
