@@ -36,15 +36,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+    """stamps=True: the diagnostic twin libffm_hip_stamps.so whose panel GEMM writes in-kernel phase time stamps
+    (tools/panel_stamps.py); every other object is shared with the product build."""
     hipcc = _hipcc()
     objs, jobs = [], []
+    lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        special = stamps and src.startswith("gemm_panel")
+        o = os.path.join(CSRC, src.replace(".hip", ".stamps.o" if special else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + (["-DFFM_PANEL_STAMPS"] if special else []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -57,10 +61,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -577,7 +577,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (ffm_skinny_ok(a, dtype)) {
         static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
-        if (!off) return ffm_skinny_launch(a, s);
+        if (!off) return ffm_skinny_launch(a, dtype, s);
     }
     if (a.b_packed) {
         const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);

@@ -19,6 +19,6 @@ int ffm_panel_ds_rows(int M, int N, int cfg);
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s);
 int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s);      // gemm_panel_rk.hip
 
-// gemm_skinny.hip: M <= 64 rows (text tower), bf16, plain epilogues
+// gemm_skinny.hip: M <= 64 rows (text tower), bf16 / f32, plain epilogues
 bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype);
-int ffm_skinny_launch(const ffm_gemm_args& a, hipStream_t s);
+int ffm_skinny_launch(const ffm_gemm_args& a, int dtype, hipStream_t s);

@@ -53,6 +53,21 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
 
+// Diagnostic build only (-DFFM_PANEL_STAMPS, tools/panel_stamps.py): wave 0 of every block writes {shader clock,
+// 100 MHz real-time clock} pairs at phase boundaries into the buffer passed in the (otherwise unused) `ts` field.
+#ifdef FFM_PANEL_STAMPS
+#define FFM_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (p.ts && tid == 0) {                                                                              \
+            unsigned long long* sb__ = (unsigned long long*)p.ts + ((size_t)blockIdx.x * 8 + (i)) * 2;       \
+            sb__[0] = __builtin_amdgcn_s_memtime();                                                          \
+            sb__[1] = __builtin_amdgcn_s_memrealtime();                                                      \
+        }                                                                                                    \
+    } while (0)
+#else
+#define FFM_STAMP(i) do { } while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void fence() {
     asm volatile("" ::: "memory");
@@ -83,6 +98,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FFM_STAMP(0);
     const int tiles_n = p.N / BNp;
     const int tiles_m = (p.M + BMp - 1) / BMp;
     const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -267,6 +283,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    FFM_STAMP(1);
 
     // VMEM issue order of step kt (nA = G::NI pieces, the same on every wave):
     //   first half : B1 = the NF fragments of half-step 2kt+3, then the nA pieces of A stage kt+3
@@ -339,6 +356,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire before the accumulators are read
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();                                                  // the ring is free from here on
+    FFM_STAMP(2);
 
     // ---------------- epilogue ----------------
     constexpr int PITCH = stage_pitch(NF);
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
 
+    FFM_STAMP(3);
     // per wave: 32-row groups of the accumulator slab through a private LDS stage, then 16-byte row segments out.
     // accumulator fragment -> stage: explicit ds_write_b32 (data straight from the AGPR / VGPR the MFMAs left it in)
     const uint32_t cw_lane = (uint32_t)(uintptr_t)(Cw + fgrp * 4 * PITCH + frow);
@@ -497,6 +516,11 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         fence();
     });
+    FFM_STAMP(4);
+#ifdef FFM_PANEL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // 5: this wave's output stores have been acknowledged
+    FFM_STAMP(5);
+#endif
 }
 
 template <int MF, int NF, bool RK, int FL>

@@ -255,7 +255,11 @@ class FairLoRAEngine:
         # prompts): bit-identical rows, 7.7x fewer of them, and far less interference with the vision chain.
         self.txt_len = min(t.context_length, max(cfg.eot) + 1)
         assert self.txt_len >= 1 + cfg.n_ctx
-        self.txt = _Stack(t.width, t.heads, t.layers, self.txt_len, self.n_text, True, 0, dtype, self.device)
+        # ... and ALWAYS in float32, also in the bf16 throughput mode: the two classes' prompts differ in a few tokens, so
+        # the logit difference l1 - l0 = e^ls <f, t1 - t0> rides on the small difference of two nearly equal text features
+        # and a 2^-9 rounding of the text activations lands on it many times amplified (measured on the tiny model: 3.5 %
+        # of l1 - l0, tools/buf_bias.py).  40 rows of latency-bound work on the side stream gain nothing from bf16.
+        self.txt = _Stack(t.width, t.heads, t.layers, self.txt_len, self.n_text, True, 0, torch.float32, self.device)
         dev, f32 = self.device, torch.float32
         self._init_vision(max_images)                 # tower-specific buffers (ViT here, RN50 in engine_rn.py)
         self.load_frozen(state_dict)
@@ -354,32 +358,34 @@ class FairLoRAEngine:
         return self.cfg.vision.layers
 
     # ------------------------------------------------------------ weights --
-    def _w(self, x: Tensor) -> Tensor:
-        return ops.cast_from_f32(x.to(self.device, torch.float32).contiguous(), self.dtype)
+    def _w(self, x: Tensor, dtype=None) -> Tensor:
+        return ops.cast_from_f32(x.to(self.device, torch.float32).contiguous(), dtype or self.dtype)
 
-    def _wt(self, x: Tensor) -> Tensor:
-        return ops.transpose_cast(x.to(self.device, torch.float32).contiguous(), self.dtype)
+    def _wt(self, x: Tensor, dtype=None) -> Tensor:
+        return ops.transpose_cast(x.to(self.device, torch.float32).contiguous(), dtype or self.dtype)
 
     def _f(self, x: Tensor) -> Tensor:
         return x.to(self.device, torch.float32).contiguous().clone()
 
     def _load_stack(self, stack: _Stack, sd, prefix: str, lora: bool) -> None:
         old = stack.blocks if stack.blocks else None
+        W = lambda x: self._w(x, stack.dtype)
+        WT = lambda x: self._wt(x, stack.dtype)
         stack.blocks = []
         for i in range(stack.layers):
             p = f"{prefix}transformer.resblocks.{i}."
             fc = "mlp.c_fc.original_linear." if lora else "mlp.c_fc."
             pj = "mlp.c_proj.original_linear." if lora else "mlp.c_proj."
             blk = _Block(
-                w_in=self._w(sd[p + "attn.in_proj_weight"]), w_in_t=self._wt(sd[p + "attn.in_proj_weight"]),
+                w_in=W(sd[p + "attn.in_proj_weight"]), w_in_t=WT(sd[p + "attn.in_proj_weight"]),
                 b_in=self._f(sd[p + "attn.in_proj_bias"]),
-                w_out=self._w(sd[p + "attn.out_proj.weight"]), w_out_t=self._wt(sd[p + "attn.out_proj.weight"]),
+                w_out=W(sd[p + "attn.out_proj.weight"]), w_out_t=WT(sd[p + "attn.out_proj.weight"]),
                 b_out=self._f(sd[p + "attn.out_proj.bias"]),
                 ln1_w=self._f(sd[p + "ln_1.weight"]), ln1_b=self._f(sd[p + "ln_1.bias"]),
                 ln2_w=self._f(sd[p + "ln_2.weight"]), ln2_b=self._f(sd[p + "ln_2.bias"]),
-                w_fc=self._w(sd[p + fc + "weight"]), w_fc_t=self._wt(sd[p + fc + "weight"]),
+                w_fc=W(sd[p + fc + "weight"]), w_fc_t=WT(sd[p + fc + "weight"]),
                 b_fc=self._f(sd[p + fc + "bias"]),
-                w_proj=self._w(sd[p + pj + "weight"]), w_proj_t=self._wt(sd[p + pj + "weight"]),
+                w_proj=W(sd[p + pj + "weight"]), w_proj_t=WT(sd[p + pj + "weight"]),
                 b_proj=self._f(sd[p + pj + "bias"]),
             )
             if lora:
@@ -390,7 +396,7 @@ class FairLoRAEngine:
                     if isinstance(val, torch.Tensor):
                         getattr(old[i], name).copy_(val)
                 blk = old[i]
-            if lora and self.dtype == torch.bfloat16:
+            if lora and stack.dtype == torch.bfloat16:
                 # frozen weights in MFMA-fragment order for the panel GEMM (csrc/gemm_panel_impl.h)
                 if blk.packed is None:
                     blk.packed = {}
@@ -649,7 +655,7 @@ class FairLoRAEngine:
         self._tbar.backward(self.dtn if self.ot else self.dtbar)
         g = self.txt.g[:rows]
         g.zero_()
-        g[self.eot_rows] = self._xe.grad.to(self.dtype)
+        g[self.eot_rows] = self._xe.grad.to(self.txt.dtype)
         self._tbar = self._xe = None
 
     def _text_glue_back_out(self) -> None:
