@@ -15,9 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FFM_LIB_PATH: a diagnostic build of the same library (tools/panel_stamps.py); there is still no fallback
 LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32_X3 = 0, 1, 2
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

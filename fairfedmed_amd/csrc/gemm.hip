@@ -557,10 +557,11 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if (!args || !args->a || !args->b || !args->c) return FFM_EINVAL;
     const ffm_gemm_args& a = *args;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
-    if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
+    const size_t esb = es;
+    if (dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3) return FFM_EINVAL;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return FFM_EINVAL;
-    if (((size_t)a.K * es) % KT_BYTES != 0 || a.N % 8 != 0) return FFM_EINVAL;
-    if (((size_t)a.lda * es) % 16 || ((size_t)a.ldb * es) % 16 || ((size_t)a.ldc * es) % 16) return FFM_EINVAL;
+    if (((size_t)a.K * esb) % KT_BYTES != 0 || a.N % 8 != 0) return FFM_EINVAL;
+    if (((size_t)a.lda * es) % 16 || ((size_t)a.ldb * esb) % 16 || ((size_t)a.ldc * es) % 16) return FFM_EINVAL;
     if (((uintptr_t)a.a | (uintptr_t)a.b | (uintptr_t)a.c) & 15) return FFM_EINVAL;
     if (a.lda < a.K || a.ldb < a.K || a.ldc < a.N) return FFM_EINVAL;
     const bool rk = (a.flags & FFM_EPI_RANKOP) != 0;
@@ -577,8 +578,9 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (ffm_skinny_ok(a, dtype)) {
         static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
-        if (!off) return ffm_skinny_launch(a, dtype, s);
+        if (!off || dtype == FFM_F32_X3) return ffm_skinny_launch(a, dtype, s);
     }
+    if (dtype == FFM_F32_X3) return FFM_EUNSUP;                           // split-operand products: skinny shapes only
     if (a.b_packed) {
         const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);

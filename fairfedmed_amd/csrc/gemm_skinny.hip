@@ -1,56 +1,115 @@
 // Skinny GEMM: C = epilogue(A * B^T) for M <= 64 rows (the text tower: 4 prompts x 10 tokens = 40 rows against
 // 512..2048-wide frozen weights).  The 128x128 kernel gives such a product N/128 = 4..16 blocks, each streaming its
 // 128-column slice of the weight serially: 10-22 us of pure latency per launch, 96 launches per step on the side
-// stream.  Here a block owns 16 output columns and ALL rows; its four waves split K, every wave issues the loads of 8
-// K32 steps before the first MFMA, and the partial accumulators meet in LDS: N/16 = 32..128 blocks, 2-5 us.
-// bf16 and f32 (the text tower always runs in f32, engine.py: class discrimination rides on the small DIFFERENCE of two
-// similar prompt features, which bf16 activations blur); epilogues: none, bias, bias+residual, bias+GELU, dGELU.
+// stream.  Here a block owns 16 output columns and ALL rows; its 4 or 8 waves split K, every wave issues the loads of
+// up to 8 K32 steps before the first MFMA, and the partial accumulators meet in LDS: N/16 = 32..128 blocks.
+// Operand types: see SkOps; epilogues: none, bias, bias+residual, bias+GELU, dGELU.
 #include "gemm_panel.h"
 
 namespace {
 
-constexpr int SK_COLS = 16, SK_WAVES = 4, SK_MF = 4, SK_UN = 8;
+constexpr int SK_COLS = 16, SK_MF = 4;
 
-template <typename T, int FL>
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
-    typedef typename Mma16<T>::frag_t frag_t;
-    constexpr int KS = Mma16<T>::kK, KC = Elem<T>::kPerChunk;     // k per fragment step, elements per 16-byte chunk
-    __shared__ f32x4 red[SK_WAVES - 1][SK_MF][64];
+// Operand traits.  TA: activation / output element, TB: weight element in memory, X3: see below.
+//   <bf16, bf16>        one bf16 MFMA per K32 step
+//   <float, float>      exact f32 MFMAs (the fp32 parity mode), K16 per step
+//   <float, float, X3>  f32 operands in memory, products on the bf16 matrix cores: both fragments are split into bf16
+//                       hi + lo pairs and hi*hi + lo*hi + hi*lo is accumulated in f32 (3 MFMAs at the bf16 rate, 16
+//                       significant bits per operand; the f32 MFMA runs at 1/16 of that rate).  This is the text tower
+//                       beside a bf16 vision tower (FFM_F32_X3; engine.py says why it is not simply bf16).
+template <typename TA, typename TB, bool X3> struct SkOps;
+template <> struct SkOps<bf16_t, bf16_t, false> {
+    static constexpr int KS = 32, UN = 8;
+    struct afrag { bf16x8 v; };
+    typedef bf16x8 braw;
+    typedef bf16x8 bprep;
+    static __device__ __forceinline__ void loadA(afrag& f, const bf16_t* p) { f.v = *reinterpret_cast<const bf16x8*>(p); }
+    static __device__ __forceinline__ void loadB(braw& f, const bf16_t* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+    static __device__ __forceinline__ bprep prep(const braw& b) { return b; }
+    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) { Mma16<bf16_t>::mma(acc, a.v, b); }
+};
+template <> struct SkOps<float, float, false> {
+    static constexpr int KS = 16, UN = 8;
+    struct afrag { f32x4 v; };
+    typedef f32x4 braw;
+    typedef f32x4 bprep;
+    static __device__ __forceinline__ void loadA(afrag& f, const float* p) { f.v = *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void loadB(braw& f, const float* p) { f = *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ bprep prep(const braw& b) { return b; }
+    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) { Mma16<float>::mma(acc, a.v, b); }
+};
+template <> struct SkOps<float, float, true> {
+    static constexpr int KS = 32, UN = 4;
+    struct afrag { f32x4 lo, hi; };                         // k 0..3 and 4..7 of the lane's group
+    typedef afrag braw;
+    struct bprep { bf16x8 h, l; };
+    static __device__ __forceinline__ void loadA(afrag& f, const float* p) {
+        f.lo = *reinterpret_cast<const f32x4*>(p);
+        f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    static __device__ __forceinline__ void loadB(braw& f, const float* p) { loadA(f, p); }
+    static __device__ __forceinline__ bprep prep(const braw& a) {
+        bprep r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.h[i] = (bf16_t)a.lo[i];
+            r.h[4 + i] = (bf16_t)a.hi[i];
+            r.l[i] = (bf16_t)(a.lo[i] - (float)r.h[i]);
+            r.l[4 + i] = (bf16_t)(a.hi[i] - (float)r.h[4 + i]);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) {
+        const bprep x = prep(a);
+        Mma16<bf16_t>::mma(acc, x.l, b.h);                  // small terms first
+        Mma16<bf16_t>::mma(acc, x.h, b.l);
+        Mma16<bf16_t>::mma(acc, x.h, b.h);
+    }
+};
+
+template <typename TA, typename TB, bool X3, int NW, int FL>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
+    typedef SkOps<TA, TB, X3> O;
+    constexpr int KS = O::KS, UN = O::UN;                          // k per fragment step, steps of loads in flight
+    constexpr int KG = KS / 4;                                     // k per lane group of a step
+    __shared__ f32x4 red[NW - 1][SK_MF][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * SK_COLS;
     const int nmf = (p.M + 15) >> 4;                               // 1..4 row fragments (uniform)
-    const int kw = p.K / SK_WAVES, k0 = wave * kw;                 // this wave's K range, a multiple of KS
-    const T* A = reinterpret_cast<const T*>(p.a);
-    const T* bp = reinterpret_cast<const T*>(p.b) + (size_t)(n0 + col) * p.ldb + k0 + kg * KC;
-    const T* ap[SK_MF];
+    const int kw = p.K / NW, k0 = wave * kw;                       // this wave's K range, a multiple of KS
+    const TA* A = reinterpret_cast<const TA*>(p.a);
+    const TB* bp = reinterpret_cast<const TB*>(p.b) + (size_t)(n0 + col) * p.ldb + k0 + kg * KG;
+    const TA* ap[SK_MF];
 #pragma unroll
     for (int mf = 0; mf < SK_MF; ++mf) {
         int row = mf * 16 + col;
         row = row < p.M ? row : p.M - 1;                           // clamped rows are never stored
-        ap[mf] = A + (size_t)row * p.lda + k0 + kg * KC;
+        ap[mf] = A + (size_t)row * p.lda + k0 + kg * KG;
     }
     f32x4 acc[SK_MF];
 #pragma unroll
     for (int mf = 0; mf < SK_MF; ++mf) acc[mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < kw; ks += KS * SK_UN) {
-        frag_t bf[SK_UN], af[SK_UN][SK_MF];
+    for (int ks = 0; ks < kw; ks += KS * UN) {
+        typename O::braw bf[UN];
+        typename O::afrag af[UN][SK_MF];
 #pragma unroll
-        for (int u = 0; u < SK_UN; ++u) {
+        for (int u = 0; u < UN; ++u) {
             if (ks + KS * u < kw) {
-                bf[u] = *reinterpret_cast<const frag_t*>(bp + ks + KS * u);
+                O::loadB(bf[u], bp + ks + KS * u);
 #pragma unroll
                 for (int mf = 0; mf < SK_MF; ++mf)
-                    if (mf < nmf) af[u][mf] = *reinterpret_cast<const frag_t*>(ap[mf] + ks + KS * u);
+                    if (mf < nmf) O::loadA(af[u][mf], ap[mf] + ks + KS * u);
             }
         }
 #pragma unroll
-        for (int u = 0; u < SK_UN; ++u) {
+        for (int u = 0; u < UN; ++u) {
             if (ks + KS * u < kw) {
+                const typename O::bprep b = O::prep(bf[u]);
 #pragma unroll
                 for (int mf = 0; mf < SK_MF; ++mf)
-                    if (mf < nmf) Mma16<T>::mma(acc[mf], af[u][mf], bf[u]);
+                    if (mf < nmf) O::mma(acc[mf], af[u][mf], b);
             }
         }
     }
@@ -63,13 +122,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(ffm_gemm_arg
     if (wave != 0) return;
     const int n = n0 + col;
     const float bias = (FL & FFM_EPI_BIAS) ? p.bias[n] : 0.f;
-    T* C = reinterpret_cast<T*>(p.c);
+    TA* C = reinterpret_cast<TA*>(p.c);
 #pragma unroll
     for (int mf = 0; mf < SK_MF; ++mf) {
         if (mf >= nmf) break;
         f32x4 v = acc[mf];
 #pragma unroll
-        for (int w = 0; w < SK_WAVES - 1; ++w) {
+        for (int w = 0; w < NW - 1; ++w) {
             const f32x4 o = red[w][mf][lane];
             v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
         }
@@ -79,37 +138,44 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(ffm_gemm_arg
             if (row >= p.M) continue;
             const size_t o = (size_t)row * p.ldc + n;
             float x = v[e] + bias;
-            if (FL & FFM_EPI_RESIDUAL) x += (float)reinterpret_cast<const T*>(p.res)[o];
-            if (FL & FFM_EPI_DGELU) x *= Act<T>::gelu_grad((float)reinterpret_cast<const T*>(p.aux)[o]);
-            C[o] = (T)x;
-            if (FL & FFM_EPI_GELU) reinterpret_cast<T*>(p.c2)[o] = (T)Act<T>::gelu(x);
+            if (FL & FFM_EPI_RESIDUAL) x += (float)reinterpret_cast<const TA*>(p.res)[o];
+            if (FL & FFM_EPI_DGELU) x *= Act<TA>::gelu_grad((float)reinterpret_cast<const TA*>(p.aux)[o]);
+            C[o] = (TA)x;
+            if (FL & FFM_EPI_GELU) reinterpret_cast<TA*>(p.c2)[o] = (TA)Act<TA>::gelu(x);
         }
     }
 }
 
-template <typename T, int FL>
+template <typename TA, typename TB, bool X3, int NW, int FL>
 int launch(const ffm_gemm_args& a, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, FL>), dim3(a.N / SK_COLS), dim3(SK_WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB, X3, NW, FL>), dim3(a.N / SK_COLS), dim3(NW * 64), 0, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
 
-template <typename T>
+template <typename TA, typename TB, bool X3, int NW>
 int launch_flags(const ffm_gemm_args& a, hipStream_t s) {
     switch (a.flags) {
-        case 0: return launch<T, 0>(a, s);
-        case FFM_EPI_BIAS: return launch<T, FFM_EPI_BIAS>(a, s);
-        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL: return launch<T, FFM_EPI_BIAS | FFM_EPI_RESIDUAL>(a, s);
-        case FFM_EPI_BIAS | FFM_EPI_GELU: return launch<T, FFM_EPI_BIAS | FFM_EPI_GELU>(a, s);
-        case FFM_EPI_DGELU: return launch<T, FFM_EPI_DGELU>(a, s);
+        case 0: return launch<TA, TB, X3, NW, 0>(a, s);
+        case FFM_EPI_BIAS: return launch<TA, TB, X3, NW, FFM_EPI_BIAS>(a, s);
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL: return launch<TA, TB, X3, NW, FFM_EPI_BIAS | FFM_EPI_RESIDUAL>(a, s);
+        case FFM_EPI_BIAS | FFM_EPI_GELU: return launch<TA, TB, X3, NW, FFM_EPI_BIAS | FFM_EPI_GELU>(a, s);
+        case FFM_EPI_DGELU: return launch<TA, TB, X3, NW, FFM_EPI_DGELU>(a, s);
     }
     return FFM_EINVAL;
+}
+
+// 8 waves split K when it divides (one round of loads per wave for K <= 2048), 4 otherwise
+template <typename TA, typename TB, bool X3>
+int launch_waves(const ffm_gemm_args& a, hipStream_t s) {
+    return a.K % 256 == 0 ? launch_flags<TA, TB, X3, 8>(a, s) : launch_flags<TA, TB, X3, 4>(a, s);
 }
 
 }  // namespace
 
 bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
-    if ((dtype != FFM_BF16 && dtype != FFM_F32) || a.M > 16 * SK_MF || a.N % SK_COLS || a.K % (32 * SK_WAVES)) return false;
+    if ((dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3) || a.M > 16 * SK_MF || a.N % SK_COLS || a.K % 128)
+        return false;
     switch (a.flags) {
         case 0:
         case FFM_EPI_BIAS:
@@ -121,5 +187,7 @@ bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
 }
 
 int ffm_skinny_launch(const ffm_gemm_args& a, int dtype, hipStream_t s) {
-    return dtype == FFM_F32 ? launch_flags<float>(a, s) : launch_flags<bf16_t>(a, s);
+    if (dtype == FFM_F32) return launch_waves<float, float, false>(a, s);
+    if (dtype == FFM_F32_X3) return launch_waves<float, float, true>(a, s);
+    return launch_waves<bf16_t, bf16_t, false>(a, s);
 }

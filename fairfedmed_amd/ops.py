@@ -116,10 +116,12 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
-            gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None) -> Tensor:
-    """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional."""
+            gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
+            x3: bool = False) -> Tensor:
+    """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
+    x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
-    assert a.dtype == b.dtype == out.dtype
+    assert a.dtype == b.dtype == out.dtype and (not x3 or a.dtype == torch.float32)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and tuple(out.shape) == (M, N)
@@ -158,7 +160,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed))
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
-    _call("ffm_gemm_nt", C.byref(args), L.dtype_code(a.dtype), L.stream_ptr())
+    _call("ffm_gemm_nt", C.byref(args), L.F32_X3 if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
 
 

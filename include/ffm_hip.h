@@ -31,6 +31,10 @@ extern "C" {
 
 #define FFM_F32 0
 #define FFM_BF16 1
+/* ffm_gemm_nt only: every operand f32 in memory as under FFM_F32, the products on the bf16 matrix cores with both
+ * operands split into bf16 hi + lo pairs (hi*hi + lo*hi + hi*lo, f32 accumulation: ~2^-16 instead of the f32 MFMA's
+ * 2^-24, at 5x its rate); products of at most 64 rows (the text tower beside a bf16 vision tower), FFM_EUNSUP otherwise */
+#define FFM_F32_X3 2
 
 #define FFM_OK 0
 #define FFM_EINVAL (-1)
@@ -40,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 5   /* 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */

@@ -551,3 +551,56 @@ def test_skinny_gemm_text_tower_shapes(M, N, K, mode):
         s = torch.sigmoid(1.702 * x)
         ref = ref * (s * (1 + 1.702 * x * (1 - s)))
     assert rel(out.float(), ref) < 1e-2                              # bf16 rounding of the output only
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 1536, 512), (40, 512, 2048), (40, 2048, 512), (1, 512, 128), (64, 128, 128),
+                                   (33, 48, 640), (8, 512, 512)])
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "exact"])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_res", "bias_gelu", "dgelu"])
+def test_skinny_gemm_f32(M, N, K, x3, mode):
+    """The text tower's products in float32 (engine.py: always, also beside a bf16 vision tower): FFM_F32_X3 (operands
+    split into bf16 hi + lo pairs, three MFMAs at the bf16 rate) and the exact f32 MFMA, 4 or 8 waves splitting K.
+    Reference: float64 on the same operands."""
+    from fairfedmed_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 1000 + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    act = torch.full((M, N), float("nan"), device="cuda")
+    ref = a.double() @ w.double().t()
+    rel = lambda got, want: float((got.double() - want.double()).abs().max() / want.double().abs().max())
+    # hi + lo keeps 16 significant bits of every operand (2^-16 per product, the lo*lo term is dropped); after the sum
+    # over K the result is far below that
+    tol = 2e-5 if x3 else 2e-6
+    if mode == "plain":
+        ops.gemm_nt(a, w, out, x3=x3)
+    elif mode == "bias":
+        ops.gemm_nt(a, w, out, bias=bias, x3=x3)
+        ref = ref + bias
+    elif mode == "bias_res":
+        ops.gemm_nt(a, w, out, bias=bias, res=res, x3=x3)
+        ref = ref + bias + res.double()
+    elif mode == "bias_gelu":
+        ops.gemm_nt(a, w, out, bias=bias, gelu_out=act, x3=x3)
+        ref = ref + bias
+        assert rel(act, ref * torch.sigmoid(1.702 * ref)) < max(tol, 1e-5)
+    else:
+        ops.gemm_nt(a, w, out, dgelu_aux=aux, x3=x3)
+        x = aux.double()
+        s = torch.sigmoid(1.702 * x)
+        ref = ref * (s * (1 + 1.702 * x * (1 - s)))
+        tol = max(tol, 1e-5)
+    assert not torch.isnan(out).any()
+    assert rel(out, ref) < tol, rel(out, ref)
+
+
+def test_x3_gemm_rejects_large_products():
+    """FFM_F32_X3 exists for skinny products only: anything else is refused, never computed some other way."""
+    from fairfedmed_amd import ops
+    a = torch.randn(256, 512, device="cuda")
+    w = torch.randn(512, 512, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, w, torch.empty(256, 512, device="cuda"), x3=True)
