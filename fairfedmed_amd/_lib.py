@@ -31,12 +31,13 @@ class GemmArgs(C.Structure):
         ("bias", _vp), ("ts", _vp), ("lw", _vp), ("res", _vp), ("c2", _vp), ("aux", _vp),
         ("rk", _vp), ("S", _vp), ("attr", _vp), ("t_out", _vp), ("ts_out", _vp), ("t_fwd", _vp), ("ds_part", _vp),
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
-        ("b_packed", _vp),
+        ("b_packed", _vp), ("lw_wide", _vp),
     ]
 
 
 class PackDesc(C.Structure):
-    _fields_ = [("src", _vp), ("dst", _vp), ("K", _i32), ("r", _i32), ("layout_rk", _i32), ("pad_", _i32)]
+    _fields_ = [("src", _vp), ("dst", _vp), ("K", _i32), ("r", _i32), ("layout_rk", _i32), ("pad_", _i32),
+                ("dst_wide", _vp)]
 
 
 class ReduceDesc(C.Structure):

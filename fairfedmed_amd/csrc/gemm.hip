@@ -549,6 +549,15 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const ffm_pack_desc* __r
         if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
         dst[i] = Elem<T>::from_f(v);
     }
+    if (d.dst_wide) {                                      // [K][32]: the `lw` tile form of the panel GEMM's rank-r update
+        T* wide = reinterpret_cast<T*>(d.dst_wide);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * d.K; i += gridDim.x * blockDim.x) {
+            const int k = i >> 5, j = i & 31;
+            float v = 0.f;
+            if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
+            wide[i] = Elem<T>::from_f(v);
+        }
+    }
 }
 
 }  // namespace

@@ -59,7 +59,7 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 #define FFM_STAMP(i)                                                                                         \
     do {                                                                                                     \
         if (p.ts && tid == 0) {                                                                              \
-            unsigned long long* sb__ = (unsigned long long*)p.ts + ((size_t)blockIdx.x * 8 + (i)) * 2;       \
+            unsigned long long* sb__ = (unsigned long long*)p.ts + ((size_t)blockIdx.x * 12 + (i)) * 2;       \
             sb__[0] = __builtin_amdgcn_s_memtime();                                                          \
             sb__[1] = __builtin_amdgcn_s_memrealtime();                                                      \
         }                                                                                                    \
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     loadB(1, bq[1]);
     loadB(2, bq[2]);
     fence();
+    FFM_STAMP(6);
 
     // ---- persistent epilogue operands (their loads overlap the first ring fills)
     float* Bias = reinterpret_cast<float*>(smem + G::RING);
@@ -250,29 +251,40 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int r = RK ? p.rank : 0;
     for (int i = tid; i < BNp; i += PT) Bias[i] = (flags & FFM_EPI_BIAS) ? p.bias[n0 + i] : 0.f;
     if constexpr (RK) {
-        // LoRA matrix tile: thread -> column n; all of its global loads are issued before the first LDS store
-        // (a load -> store loop pays one memory round trip per iteration), then one 64-byte row is written.
-        constexpr int NCOL = (BNp + PT - 1) / PT;
-        float lwv[NCOL][16];
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            const int n = tid + c * PT;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                lwv[c][j] = 0.f;
-                if (j < r && n < BNp)
-                    lwv[c][j] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
+        if (p.lw_wide) {
+            // the tile [BN][32] of the pre-packed LoRA matrix (ffm_lora_pack_multi, dst_wide) is one contiguous
+            // BN * 64 bytes: straight into LDS by DMA, 1 KiB pieces dealt over the waves (no VALU, no LDS stores; the
+            // conversion loop below cost 3-6.5 us of VMEM issue behind the ring fills, tools/panel_stamps.py)
+            const char* wsrc = reinterpret_cast<const char*>(p.lw_wide) + (size_t)n0 * 64 + lane * 16;
+            for (int q = wave; q < BNp / 16; q += PW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + q * 1024),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(LwB) + q * 1024),
+                                                 16, 0, 0);
+        } else {
+            // LoRA matrix tile: thread -> column n; all of its global loads are issued before the first LDS store
+            // (a load -> store loop pays one memory round trip per iteration), then one 64-byte row is written.
+            constexpr int NCOL = (BNp + PT - 1) / PT;
+            float lwv[NCOL][16];
+    #pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                const int n = tid + c * PT;
+    #pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    lwv[c][j] = 0.f;
+                    if (j < r && n < BNp)
+                        lwv[c][j] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + n) * r + j] : p.lw[(size_t)j * p.N + n0 + n];
+                }
             }
-        }
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            const int n = tid + c * PT;
-            if (n < BNp) {
-                bf16x8 lo8, hi8, z8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { lo8[j] = (bf16_t)lwv[c][j]; hi8[j] = (bf16_t)lwv[c][8 + j]; z8[j] = (bf16_t)0.f; }
-                bf16x8* row = reinterpret_cast<bf16x8*>(LwB + n * 32);
-                row[0] = lo8; row[1] = hi8; row[2] = z8; row[3] = z8;
+    #pragma unroll
+            for (int c = 0; c < NCOL; ++c) {
+                const int n = tid + c * PT;
+                if (n < BNp) {
+                    bf16x8 lo8, hi8, z8;
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) { lo8[j] = (bf16_t)lwv[c][j]; hi8[j] = (bf16_t)lwv[c][8 + j]; z8[j] = (bf16_t)0.f; }
+                    bf16x8* row = reinterpret_cast<bf16x8*>(LwB + n * 32);
+                    row[0] = lo8; row[1] = hi8; row[2] = z8; row[3] = z8;
+                }
             }
         }
         if (tid < p.G * r) Sg[tid] = p.S[tid];
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             Ga[i] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
         }
     }
+    FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FFM_STAMP(1);
@@ -363,9 +376,8 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int CPR = 2 * NF;                       // 8-column chunks per row of the wave's slab
     constexpr int NRG = (MF + 1) / 2;                 // 32-row groups
     constexpr int PF = NRG < 3 ? NRG : 3;             // row groups of residual / pre-activation rows kept in flight
-    float* Tt = reinterpret_cast<float*>(smem);                       // RANKOP: t tile [BM][16]
+    // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
-    float* Wv = reinterpret_cast<float*>(smem + BMp * 128);           // dS scratch [BM][16]
     float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + wave * (32 * PITCH);
     bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
 
@@ -373,15 +385,26 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr bool PRE = (flags & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU)) != 0;
     const bf16_t* prep = reinterpret_cast<const bf16_t*>((flags & FFM_EPI_RESIDUAL) ? p.res : p.aux);
     bf16x8 rpre[PF][NF];
+    // The loads are inline asm with hand-counted waits, like the weight fragments of the main loop: left to the
+    // compiler, every use of a prefetched row group became s_waitcnt vmcnt(0), which also waits for the stores just
+    // issued and for the two younger prefetches (dX(c_proj): 26 us of output epilogue for 13 us of HBM traffic).
+    // Rows beyond M (last row tile) are clamped: loaded, never stored.
     auto load_pre = [&](int rg, bf16x8 (&dst)[NF]) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
-            const int gm = m0 + rg * 32 + row;
-            if (gm < p.M && rg * 32 + row < BMp)
-                dst[i] = *reinterpret_cast<const bf16x8*>(prep + (size_t)gm * p.ldc + n0w + ch * 8);
+            int gm = m0 + rg * 32 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            const bf16_t* src = prep + (size_t)gm * p.ldc + n0w + ch * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[i]) : "v"(src) : "memory");
         }
     };
+    // VMEM operations younger than the load of (row group q >= PF, chunk i), which is issued at the end of group q - PF:
+    // the rest of its batch, groups q-PF+1 .. q-1 (NF * SPC stores each, plus a batch of NF loads while one is left to
+    // issue), and this group's stores so far.  Exact when every lane stores (full tiles); the last group of an odd MF
+    // has chunks without rows, so its own stores are not counted (waits a little longer than needed).
+    constexpr int SPC = (flags & FFM_EPI_GELU) ? 2 : 1;
+    const bool full_tile = m0 + BMp <= p.M;
     if constexpr (PRE) {
 #pragma unroll
         for (int g = 0; g < PF; ++g) load_pre(g, rpre[g]);
@@ -389,73 +412,138 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     if constexpr (RK) {
         // pi_b[g] = lambda on the sample's own group, (1 - lambda) / (G - 1) elsewhere, 1 / G without an attribute:
-        //   s_b[j] = sum_g pi_b[g] S[g][j] = w_o * Ssum[j] + (lambda - w_o) * S[a][j]      (a >= 0)
+        //   s_b[j] = sum_g pi_b[g] S[g][j] = w_o * ssum[j] + (lambda - w_o) * S[a][j]      (a >= 0), ssum[j] = sum_g S[g][j]
         // (one LDS read and one FMA per entry instead of a loop over the groups with a division in it)
         const float w_own = p.lambda_group, w_oth = (1.0f - p.lambda_group) / (float)(p.G > 1 ? p.G - 1 : 1);
         const float w_uni = 1.0f / (float)p.G;
-        if (tid < r) {
-            float sacc = 0.f;
-            for (int g = 0; g < p.G; ++g) sacc += Sg[g * r + tid];
-            Ssum[tid] = sacc;
-        }
+        // Every block of a tile row holds the same t: the stores of t / ts and the dS partial sums are split over
+        // the tiles_n blocks by FRAGMENT ROWS (block tn takes the fragment rows mf = tn mod tiles_n), so that no block
+        // becomes a straggler of this single-round kernel and the choice is a wave-uniform branch.
+        const bool do_ds = p.t_fwd && p.ds_part;
+        // t stays in the registers of the wave whose MFMAs made it (fragment row mfi belongs to wave mfi % 4; lane =
+        // (column j = frow, rows 4 * fgrp + e)): ts, the t / ts stores and the dS products are formed right there, only
+        // the bf16 ts tile goes through LDS (it is the A operand of the rank-r update of ALL four waves).  Before, t
+        // made a round trip through LDS into a thread-per-element loop with the t_fwd loads inside it, and 24 threads
+        // summed the dS products row by row: 4-10 us per launch (tools/panel_stamps.py), now one barrier.
+        const int j = frow;
+        const bool jok = j < r;
+        float ssum = 0.f;
+#pragma unroll
+        for (int g = 0; g < FFM_MAX_GROUPS; ++g)
+            if (g < p.G && jok) ssum += Sg[g * r + j];
+        float d_all = 0.f, d_uni = 0.f, d_own[FFM_MAX_GROUPS];
+#pragma unroll
+        for (int g = 0; g < FFM_MAX_GROUPS; ++g) d_own[g] = 0.f;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int mfi = wave + PW * i;
             if (mfi < MF) {
+                const bool mine = __builtin_amdgcn_readfirstlane((int)((unsigned)mfi % (unsigned)tiles_n)) == tn;
+                const int row0 = mfi * 16 + fgrp * 4;
+                // (three passes, so that the LDS / global reads of the four elements are in flight together)
+                int ga[4];
+                float sgv[4], tfw[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Tt[(mfi * 16 + fgrp * 4 + e) * 16 + frow] = tacc[i][e];
-            }
-        }
-        __syncthreads();
-        // Every block of a tile row holds the same t: the stores of t / ts and the dS partial sums are split over
-        // the tiles_n blocks by rows, so that no block becomes a straggler of this single-round kernel.
-        const int rsl = (BMp + tiles_n - 1) / tiles_n;
-        const int rs0 = tn * rsl, rs1 = (rs0 + rsl) < BMp ? (rs0 + rsl) : BMp;
-        const bool do_ds = p.t_fwd && p.ds_part;
-        for (int idx = tid; idx < BMp * 16; idx += PT) {
-            const int row = idx >> 4, j = idx & 15;
-            const int gm = m0 + row;
-            float tsv = 0.f, wv = 0.f;
-            if (j < r && gm < p.M) {
-                const float tv = Tt[idx];
-                const int a = Ga[row];
-                const float sb = a < 0 ? w_uni * Ssum[j] : w_oth * Ssum[j] + (w_own - w_oth) * Sg[a * r + j];
-                tsv = p.scaling * tv * sb;
-                if (row >= rs0 && row < rs1) {
-                    if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
-                    if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv;
-                    if (do_ds) wv = p.scaling * p.t_fwd[(size_t)gm * r + j] * tv;
+                for (int e = 0; e < 4; ++e) {
+                    ga[e] = Ga[row0 + e];
+                    tfw[e] = 0.f;
+                }
+                if (mine && do_ds && jok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m0 + row0 + e < p.M) tfw[e] = p.t_fwd[(size_t)(m0 + row0 + e) * r + j];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sgv[e] = (jok && ga[e] >= 0) ? Sg[ga[e] * r + j] : 0.f;
+                float tsv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sb = ga[e] < 0 ? w_uni * ssum : w_oth * ssum + (w_own - w_oth) * sgv[e];
+                    tsv[e] = (jok && m0 + row0 + e < p.M) ? p.scaling * tacc[i][e] * sb : 0.f;
+                    TsA[(row0 + e) * 32 + j] = (bf16_t)tsv[e];
+                    TsA[(row0 + e) * 32 + 16 + j] = (bf16_t)0.f;
+                }
+                if (mine && jok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gm = m0 + row0 + e;
+                        if (gm < p.M) {
+                            if (p.t_out) p.t_out[(size_t)gm * r + j] = tacc[i][e];
+                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv[e];
+                        }
+                        const float wv = p.scaling * tfw[e] * tacc[i][e];      // tfw = 0 beyond M and without dS
+                        if (ga[e] < 0) d_uni += wv; else d_all += wv;
+#pragma unroll
+                        for (int g = 0; g < FFM_MAX_GROUPS; ++g) d_own[g] += (ga[e] == g) ? wv : 0.f;
+                    }
                 }
             }
-            TsA[row * 32 + j] = (bf16_t)tsv;
-            TsA[row * 32 + 16 + j] = (bf16_t)0.f;
-            if (do_ds) Wv[idx] = wv;
+        }
+        FFM_STAMP(8);
+        float* DsP = reinterpret_cast<float*>(smem);                  // [PW][FFM_MAX_GROUPS + 2][16]: per-wave dS sums
+        if (do_ds) {
+            // dS partial of this block's row slice: sum_rows pi_b[g] * scaling * t_fwd * t
+            //   = w_o * sum_rows wv + (lambda - w_o) * sum_{rows of group g} wv     (uniform mix: w_uni * sum_rows wv)
+            // fixed order: the lane's rows, the four row groups of the wave (two butterfly steps), then the waves
+            auto rows4 = [](float v) {
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                return v;
+            };
+            d_all = rows4(d_all);
+            d_uni = rows4(d_uni);
+#pragma unroll
+            for (int g = 0; g < FFM_MAX_GROUPS; ++g)
+                if (g < p.G) d_own[g] = rows4(d_own[g]);
+            if (fgrp == 0) {
+                float* dst = DsP + wave * ((FFM_MAX_GROUPS + 2) * 16) + j;
+                dst[0] = d_all;
+                dst[16] = d_uni;
+#pragma unroll
+                for (int g = 0; g < FFM_MAX_GROUPS; ++g)
+                    if (g < p.G) dst[(2 + g) * 16] = d_own[g];
+            }
         }
         __syncthreads();
+        FFM_STAMP(9);
         if (do_ds && tid < p.G * r) {
-            // dS partial of this block's row slice: sum_rows pi_b[g] * scaling * t_fwd * t
-            //   = w_o * sum_rows Wv + (lambda - w_o) * sum_{rows of group g} Wv     (uniform mix: w_uni * sum_rows Wv)
-            const int g = tid / r, j = tid % r;
+            const int g = tid / r, jj = tid % r;
             float all = 0.f, own = 0.f, uni = 0.f;
-            for (int row = rs0; row < rs1; ++row) {
-                const float w = Wv[row * 16 + j];
-                const int a = Ga[row];
-                if (a < 0) uni += w; else { all += w; if (a == g) own += w; }
+#pragma unroll
+            for (int w = 0; w < PW; ++w) {
+                const float* src = DsP + w * ((FFM_MAX_GROUPS + 2) * 16) + jj;
+                all += src[0];
+                uni += src[16];
+                own += src[(2 + g) * 16];
             }
-            p.ds_part[((size_t)(tm * tiles_n + tn) * p.G + g) * r + j] = w_uni * uni + w_oth * all + (w_own - w_oth) * own;
+            p.ds_part[((size_t)(tm * tiles_n + tn) * p.G + g) * r + jj] = w_uni * uni + w_oth * all + (w_own - w_oth) * own;
         }
         // rank-r update on the matrix cores: acc += TsA . LwB^T (K = 32 rank slots, zero padded)
         frag_t lb[NF];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
             lb[nf] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(LwB) + (wave * WN + nf * 16 + frow) * 64 + fgrp * 16);
-        static_for<MF>([&](auto MF_) {
-            constexpr int mf = decltype(MF_)::value;
-            const frag_t a = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(TsA) + (mf * 16 + frow) * 64 + fgrp * 16);
-            static_for<NF>([&](auto NF_) {
-                constexpr int nf = decltype(NF_)::value;
-                mma(std::integral_constant<int, mf * NF + nf>{}, acc[mf][nf], a, lb[nf]);
+        FFM_STAMP(10);
+        // ts fragments in batches ahead of their MFMAs (the weight-fragment ring is dead; a tile whose accumulators
+        // and pre-activation rows already fill the register file takes smaller batches)
+        constexpr int TB = MF * NF > 64 ? 4 : MF;
+        static_for<(MF + TB - 1) / TB>([&](auto B_) {
+            constexpr int b0 = decltype(B_)::value * TB;
+            constexpr int nb = (MF - b0) < TB ? (MF - b0) : TB;
+            frag_t ta[nb];
+#pragma unroll
+            for (int q = 0; q < nb; ++q)
+                ta[q] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(TsA) + ((b0 + q) * 16 + frow) * 64 + fgrp * 16);
+            const f32x4(&accr)[MF][NF] = acc;
+            (void)accr;
+            static_for<nb>([&](auto Q_) {
+                constexpr int mf = b0 + decltype(Q_)::value;
+                static_for<NF>([&](auto NF_) {
+                    constexpr int nf = decltype(NF_)::value;
+                    mma(std::integral_constant<int, mf * NF + nf>{}, acc[mf][nf], ta[decltype(Q_)::value], lb[nf]);
+                });
             });
+            fence();
         });
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
@@ -492,6 +580,32 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8 + 4]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { v[c] = c0[c] + b0[c]; v[4 + c] = c1[c] + b1[c]; }
+            if constexpr (PRE) {
+                if constexpr (rg < PF) {
+                    // issued before the rank-r update: one drain in front of the first use covers the first PF groups
+                    if (rg == 0 && i == 0) wait_vm<0>();
+                } else {
+                    constexpr int last_odd = (rg == NRG - 1 && (MF & 1)) ? 1 : 0;
+                    constexpr int batches = (PF - 1) - ((rg - 1 + PF >= NRG) ? 1 : 0) - ((rg - 2 + PF >= NRG && PF >= 3) ? 1 : 0);
+                    static_assert(PF <= 3, "the count below walks at most two groups back");
+                    constexpr int young_base = (PF - 1) * NF * SPC + (batches > 0 ? batches : 0) * NF;
+                    // (i is a loop variable of an unrolled loop: the switch folds to one immediate per copy)
+                    const int young = young_base + (NF - 1 - i) + (last_odd ? 0 : i * SPC);
+                    if (!full_tile) wait_vm<0>();
+                    else switch (young) {
+#define FFM_WV(n) case n: wait_vm<n>(); break;
+                        FFM_WV(0) FFM_WV(1) FFM_WV(2) FFM_WV(3) FFM_WV(4) FFM_WV(5) FFM_WV(6) FFM_WV(7) FFM_WV(8) FFM_WV(9)
+                        FFM_WV(10) FFM_WV(11) FFM_WV(12) FFM_WV(13) FFM_WV(14) FFM_WV(15) FFM_WV(16) FFM_WV(17) FFM_WV(18)
+                        FFM_WV(19) FFM_WV(20) FFM_WV(21) FFM_WV(22) FFM_WV(23) FFM_WV(24) FFM_WV(25) FFM_WV(26) FFM_WV(27)
+                        FFM_WV(28) FFM_WV(29) FFM_WV(30) FFM_WV(31) FFM_WV(32) FFM_WV(33) FFM_WV(34) FFM_WV(35) FFM_WV(36)
+                        FFM_WV(37) FFM_WV(38) FFM_WV(39) FFM_WV(40) FFM_WV(41) FFM_WV(42) FFM_WV(43) FFM_WV(44) FFM_WV(45)
+                        FFM_WV(46) FFM_WV(47) FFM_WV(48)
+#undef FFM_WV
+                        default: wait_vm<0>();
+                    }
+                }
+                asm volatile("" : "+v"(rpre[rg % PF][i]));
+            }
             if constexpr ((flags & FFM_EPI_RESIDUAL) != 0) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];

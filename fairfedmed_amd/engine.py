@@ -350,14 +350,19 @@ class FairLoRAEngine:
             w = v.width
             ent = []
             self.rk = []
+            self.lw_wide = []
             for blk in self.vis.blocks:
                 pk = {"fc_A": torch.zeros(16, w, device=dev, dtype=dtype),
                       "proj_A": torch.zeros(16, 4 * w, device=dev, dtype=dtype),
                       "fc_B": torch.zeros(16, 4 * w, device=dev, dtype=dtype),
                       "proj_B": torch.zeros(16, w, device=dev, dtype=dtype)}
                 self.rk.append(pk)
+                # the same matrices as [K, 32] rows: the `lw` operand of the GEMM whose OUTPUT columns they span
+                wd = {role: torch.zeros(buf.shape[1], 32, device=dev, dtype=dtype) for role, buf in pk.items()} \
+                    if dtype == torch.bfloat16 else {}
+                self.lw_wide.append(wd)
                 for role, buf in pk.items():
-                    ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf))
+                    ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf, wd.get(role)))
             self.pack_plan = ops.PackPlan(ent, dtype, dev)
 
     def _n_layer_events(self) -> int:
@@ -475,11 +480,12 @@ class FairLoRAEngine:
             ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
             if r and self.fused_rank:
                 ro = ops.RankOp(self.rk[i]["fc_A"], self._S(i, "fc"), attr, rows_per_sample, lo.scaling,
-                                lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i])
+                                lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i], lw_wide=self.lw_wide[i].get("fc_B"))
                 gemm(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
                             b_packed=blk.pk("w_fc"))
                 ro = ops.RankOp(self.rk[i]["proj_A"], self._S(i, "proj"), attr, rows_per_sample,
-                                lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i])
+                                lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i],
+                                lw_wide=self.lw_wide[i].get("proj_B"))
                 gemm(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
                             res=xm, rankop=ro, b_packed=blk.pk("w_proj"))
             elif r:
@@ -521,7 +527,8 @@ class FairLoRAEngine:
                 fused = self.fused_rank
                 if fused:
                     ro = ops.RankOp(self.rk[i]["proj_B"], self._S(i, "proj"), attr, rows_per_sample,
-                                    lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"])
+                                    lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"],
+                                    lw_wide=self.lw_wide[i].get("proj_A"))
                     gemm(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                                 dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"))
                 else:
@@ -532,7 +539,8 @@ class FairLoRAEngine:
                 if fused and not last:
                     # u1 = dpre B_fc^T rides inside the dX GEMM of c_fc
                     ro = ops.RankOp(self.rk[i]["fc_B"], self._S(i, "fc"), attr, rows_per_sample,
-                                    lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"])
+                                    lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"],
+                                    lw_wide=self.lw_wide[i].get("fc_A"))
                     gemm(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
                                 rankop=ro, b_packed=blk.pk("w_fc_t"))
                 else:

@@ -91,10 +91,11 @@ class RankOp:
 
     def __init__(self, rk: Tensor, S: Tensor, attr: Optional[Tensor], rows_per_sample: int, scaling: float,
                  lambda_group: float, t_out: Optional[Tensor] = None, ts_out: Optional[Tensor] = None,
-                 t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None):
+                 t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None, lw_wide: Optional[Tensor] = None):
         self.rk, self.S, self.attr, self.rps = rk, S, attr, rows_per_sample
         self.scaling, self.lam = scaling, lambda_group
         self.t_out, self.ts_out, self.t_fwd, self.ds_part = t_out, ts_out, t_fwd, ds_part
+        self.lw_wide = lw_wide                    # `lw` as [N, 32] rows in the activation dtype (PackPlan's wide output)
 
 
 def gemm_tiles_m(M: int, N: int = 128, K: int = 128, flags: int = 0, rank: int = 0, dtype=torch.float32,
@@ -131,7 +132,9 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         _f32(bias)
     ro = rankop
     if ro is not None:
-        _dev(ro.rk, ro.S, ro.attr, ro.t_out, ro.ts_out, ro.t_fwd, ro.ds_part)
+        _dev(ro.rk, ro.S, ro.attr, ro.t_out, ro.ts_out, ro.t_fwd, ro.ds_part, ro.lw_wide)
+        assert ro.lw_wide is None or (ro.lw_wide.dtype == a.dtype and tuple(ro.lw_wide.shape) == (N, 32)
+                                      and ro.lw_wide.is_contiguous())
         flags |= L.EPI_LORA | L.EPI_RANKOP | (L.EPI_LORA_KR if lw_is_kr else 0)
         rank = ro.S.shape[1]
         assert ro.rk.dtype == a.dtype and tuple(ro.rk.shape) == (16, K) and ro.rk.is_contiguous()
@@ -158,7 +161,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
-                      L.ptr(b_packed))
+                      L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None)
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
     _call("ffm_gemm_nt", C.byref(args), L.F32_X3 if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
@@ -440,15 +443,18 @@ class PackPlan:
     """Device-resident descriptor table for ffm_lora_pack_multi (all adapters in one launch)."""
 
     def __init__(self, entries, dtype, device):
-        # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype)
+        # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype[, wide [K,32] dtype])
         arr = (L.PackDesc * len(entries))()
         self.keep, self.max_K, self.dtype = entries, 0, dtype
-        for i, (src, layout_rk, dst) in enumerate(entries):
-            _dev(src, dst)
+        for i, ent in enumerate(entries):
+            src, layout_rk, dst = ent[:3]
+            wide = ent[3] if len(ent) > 3 else None
+            _dev(src, dst, wide)
             K = dst.shape[1]
             r = src.shape[0] if layout_rk else src.shape[1]
             assert dst.dtype == dtype and dst.shape[0] == 16 and dst.is_contiguous() and src.is_contiguous()
-            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0)
+            assert wide is None or (wide.dtype == dtype and tuple(wide.shape) == (K, 32) and wide.is_contiguous())
+            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0, L.ptr(wide))
             self.max_K = max(self.max_K, K)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n = len(entries)

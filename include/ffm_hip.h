@@ -44,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide, ffm_pack_desc.dst_wide; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -85,6 +85,10 @@ typedef struct ffm_gemm_args {
      * weights.  When present and the shape fills the chip in one round of large tiles, the panel kernel
      * streams it straight into registers (csrc/gemm_panel.hip); `b` must still be valid. */
     const void*  b_packed;
+    /* optional (bf16, FFM_EPI_RANKOP): the LoRA matrix `lw` as [N, 32] dtype rows, row n = the r entries of output
+     * column n followed by zeros (ffm_lora_pack_multi's dst_wide): the panel kernel copies its tile of it straight
+     * into LDS instead of converting `lw`; `lw` must still be valid. */
+    const void*  lw_wide;
 } ffm_gemm_args;
 
 /*
@@ -114,6 +118,7 @@ typedef struct ffm_pack_desc {
     const float* src;
     void* dst;
     int32_t K, r, layout_rk, pad_;
+    void* dst_wide;     /* optional [K, 32] dtype: dst_wide[k][j] = the same element as dst[j][k], columns >= r zero */
 } ffm_pack_desc;
 int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream);
 

@@ -5,6 +5,7 @@ pairs at its phase boundaries, one set per block:
 
   0 entry | 1 prologue done (ring stages 0-2 landed, epilogue operands in LDS) | 2 main loop done |
   3 rank-r update done | 4 epilogue stores issued | 5 stores acknowledged
+  (inside the prologue: 6 ring stages + weight fragments issued | 7 epilogue operands loaded and in LDS)
 
 Prints, per shape: launch duration by HIP events, the spread of block entry times, and the median / max per-phase
 time over the blocks (us, from the 100 MHz clock; cycles from the shader clock).
@@ -22,7 +23,7 @@ from fairfedmed_amd import ops
 
 dt = torch.bfloat16
 M, W, R, G, RPS = 6304, 768, 8, 3, 197
-NST = 8
+NST = 12
 
 
 def plain(a, b, out, bp, bias, res, st):
@@ -59,15 +60,18 @@ def case(name, N, K, mode):
             P = torch.randn(K, R, device="cuda", generator=g) * 0.1
             rk = torch.zeros(16, K, device="cuda", dtype=dt)
             ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+            lwsrc = torch.randn(N, R, device="cuda", generator=g) if kr else torch.randn(R, N, device="cuda", generator=g)
+            wide = torch.zeros(N, 32, device="cuda", dtype=dt)
+            ops.PackPlan([(lwsrc, not kr, torch.zeros(16, N, device="cuda", dtype=dt), wide)], dt, "cuda").run()
             attr = torch.randint(0, G, (32,), device="cuda", dtype=torch.int32)
             t, ts = torch.empty(M, R, device="cuda"), torch.empty(M, R, device="cuda")
             rows = max(ops.gemm_tiles_m(M, N, K, 0, 0, dt, False), 512)
             ro = ops.RankOp(rk, torch.randn(G, R, device="cuda", generator=g), attr, RPS, 0.25, 0.7,
                             t_out=None if kr else t, ts_out=ts,
                             t_fwd=torch.randn(M, R, device="cuda", generator=g) if kr else None,
-                            ds_part=torch.empty(rows, G, R, device="cuda") if kr else None)
-            kw.update(lw=torch.randn(N, R, device="cuda", generator=g) if kr else torch.randn(R, N, device="cuda", generator=g),
-                      lw_is_kr=kr, rankop=ro)
+                            ds_part=torch.empty(rows, G, R, device="cuda") if kr else None,
+                            lw_wide=None if "nowide" in sys.argv else wide)
+            kw.update(lw=lwsrc, lw_is_kr=kr, rankop=ro)
         sets.append((a, b, out, ops.pack_b(b), kw))
     stamps = torch.zeros(1024 * NST * 2, device="cuda", dtype=torch.int64)
     nostamp = None
@@ -97,6 +101,14 @@ def case(name, N, K, mode):
         d, dc = rt[:, i + 1] - rt[:, i], cyc[:, i + 1] - cyc[:, i]
         print(f"    {n:16s} median {np.median(d):6.2f} us  max {d.max():6.2f} us   {np.median(dc):9.0f} cycles "
               f"({np.median(dc) / max(np.median(d), 1e-9) / 1e3:.2f} GHz)")
+    for n, i, j in (("  pro: issue ring+B", 0, 6), ("  pro: epilogue operands", 6, 7), ("  pro: wait for all", 7, 1)):
+        d = rt[:, j] - rt[:, i]
+        print(f"    {n:24s} median {np.median(d):6.2f} us  max {d.max():6.2f} us")
+    if "l" in mode:
+        for n, i, j in (("  rank: ts in registers", 2, 8), ("  rank: barrier", 8, 9), ("  rank: dS sum, lw frags", 9, 10),
+                        ("  rank: MFMAs", 10, 3)):
+            d = rt[:, j] - rt[:, i]
+            print(f"    {n:24s} median {np.median(d):6.2f} us  max {d.max():6.2f} us")
     end = rt[:, 5] - t0
     print(f"    block end time   median {np.median(end):6.2f} us  min {end.min():6.2f}  max {end.max():6.2f}")
 
