@@ -48,7 +48,8 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
         o = os.path.join(CSRC, src.replace(".hip", ".stamps.o" if special else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + (["-DFFM_PANEL_STAMPS"] if special else []) + ["-c", s, "-o", o])
+            extra = ["-DFFM_PANEL_STAMPS"] + os.environ.get("FFM_STAMPS_DEFS", "").split() if special else []
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -13,6 +13,8 @@
 //   backward: dQ kernel (same shape as forward); delta = rowsum(dO * O) is formed inside both kernels;
 //             dK/dV kernel: waves own 16-key tiles and sweep all queries.
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -501,6 +503,190 @@ template <typename F> int set_lds(F fn, int bytes) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Second-generation kernels for the vision tower (bf16, no mask, 8..14 key fragments: L = 113..224 tokens).
+//
+// What the first generation spends its time on (rocprofv3 + SQ counters, profiles/r01_v6_sq_counters.json: MFMA pipes
+// 5-9 % busy): (i) one block per (b, h) = 384 blocks of 14 waves on 256 CUs, two per CU on half of the chip and one on
+// the rest; (ii) ~10 VALU instructions per score element (scale, mask, max, subtract, exp, ...) at 6-7 waves per SIMD;
+// (iii) V (and K / Q / dO in the backward kernels) staged TRANSPOSED through registers with 2-byte LDS stores.
+// Here:
+//   * a block is HALF a head's 16-row tiles (7 + 6 for L = 197): 768 blocks = exactly three per CU at 7 waves each,
+//     the two halves of a head on one XCD (block ids b and b + 8), so the second fetch of K / V is an L2 hit;
+//   * K and V land ROW-major in LDS by LDS-DMA (8 rows x 128 B per wave instruction, the XOR swizzle applied to the
+//     source address); the transposed operand of O^T = V^T P^T comes from ds_read_b64_tr_b16, so nothing is staged
+//     through registers and no tile exists twice;
+//   * the scores stay unscaled: p = exp2(c s - c m) is one FMA and one exp per element (c = log2(e) / 8), the row
+//     maximum is taken on the raw scores, and only the fragment that straddles L is masked;
+//   * two key chunks with a running maximum (8 fragments, then the rest): 32 score registers instead of 56, which is
+//     what lets three blocks share a CU (<= 80 registers per lane).
+// Rows >= L of the LDS tiles are copies of row L - 1 (the DMA source is clamped): finite, and always multiplied by an
+// exactly zero probability.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// 16-B chunk c of row `row` in a row-major [rows][64] bf16 tile (128-byte rows): the same image as rm_off<bf16_t>
+__device__ __forceinline__ int rm2(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }
+
+// rows [0, nrows) of the token-major matrix `src` (row stride ld elements, 64 columns) -> swizzled LDS tile, by DMA
+template <int NW>
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld, int L, int nrows, char* dst, int wave, int lane) {
+    const int rsub = lane >> 3, slot = lane & 7;
+    for (int pc = wave; pc < nrows / 8; pc += NW) {
+        int row = pc * 8 + rsub;
+        const int chunk = slot ^ (row & 7);
+        row = row < L ? row : L - 1;
+        const bf16_t* g = src + (size_t)row * ld + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    }
+}
+
+// A-operand fragment (8 bf16) of X^T for the k-step whose keys are 32 s + 16 (j >> 2) + 4 g + (j & 3), rows d = 16 fd + (lane & 15):
+// two transposed reads of the row-major tile X [token][64] (cdna_hip_programming.md T10: lane 4q + p of a 16-lane
+// group addresses row q, columns 4p .. 4p + 3 of a 4 x 16 block and receives column (lane & 15) of its four rows)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int fd, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    const int c = fd * 2 + (p >> 1), half = (p & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + rm2(r0, c) + half));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + rm2(r1, c) + half));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// (b, h) pair and half of a block id: ids b and b + 8 (one XCD under round-robin placement: speed only) are the two
+// halves of one pair
+__device__ __forceinline__ void unit_of_block(int bid, int& bh, int& half) {
+    bh = (bid >> 4) * 8 + (bid & 7);
+    half = (bid >> 3) & 1;
+}
+
+constexpr int A2_NW = 7;            // waves per block = 16-row tiles of half a head (L <= 224)
+constexpr float A2_C = 0.125f * 1.44269504088896341f;
+
+template <int NF>
+__global__ __launch_bounds__(A2_NW * 64) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                               float* __restrict__ lse, int L, int heads, int BH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = NF * 16;                                   // key rows of a tile
+    constexpr int CA = 8, CB = NF - CA;                           // key fragments of the two chunks
+    static_assert(NF >= 9 && NF <= 14, "two chunks: 8 fragments + 1..6");
+    char* Vs = smem;                                              // [NK][128 B]; PV reads up to 16 rows past it: into Ks
+    char* Ks = smem + NK * 128;
+    int bh, half;
+    unit_of_block(blockIdx.x, bh, half);
+    if (bh >= BH) return;
+    const int b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const bf16_t* base = qkv + (size_t)b * L * ld + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
+    const int qt = half * h0 + wave;                              // this wave's 16-query tile
+    const bool active = qt < (half ? NFq : h0);
+
+    dma_tile<A2_NW>(base + 2 * E, ld, L, NK, Vs, wave, lane);
+    dma_tile<A2_NW>(base + E, ld, L, NK, Ks, wave, lane);
+    const int q = qt * 16 + col;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = gfrag<bf16_t>(base, ld, active ? q : 0, L, ks, g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;                                          // whole waves only (the transposed reads need EXEC = all ones)
+
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) o[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto chunk = [&](auto F0_, auto CF_) {
+        constexpr int F0 = decltype(F0_)::value, CF = decltype(CF_)::value, CP = (CF + 1) & ~1;
+        f32x4 s[CP];
+        float mx = m;
+#pragma unroll
+        for (int f = 0; f < CF; ++f) {
+            const int row = (F0 + f) * 16 + col;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Ks + rm2(row, ks * 4 + g)), qf[ks], acc, 0, 0, 0);
+            if ((F0 + f) * 16 + 15 >= L) {                        // the fragment that straddles L (uniform branch)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((F0 + f) * 16 + g * 4 + e >= L) acc[e] = -INFINITY;
+            }
+            s[f] = acc;
+            mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+        }
+        if constexpr (CP > CF) s[CF] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        mx = group4_max(mx);
+        // running maximum: everything accumulated so far is rescaled by 2^(c (m - mx)) (0 the first time: m = -inf)
+        const float alpha = __builtin_amdgcn_exp2f((m - mx) * A2_C);
+        const float mc = mx * A2_C;
+        m = mx;
+        l *= alpha;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[fd][e] *= alpha;
+        float sum = 0.f;
+#pragma unroll
+        for (int st = 0; st < CP / 2; ++st) {
+            bf16x8 pf;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[2 * st + hf][e], A2_C, -mc));
+                    sum += p;
+                    pf[4 * hf + e] = (bf16_t)p;
+                }
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd)
+                o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, F0 / 2 + st, fd, lane), pf, o[fd], 0, 0, 0);
+        }
+        l += group4_sum(sum);
+    };
+    chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, CA>{});
+    chunk(std::integral_constant<int, CA>{}, std::integral_constant<int, CB>{});
+
+    if (q < L) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = out + ((size_t)b * L + q) * E + h * HD;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            f32x4 v = o[fd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= inv;
+            Vec4<bf16_t>::store(orow + fd * 16 + g * 4, v);
+        }
+        if (g == 0 && lse) lse[((size_t)b * heads + h) * L + q] = m * 0.125f + __logf(l);
+    }
+}
+
+template <int NF>
+int run_fwd2(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+    constexpr int lds = 2 * NF * 16 * 128;
+    int e = set_lds(attn2_fwd_kernel<NF>, lds);
+    if (e) return e;
+    const int BH = B * heads;
+    hipLaunchKernelGGL((attn2_fwd_kernel<NF>), dim3(((BH + 7) / 8) * 16), dim3(A2_NW * 64), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                       L, heads, BH);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+// FFM_ATTN=v1: always the first-generation kernels (A/B runs)
+inline bool attn_v1_forced() {
+    static const bool v1 = getenv("FFM_ATTN") && getenv("FFM_ATTN")[0] == 'v' && getenv("FFM_ATTN")[1] == '1';
+    return v1;
+}
+
 inline int pick_split(int bh, int NF) {
     // aim for >= ~3 blocks per CU while keeping >= 4 tiles (one per wave) per block
     int s = 1;
@@ -587,6 +773,16 @@ extern "C" int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return FFM_EINVAL;
     const int nfp = (((L + 15) / 16) + 1) & ~1;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16 && !causal && !attn_v1_forced()) {
+        switch ((L + 15) / 16) {                        // the vision tower's shapes: attn2_* (half a head per block)
+            case 9: return run_fwd2<9>(qkv, out, lse, B, L, heads, s);
+            case 10: return run_fwd2<10>(qkv, out, lse, B, L, heads, s);
+            case 11: return run_fwd2<11>(qkv, out, lse, B, L, heads, s);
+            case 12: return run_fwd2<12>(qkv, out, lse, B, L, heads, s);
+            case 13: return run_fwd2<13>(qkv, out, lse, B, L, heads, s);
+            case 14: return run_fwd2<14>(qkv, out, lse, B, L, heads, s);
+        }
+    }
     if (dtype == FFM_BF16) return dispatch_fwd<bf16_t>(nfp, qkv, out, lse, B, L, heads, causal, s);
     if (dtype == FFM_F32) return dispatch_fwd<float>(nfp, qkv, out, lse, B, L, heads, causal, s);
     return FFM_EINVAL;

@@ -79,6 +79,17 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// The four waves of a block leave a barrier together and run the same instruction stream, so their vector-memory
+// instructions reach the CU's one texture path in the same cycle and three of them wait (an MFMA cannot issue behind
+// a stalled VMEM instruction).  Wave w idles w * FFM_PANEL_STAGGER * 8 cycles after every barrier.
+#ifndef FFM_PANEL_STAGGER
+#define FFM_PANEL_STAGGER 0
+#endif
+__device__ __forceinline__ void stagger(int wave) {
+    if constexpr (FFM_PANEL_STAGGER > 0) {
+        for (int q = 0; q < wave * FFM_PANEL_STAGGER; ++q) asm volatile("s_nop 7");
+    }
+}
 
 __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }                // floats
 // persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
@@ -296,6 +307,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stagger(wave);
     FFM_STAMP(1);
 
     // VMEM issue order of step kt (nA = G::NI pieces, the same on every wave):
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             else if (rem == 3) wait_vm<5 * NF + nA>();
             else wait_vm<4 * NF>();
             block_barrier();
+            stagger(wave);
         }
     };
     auto main_loop = [&](auto W_) {

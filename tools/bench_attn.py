@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Attention forward / backward at the bench shape (B 32, L 197, 12 heads, bf16): us per launch, v2 kernels vs FFM_ATTN=v1
+(run twice, once with FFM_ATTN=v1 in the environment)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fairfedmed_amd import ops
+
+B, L, H = 32, 197, 12
+E = H * 64
+dt = torch.bfloat16
+g = torch.Generator("cuda").manual_seed(1)
+sets = []
+for _ in range(6):
+    qkv = torch.randn(B * L, 3 * E, device="cuda", generator=g).to(dt)
+    out = torch.empty(B * L, E, device="cuda", dtype=dt)
+    lse = torch.empty(B, H, L, device="cuda")
+    dout = torch.randn(B * L, E, device="cuda", generator=g).to(dt)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, L, device="cuda")
+    sets.append((qkv, out, lse, dout, dqkv, delta))
+
+
+def bench(fn, iters=60):
+    for i in range(6):
+        fn(sets[i % 6])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(sets[i % 6])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+f = bench(lambda s: ops.attention_fwd(s[0], s[1], s[2], B, L, H, False))
+b = bench(lambda s: ops.attention_bwd(s[0], s[1], s[3], s[2], s[5], s[4], B, L, H, False))
+print(f"FFM_ATTN={os.environ.get('FFM_ATTN', 'v2')}: forward {f:.1f} us, backward {b:.1f} us per launch "
+      f"(fwd {4 * B * H * L * L * 64 / f / 1e6:.0f} TF/s, bwd {10 * B * H * L * L * 64 / b / 1e6:.0f} TF/s)")
