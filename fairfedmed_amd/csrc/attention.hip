@@ -529,6 +529,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 __device__ __forceinline__ int rm2(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }
 
 // rows [0, nrows) of the token-major matrix `src` (row stride ld elements, 64 columns) -> swizzled LDS tile, by DMA
+// (nrows = L rounded up to 8: the tile's rows)
 template <int NW>
 __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld, int L, int nrows, char* dst, int wave, int lane) {
     const int rsub = lane >> 3, slot = lane & 7;
@@ -545,10 +546,20 @@ __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld,
 // A-operand fragment (8 bf16) of X^T for the k-step whose keys are 32 s + 16 (j >> 2) + 4 g + (j & 3), rows d = 16 fd + (lane & 15):
 // two transposed reads of the row-major tile X [token][64] (cdna_hip_programming.md T10: lane 4q + p of a 16-lane
 // group addresses row q, columns 4p .. 4p + 3 of a 4 x 16 block and receives column (lane & 15) of its four rows)
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int fd, int lane) {
+// Rows are clamped to the tile (rmax = its last row): a lane supplies its own address, and whatever a clamped row
+// delivers meets an exactly zero probability.
+// CLAMP (the peeled last k-step of a tile with fewer than 16 NF rows): only the last 8 rows of fragment NF - 1 and the
+// phantom fragment of an odd NF can lie beyond such a tile.  Without it the rows past the tile are whatever follows it
+// in LDS: callers put another bf16 tile there.
+template <bool CLAMP>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int fd, int lane, int rmax) {
     typedef __attribute__((address_space(3))) s16x4 lds_v;
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    int r0 = 32 * s + 4 * g + q, r1 = r0 + 16;
+    if constexpr (CLAMP) {
+        r0 = r0 < rmax ? r0 : rmax;
+        r1 = r1 < rmax ? r1 : rmax;
+    }
     const int c = fd * 2 + (p >> 1), half = (p & 1) * 8;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + rm2(r0, c) + half));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + rm2(r1, c) + half));
@@ -567,15 +578,17 @@ __device__ __forceinline__ void unit_of_block(int bid, int& bh, int& half) {
 constexpr int A2_NW = 7;            // waves per block = 16-row tiles of half a head (L <= 224)
 constexpr float A2_C = 0.125f * 1.44269504088896341f;
 
-template <int NF>
-__global__ __launch_bounds__(A2_NW * 64) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int NF, bool SH>
+__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                float* __restrict__ lse, int L, int heads, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NK = NF * 16;                                   // key rows of a tile
     constexpr int CA = 8, CB = NF - CA;                           // key fragments of the two chunks
     static_assert(NF >= 9 && NF <= 14, "two chunks: 8 fragments + 1..6");
-    char* Vs = smem;                                              // [NK][128 B]; PV reads up to 16 rows past it: into Ks
-    char* Ks = smem + NK * 128;
+    // rows of a tile: 16 NF, or 8 fewer when L leaves the last 8 rows of the last fragment empty (L = 197: 200 rows,
+    // 51,200 B for both tiles, three blocks per CU); row indices beyond are clamped
+    constexpr int R8 = SH ? NF * 16 - 8 : NF * 16, rmax = R8 - 1;
+    char* Vs = smem;                                              // [R8][128 B]
+    char* Ks = smem + R8 * 128;
     int bh, half;
     unit_of_block(blockIdx.x, bh, half);
     if (bh >= BH) return;
@@ -589,8 +602,8 @@ __global__ __launch_bounds__(A2_NW * 64) void attn2_fwd_kernel(const bf16_t* __r
     const int qt = half * h0 + wave;                              // this wave's 16-query tile
     const bool active = qt < (half ? NFq : h0);
 
-    dma_tile<A2_NW>(base + 2 * E, ld, L, NK, Vs, wave, lane);
-    dma_tile<A2_NW>(base + E, ld, L, NK, Ks, wave, lane);
+    dma_tile<A2_NW>(base + 2 * E, ld, L, R8, Vs, wave, lane);
+    dma_tile<A2_NW>(base + E, ld, L, R8, Ks, wave, lane);
     const int q = qt * 16 + col;
     bf16x8 qf[2];
 #pragma unroll
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(A2_NW * 64) void attn2_fwd_kernel(const bf16_t* __r
                 }
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd)
-                o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, F0 / 2 + st, fd, lane), pf, o[fd], 0, 0, 0);
+                o[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<false>(Vs, F0 / 2 + st, fd, lane, rmax), pf, o[fd], 0, 0, 0);
         }
         l += group4_sum(sum);
     };
@@ -669,16 +682,254 @@ __global__ __launch_bounds__(A2_NW * 64) void attn2_fwd_kernel(const bf16_t* __r
     }
 }
 
-template <int NF>
-int run_fwd2(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
-    constexpr int lds = 2 * NF * 16 * 128;
-    int e = set_lds(attn2_fwd_kernel<NF>, lds);
+template <int NF, bool SH>
+int run_fwd2s(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+    constexpr int lds = 2 * (SH ? NF * 16 - 8 : NF * 16) * 128;
+    int e = set_lds(attn2_fwd_kernel<NF, SH>, lds);
     if (e) return e;
     const int BH = B * heads;
-    hipLaunchKernelGGL((attn2_fwd_kernel<NF>), dim3(((BH + 7) / 8) * 16), dim3(A2_NW * 64), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse,
-                       L, heads, BH);
+    hipLaunchKernelGGL((attn2_fwd_kernel<NF, SH>), dim3(((BH + 7) / 8) * 16), dim3(A2_NW * 64), lds, s, (const bf16_t*)qkv, (bf16_t*)out,
+                       lse, L, heads, BH);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
+}
+template <int NF>
+int run_fwd2(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+    return run_fwd2s<NF, false>(qkv, out, lse, B, L, heads, s);
+}
+
+
+constexpr float A2_LOG2E = 1.44269504088896341f;
+
+// dQ (and delta = rowsum(dO * O), which the dK/dV kernel reads back): a wave owns a 16-query tile, the key on the MFMA
+// row.  S^T = K Q^T and dP^T = V dO^T share the lane layout; dP's accumulator starts at -delta, so dS^T = p * acc with
+// p = exp2(c s - log2(e) lse): one FMA, one exp and one multiply per element (the 1/8 goes onto the dQ tile at the end).
+template <int NF, bool SH>
+__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                  const float* __restrict__ lse, const bf16_t* __restrict__ o_fwd,
+                                                                  bf16_t* __restrict__ dqkv, float* __restrict__ delta, int L,
+                                                                  int heads, int BH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R8 = SH ? NF * 16 - 8 : NF * 16, rmax = R8 - 1;
+    char* Ks = smem;
+    char* Vs = smem + R8 * 128;
+    int bh, half;
+    unit_of_block(blockIdx.x, bh, half);
+    if (bh >= BH) return;
+    const int b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const bf16_t* base = qkv + (size_t)b * L * ld + h * HD;
+    const bf16_t* dob = d_o + (size_t)b * L * E + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
+    const int qt = half * h0 + wave;
+    const bool active = qt < (half ? NFq : h0);
+
+    dma_tile<A2_NW>(base + E, ld, L, R8, Ks, wave, lane);
+    dma_tile<A2_NW>(base + 2 * E, ld, L, R8, Vs, wave, lane);
+    const int q = qt * 16 + col, qs = active ? q : 0;
+    bf16x8 qf[2], dof[2], of[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = gfrag<bf16_t>(base, ld, qs, L, ks, g);
+        dof[ks] = gfrag<bf16_t>(dob, E, qs, L, ks, g);
+        of[ks] = gfrag<bf16_t>(o_fwd + (size_t)b * L * E + h * HD, E, qs, L, ks, g);
+    }
+    const float lq2 = lse[((size_t)b * heads + h) * L + (qs < L ? qs : L - 1)] * A2_LOG2E;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)of[ks][e] * (float)dof[ks][e];
+    dl = group4_sum(dl);
+    if (g == 0 && q < L) delta[((size_t)b * heads + h) * L + q] = dl;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) dq[fd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NS = (NF + 1) / 2;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        bf16x8 df;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int f = 2 * st + hf;
+            if (f < NF) {
+                const int row = f * 16 + col;
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {-dl, -dl, -dl, -dl};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Ks + rm2(row, ks * 4 + g)), qf[ks], sa, 0, 0, 0);
+                    pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Vs + rm2(row, ks * 4 + g)), dof[ks], pa, 0, 0, 0);
+                }
+                if (f * 16 + 15 >= L) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (f * 16 + g * 4 + e >= L) sa[e] = -INFINITY;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) df[4 * hf + e] = (bf16_t)(__builtin_amdgcn_exp2f(fmaf(sa[e], A2_C, -lq2)) * pa[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) df[4 * hf + e] = (bf16_t)0.f;
+            }
+        }
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd)
+            dq[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<false>(Ks, st, fd, lane, rmax), df, dq[fd], 0, 0, 0);
+    }
+    if (q < L) {
+        bf16_t* drow = dqkv + ((size_t)b * L + q) * ld + h * HD;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            f32x4 v = dq[fd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= 0.125f;
+            Vec4<bf16_t>::store(drow + fd * 16 + g * 4, v);
+        }
+    }
+}
+
+// dK / dV: a wave owns a 16-key tile and sweeps the queries, the query on the MFMA row: S = Q K^T, dP = dO V^T (its
+// accumulator starts at -delta[q]), then dV^T += dO^T P and dK^T += Q^T dS with the transposed operands read from the
+// same row-major Q / dO tiles (ds_read_b64_tr_b16).  lse (times log2 e) and delta sit in LDS per query.
+template <int NF, bool SH>
+__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, int L, int heads, int BH) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R8 = SH ? NF * 16 - 8 : NF * 16, rmax = R8 - 1;
+    char* Qs = smem;
+    char* dOs = smem + R8 * 128;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);     // [NF * 16]
+    float* del_s = lse_s + NF * 16;
+    int bh, half;
+    unit_of_block(blockIdx.x, bh, half);
+    if (bh >= BH) return;
+    const int b = bh / heads, h = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const bf16_t* base = qkv + (size_t)b * L * ld + h * HD;
+    const bf16_t* dob = d_o + (size_t)b * L * E + h * HD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, g = lane >> 4;
+    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
+    const int kt = half * h0 + wave;
+    const bool active = kt < (half ? NFq : h0);
+
+    dma_tile<A2_NW>(base, ld, L, R8, Qs, wave, lane);
+    dma_tile<A2_NW>(dob, E, L, R8, dOs, wave, lane);
+    for (int i = tid; i < NF * 16; i += A2_NW * 64) {
+        const size_t o = ((size_t)b * heads + h) * L + i;
+        lse_s[i] = i < L ? lse[o] * A2_LOG2E : 0.f;
+        del_s[i] = i < L ? delta[o] : 0.f;
+    }
+    const int key = kt * 16 + col, kc = active ? key : 0;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = gfrag<bf16_t>(base + E, ld, kc, L, ks, g);
+        vf[ks] = gfrag<bf16_t>(base + 2 * E, ld, kc, L, ks, g);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+
+    f32x4 dv[4], dk[4];
+#pragma unroll
+    for (int fd = 0; fd < 4; ++fd) { dv[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    constexpr int NS = (NF + 1) / 2;
+    // one k-step = 32 queries (fragments 2 st, 2 st + 1).  The loop is NOT unrolled (unrolled, the compiler hoists the
+    // reads of several steps and the kernel leaves the 80 registers that three blocks per CU allow); the last step is
+    // peeled: it alone can touch rows beyond the tile or a phantom fragment.
+    auto step = [&](int st, auto LAST_) {
+        constexpr bool LAST = decltype(LAST_)::value;
+        bf16x8 pf, df;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int f = 2 * st + hf;
+            if (!LAST || f < NF) {
+                int row = f * 16 + col;
+                if constexpr (LAST) row = row < rmax ? row : rmax;
+                const int qb = f * 16 + g * 4;                    // this lane's 4 consecutive queries
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[qb]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[qb]);
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, pa = {-d4[0], -d4[1], -d4[2], -d4[3]};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Qs + rm2(row, ks * 4 + g)), kf[ks], sa, 0, 0, 0);
+                    pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(dOs + rm2(row, ks * 4 + g)), vf[ks], pa, 0, 0, 0);
+                }
+                if constexpr (LAST) {                             // queries beyond L contribute nothing
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (qb + e >= L) sa[e] = -INFINITY;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sa[e], A2_C, -l4[e]));
+                    pf[4 * hf + e] = (bf16_t)p;
+                    df[4 * hf + e] = (bf16_t)(p * pa[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pf[4 * hf + e] = (bf16_t)0.f; df[4 * hf + e] = (bf16_t)0.f; }
+            }
+        }
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LAST>(dOs, st, fd, lane, rmax), pf, dv[fd], 0, 0, 0);
+            dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LAST>(Qs, st, fd, lane, rmax), df, dk[fd], 0, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int st = 0; st < NS - 1; ++st) step(st, std::false_type{});
+    step(NS - 1, std::true_type{});
+    if (key < L) {
+        bf16_t* drow = dqkv + ((size_t)b * L + key) * ld + h * HD;
+#pragma unroll
+        for (int fd = 0; fd < 4; ++fd) {
+            f32x4 v = dk[fd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= 0.125f;
+            Vec4<bf16_t>::store(drow + E + fd * 16 + g * 4, v);
+            Vec4<bf16_t>::store(drow + 2 * E + fd * 16 + g * 4, dv[fd]);
+        }
+    }
+}
+
+template <int NF, bool SH>
+int run_bwd2s(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
+              int heads, hipStream_t s) {
+    constexpr int R8 = SH ? NF * 16 - 8 : NF * 16;
+    constexpr int lds_dq2 = 2 * NF * 16 * 128, lds_dkv2 = 2 * R8 * 128 + 2 * NF * 16 * 4;
+    const int BH = B * heads;
+    int e = set_lds(attn2_bwd_dq_kernel<NF, false>, lds_dq2);
+    if (e) return e;
+    e = set_lds(attn2_bwd_dkv_kernel<NF, SH>, lds_dkv2);
+    if (e) return e;
+    const dim3 grid(((BH + 7) / 8) * 16), block(A2_NW * 64);
+    hipLaunchKernelGGL((attn2_bwd_dq_kernel<NF, false>), grid, block, lds_dq2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       (const bf16_t*)out, (bf16_t*)dqkv, delta, L, heads, BH);
+    FFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NF, SH>), grid, block, lds_dkv2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+                       (const float*)delta, (bf16_t*)dqkv, L, heads, BH);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+template <int NF>
+int run_bwd2(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
+             int heads, hipStream_t s) {
+    return L <= NF * 16 - 8 ? run_bwd2s<NF, true>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s)
+                            : run_bwd2s<NF, false>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
 }
 
 // FFM_ATTN=v1: always the first-generation kernels (A/B runs)
@@ -795,6 +1046,16 @@ extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* d
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return FFM_EINVAL;
     const int nfp = (((L + 15) / 16) + 1) & ~1;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == FFM_BF16 && !causal && !attn_v1_forced()) {
+        switch ((L + 15) / 16) {
+            case 9: return run_bwd2<9>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+            case 10: return run_bwd2<10>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+            case 11: return run_bwd2<11>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+            case 12: return run_bwd2<12>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+            case 13: return run_bwd2<13>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+            case 14: return run_bwd2<14>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
+        }
+    }
     if (dtype == FFM_BF16) return dispatch_bwd<bf16_t>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
     if (dtype == FFM_F32) return dispatch_bwd<float>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
     return FFM_EINVAL;
