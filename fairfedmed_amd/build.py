@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
         special = stamps and src.startswith("gemm_panel")
         o = os.path.join(CSRC, src.replace(".hip", ".stamps.o" if special else ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s] + HEADERS) or (special and os.environ.get("FFM_STAMPS_DEFS")):
             extra = ["-DFFM_PANEL_STAMPS"] + os.environ.get("FFM_STAMPS_DEFS", "").split() if special else []
             jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 

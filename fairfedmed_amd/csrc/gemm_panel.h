@@ -8,9 +8,11 @@
 struct ffm_panel_cfg {
     int mf, nf;
     bool rankop;     // instantiated for the FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
+    int per_cu;      // blocks that share a CU (registers + LDS): a round is 256 * per_cu blocks
 };
-constexpr int FFM_PANEL_NCFG = 4;
-constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true}, {16, 4, false}, {10, 2, false}, {11, 2, true}};
+constexpr int FFM_PANEL_NCFG = 5;
+constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1}, {16, 4, false, 1}, {10, 2, false, 1}, {11, 2, true, 1},
+                                                          {8, 4, false, 2}};
 
 // -1: use the 128x128 kernel; otherwise the index into FFM_PANEL_CFGS
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);

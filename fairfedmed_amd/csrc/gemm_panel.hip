@@ -48,12 +48,15 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         if (N % bn || FFM_PANEL_CFGS[c].rankop != rk) continue;
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
-        if (!rk && FFM_PANEL_CFGS[c].nf >= 4 && K < 1536) continue;
+        const int per_cu = FFM_PANEL_CFGS[c].per_cu;
+        if (!rk && FFM_PANEL_CFGS[c].nf >= 4 && K < 1536 && per_cu == 1) continue;
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
-        // more than one round of one-block-per-CU tiles loses to the 128x128 kernel, whose two blocks per CU overlap
-        // one tile's epilogue with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
-        if (blocks > 256) continue;
-        const long cost = ((blocks + 255) / 256) * (bm + bn);
+        // more than one round of tiles loses to the 128x128 kernel, whose two blocks per CU overlap one tile's epilogue
+        // with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
+        if (blocks > 256 * per_cu) continue;
+        // (a two-per-CU tile that fills less than half of its slots is a one-per-CU tile with a worse shape)
+        if (per_cu > 1 && blocks <= 256) continue;
+        const long cost = (long)per_cu * (bm + bn);
         if (cost < best) { best = cost; pick = c; }
     }
     return pick;
@@ -69,6 +72,7 @@ int ffm_panel_ds_rows(int M, int N, int cfg) {
         switch (cfg) {                                                                     \
             case 1: return ffm_panel::launch_panel<16, 4, false, F>(a, s);                 \
             case 2: return ffm_panel::launch_panel<10, 2, false, F>(a, s);                 \
+            case 4: return ffm_panel::launch_panel<8, 4, false, F>(a, s);                  \
         }                                                                                  \
         return FFM_EINVAL;
 

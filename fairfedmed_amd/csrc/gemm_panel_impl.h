@@ -85,6 +85,11 @@ __device__ __forceinline__ void block_barrier() {
 #ifndef FFM_PANEL_STAGGER
 #define FFM_PANEL_STAGGER 0
 #endif
+// Diagnostic builds only (tools/panel_stamps.py): drop parts of the main loop to price them.  1: no weight-fragment
+// loads, 2: no LDS-DMA of the activation ring, 4: no MFMAs, 8: no LDS fragment reads (results are garbage).
+#ifndef FFM_PANEL_ABL
+#define FFM_PANEL_ABL 0
+#endif
 __device__ __forceinline__ void stagger(int wave) {
     if constexpr (FFM_PANEL_STAGGER > 0) {
         for (int q = 0; q < wave * FFM_PANEL_STAGGER; ++q) asm volatile("s_nop 7");
@@ -98,8 +103,13 @@ __host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk) {
     return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0);
 }
 
+// Two blocks per CU (two waves per SIMD) for the 128 x 256 plain tile: 128 accumulator registers and a 64 KiB ring
+// leave room for it, and the second wave issues MFMAs while the first sits in a VMEM / LDS issue slot.
+template <int MF, int NF, bool RK> constexpr int panel_waves_per_eu() { return (MF == 8 && NF == 4 && !RK) ? 2 : 1; }
+
 template <int MF, int NF, bool RK, int FL>
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_panel_kernel(ffm_gemm_args p) {
+__global__ __launch_bounds__(PT)
+__attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves_per_eu<MF, NF, RK>()))) void gemm_panel_kernel(ffm_gemm_args p) {
     using G = PanelGeom<MF, RK>;
     constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
@@ -177,6 +187,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto mma = [&](auto IDX_, f32x4& c, const frag_t& a, const frag_t& b) {
+        if constexpr ((FFM_PANEL_ABL & 4) != 0) return;
         if constexpr (decltype(IDX_)::value < 64)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
         else
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         constexpr int AD = NF >= 6 ? 2 : (NF >= 4 ? 3 : 5);
         const uint32_t sa = (uint32_t)(uintptr_t)st + (uint32_t)off;
         auto lds_read = [](frag_t& dst, uint32_t addr, auto OFF_) {
+            if constexpr ((FFM_PANEL_ABL & 8) != 0) return;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFF_)::value) : "memory");
         };
         frag_t a[AD + 1];
@@ -334,9 +346,9 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         half(W_, st, offA0, bq[2 * P], [&](auto J_) {
             constexpr int j = decltype(J_)::value;
             if constexpr (j < NF) {
-                if (!TAIL || rem >= 2) loadB1(2 * kt + 3, j, bq[(2 * P + 3) & 3][j]);
+                if (!(FFM_PANEL_ABL & 1) && (!TAIL || rem >= 2)) loadB1(2 * kt + 3, j, bq[(2 * P + 3) & 3][j]);
             } else if constexpr (j < NF + nA) {
-                if (!TAIL || rem >= 4) dma_piece(kt + 3, j - NF);
+                if (!(FFM_PANEL_ABL & 2) && (!TAIL || rem >= 4)) dma_piece(kt + 3, j - NF);
             }
         });
         fence();
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         half(W_, st, offA1, bq[2 * P + 1], [&](auto J_) {
             constexpr int j = decltype(J_)::value;
             if constexpr (j < NF) {
-                if (!TAIL || rem >= 3) loadB1(2 * kt + 4, j, bq[2 * P][j]);
+                if (!(FFM_PANEL_ABL & 1) && (!TAIL || rem >= 3)) loadB1(2 * kt + 4, j, bq[2 * P][j]);
             }
         });
         fence();
