@@ -75,6 +75,8 @@ SIGNATURES = {
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "ffm_eval_counts_ws_bytes": [_i32],
+    "ffm_eval_counts_sorted": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp],
     "ffm_ot_head_fwd": [_vp] * 10 + [_i32] * 6 + [_f32, _f32, _i32, _f32, _i32, _vp],
     "ffm_ot_head_bwd": [_vp] * 8 + [_i32] * 6 + [_vp],
     "ffm_expand_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -116,7 +118,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith("_ws_bytes") else C.c_int
     v = lib.ffm_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libffm_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")

@@ -380,15 +380,31 @@ def expand_u8(src: Tensor, dst: Tensor, rep: int) -> Tensor:
 EVAL_SLOTS = 10
 
 
-def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups: int) -> Tensor:
-    """Integer counts behind every score of the binary-task evaluator (ffm_eval_counts): int64 [(G + 2), 10] on the
-    device (rows: groups 0..G-1, unknown, all)."""
+EVAL_SORT_FROM = 32768      # samples from which the O(N log N) evaluator replaces the all-pairs kernel
+
+
+def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups: int, method: str = "auto") -> Tensor:
+    """Integer counts behind every score of the binary-task evaluator: int64 [(G + 2), 10] on the device (rows: groups
+    0..G-1, unknown, all).  method: 'pairs' (ffm_eval_counts, all pairs), 'sort' (ffm_eval_counts_sorted, for large test
+    sets), 'auto' (by N); the two give identical integers."""
     _dev(prob, label, attr)
     N = prob.shape[0]
     assert prob.dtype == torch.float32 and prob.dim() == 2 and prob.shape[1] == 2 and prob.is_contiguous()
     assert label.dtype == torch.int64 and label.is_contiguous() and label.numel() == N
     assert attr is None or (attr.dtype == torch.int64 and attr.is_contiguous() and attr.numel() == N)
+    assert method in ("auto", "pairs", "sort")
     out = torch.empty(num_groups + 2, EVAL_SLOTS, device=prob.device, dtype=torch.int64)
+    if method == "sort" or (method == "auto" and N >= EVAL_SORT_FROM):
+        nbytes = int(L.load().ffm_eval_counts_ws_bytes(N))
+        if nbytes <= 0:
+            raise RuntimeError("ffm_eval_counts_ws_bytes failed")
+        ws = torch.empty(nbytes + 256, device=prob.device, dtype=torch.uint8)      # device memory is PyTorch's job
+        off = (-ws.data_ptr()) % 256
+        _call("ffm_eval_counts_sorted", L.ptr(prob), L.ptr(label), L.ptr(attr), N, num_groups, L.ptr(out),
+              ws.data_ptr() + off, nbytes, L.stream_ptr())
+        if recording():
+            raise RuntimeError("eval_counts(method='sort') holds a temporary workspace and cannot be recorded")
+        return out
     _call("ffm_eval_counts", L.ptr(prob), L.ptr(label), L.ptr(attr), N, num_groups, L.ptr(out), L.stream_ptr())
     return out
 

@@ -44,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide, ffm_pack_desc.dst_wide; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -343,6 +343,14 @@ int ffm_expand_u8(const uint8_t* src, float* dst, int B, int C1, int HW, int rep
 #define FFM_EVAL_SLOTS 10
 int ffm_eval_counts(const float* prob, const int64_t* label, const int64_t* attr, int N, int G, uint64_t* out,
                     void* stream);
+/*
+ * The same table for large test sets in O(N log N) (sort by score, prefix counts of the negatives; csrc/evalsort.hip):
+ * bit-identical to ffm_eval_counts, which compares all pairs (N^2 / 2: 100 x slower at 200 k samples).  workspace: a
+ * 256-byte aligned device buffer of at least ffm_eval_counts_ws_bytes(N) bytes (the library allocates nothing).
+ */
+int64_t ffm_eval_counts_ws_bytes(int N);
+int ffm_eval_counts_sorted(const float* prob, const int64_t* label, const int64_t* attr, int N, int G, uint64_t* out,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Logits heads with a transport plan, TRAINER.GLP_OT.OT = 'Sinkhorn' (mode 1) / 'COT' (mode 2)

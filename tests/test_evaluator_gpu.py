@@ -70,3 +70,43 @@ def test_trainer_test_device_and_host_metrics_agree():
         assert np.allclose(dev_full[k], host_full[k], rtol=0, atol=1e-12), k
     for a, b in zip(dev_full["aucs_by_attrs"], host_full["aucs_by_attrs"]):
         assert np.allclose(a, b, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,G,unknown,ties", [(1, 2, 0, True), (37, 3, 0, True), (256, 2, 5, True), (1000, 3, 11, True),
+                                              (4099, 8, 0, True), (20000, 3, 7, False), (20000, 2, 0, True)])
+def test_eval_counts_sorted_equals_pairs(N, G, unknown, ties):
+    """ffm_eval_counts_sorted (O(N log N): sort by score, prefix counts of the negatives, two binary searches per
+    positive) gives the integers of the all-pairs kernel, ties and the 'unknown' group included; and of the brute force."""
+    from fairfedmed_amd import ops
+    prob, y, a = make(N, G, seed=N + G, ties=ties, unknown=unknown)
+    args = (torch.from_numpy(prob).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(a).cuda(), G)
+    pairs = ops.eval_counts(*args, method="pairs").cpu().numpy()
+    srt = ops.eval_counts(*args, method="sort").cpu().numpy()
+    assert np.array_equal(srt, pairs)
+    if N <= 4099:
+        assert np.array_equal(srt, _brute_counts(prob, y, a, G))
+    no_attr = ops.eval_counts(args[0], args[1], None, G, method="sort").cpu().numpy()
+    assert np.array_equal(no_attr[-1], srt[-1]) and np.array_equal(no_attr[-2], no_attr[-1]) and not no_attr[:-2].any()
+
+
+def test_eval_counts_200k_samples_sorted():
+    """A CheXpert-sized test set: 2 * 10^5 samples = 2 * 10^10 score pairs.  The sorted evaluator's AUC
+    equals the host's mid-rank AUC; 'auto' picks it from 32768 samples on."""
+    import time
+    from fairfedmed_amd import ops
+    prob, y, a = make(200000, 3, seed=5, ties=False)
+    args = (torch.from_numpy(prob).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(a).cuda(), 3)
+    ops.eval_counts(*args)                                                  # warm-up (workspace query, code load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t = ops.eval_counts(*args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = t.cpu().numpy()
+    assert abs(M.basic_from_counts(t)[3] - 100.0 * M.auc_macro_ovr(prob, y)) < 1e-9
+    ga = M.group_aucs(prob, y, a)
+    for g in range(3):
+        assert abs(M._auc_from_row(t[g]) - ga[g]) < 1e-12
+    assert t[-1, 0] + t[-1, 1] == 200000
+    print(f"200k-sample evaluator: {dt * 1e3:.2f} ms")
+    assert dt < 0.05

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ffm_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(ffm_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\bint(?:64_t)?\s+(ffm_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no prototypes parsed"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
