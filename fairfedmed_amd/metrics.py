@@ -9,9 +9,11 @@ The last two come from a third-party package that is absent from the build image
 pins no version; the definitions below are those of fairlearn 0.7-0.10, ``fairlearn.metrics``:
 ``demographic_parity_difference`` = max - min over groups of the selection rate P(y_hat = 1 | g);
 ``equalized_odds_difference`` = the larger of the max - min gaps of the true-positive and false-positive rates).
-They are restated from the published definition and are NOT pinned against the reference (parity unpinned);
-AUC, per-group AUC, ES-AUC and the disparity ratios are pinned against the imported reference functions
-(tests/golden/make_golden.py, ``fair.*``)."""
+They are restated from the published definition; with the package absent they cannot be pinned against the reference's
+own call, so they are pinned against values derived BY HAND from that definition
+(tests/test_host_cpu.py::test_dpd_eod_against_hand_derived_fairlearn_values: several groups, the -1 "unknown" value as
+a group, empty-denominator rates, the single-group case).  AUC, per-group AUC, ES-AUC and the disparity ratios are
+pinned against the imported reference functions (tests/golden/make_golden.py, ``fair.*``)."""
 from __future__ import annotations
 
 import numpy as np

@@ -224,6 +224,60 @@ def test_scores_from_counts_equal_the_sort_based_scores():
     assert abs(res[2] - 100.0 * 2 * tp / (2 * tp + fn)) < 1e-12
 
 
+def test_dpd_eod_against_hand_derived_fairlearn_values():
+    """fairlearn is not installable here, so demographic_parity_difference / equalized_odds_difference
+    (evaluation/metrics.py:256-279 calls them with sensitive_features = the attribute column, -1 included) are pinned
+    against values worked out BY HAND from the package's published definitions:
+
+      selection rate  SR_g  = P(y_hat = 1 | group g)
+      DPD                   = max_g SR_g - min_g SR_g
+      TPR_g = P(y_hat = 1 | y = 1, g),  FPR_g = P(y_hat = 1 | y = 0, g)   (0 when the group has no such sample:
+                              recall_score's zero_division convention, which fairlearn's rates inherit)
+      EOD                   = max(max_g TPR_g - min_g TPR_g, max_g FPR_g - min_g FPR_g)
+
+    for the host functions AND for the scores derived from the device evaluator's count table."""
+    from fairfedmed_amd import metrics as M
+
+    def table_scores(y, pred, attr, G=4):
+        prob = np.stack([1.0 - pred, pred.astype(np.float64)], 1).astype(np.float32)     # argmax reproduces pred
+        out = M.comprehensive_scores_from_counts([_brute_counts(prob, y, attr, G)])
+        return out["dpds"][0], out["eods"][0]
+
+    # --- case 1: two groups
+    #   g0: y_hat 1 1 0 0 | y 1 0 1 0  -> SR 2/4, TPR 1/2, FPR 1/2
+    #   g1: y_hat 1 0 0 0 0 | y 1 1 0 0 0 -> SR 1/5, TPR 1/2, FPR 0/3
+    pred = np.array([1, 1, 0, 0, 1, 0, 0, 0, 0])
+    y = np.array([1, 0, 1, 0, 1, 1, 0, 0, 0])
+    a = np.array([0, 0, 0, 0, 1, 1, 1, 1, 1])
+    for dpd, eod in ((M.demographic_parity_difference(y, pred, a), M.equalized_odds_difference(y, pred, a)),
+                     table_scores(y, pred, a)):
+        assert abs(dpd - (2 / 4 - 1 / 5)) < 1e-12                   # 0.3
+        assert abs(eod - max(1 / 2 - 1 / 2, 1 / 2 - 0.0)) < 1e-12   # FPR gap 0.5
+    # --- case 2: three groups, one of them the "unknown" value -1 (a group like any other for fairlearn)
+    #   g-1: y_hat 1 1 1 | y 1 1 0     -> SR 3/3, TPR 2/2, FPR 1/1
+    #   g0 : y_hat 0 0 1 0 | y 1 0 0 0 -> SR 1/4, TPR 0/1, FPR 1/3
+    #   g2 : y_hat 1 0 | y 1 1         -> SR 1/2, TPR 1/2, FPR 0 (no negatives)
+    pred = np.array([1, 1, 1, 0, 0, 1, 0, 1, 0])
+    y = np.array([1, 1, 0, 1, 0, 0, 0, 1, 1])
+    a = np.array([-1, -1, -1, 0, 0, 0, 0, 2, 2])
+    for dpd, eod in ((M.demographic_parity_difference(y, pred, a), M.equalized_odds_difference(y, pred, a)),
+                     table_scores(y, pred, a)):
+        assert abs(dpd - (1.0 - 1 / 4)) < 1e-12                     # 0.75
+        assert abs(eod - max(1.0 - 0.0, 1.0 - 0.0)) < 1e-12         # TPR gap 1 - 0, FPR gap 1 - 0
+    # --- case 3: perfectly fair predictor with unequal base rates: equal rates in every group -> both 0
+    #   g0: y_hat 1 0 1 0 | y 1 1 0 0 ; g1: y_hat 1 0 1 0 1 0 1 0 | y 1 1 0 0 1 1 0 0  -> SR 1/2, TPR 1/2, FPR 1/2
+    pred = np.array([1, 0, 1, 0] + [1, 0, 1, 0, 1, 0, 1, 0])
+    y = np.array([1, 1, 0, 0] + [1, 1, 0, 0, 1, 1, 0, 0])
+    a = np.array([0] * 4 + [1] * 8)
+    for dpd, eod in ((M.demographic_parity_difference(y, pred, a), M.equalized_odds_difference(y, pred, a)),
+                     table_scores(y, pred, a)):
+        assert dpd == 0.0 and eod == 0.0
+    # --- case 4: one group only -> both differences are 0 by definition (max = min)
+    a = np.zeros(12, dtype=np.int64)
+    assert M.demographic_parity_difference(y, pred, a) == 0.0 and M.equalized_odds_difference(y, pred, a) == 0.0
+    assert table_scores(y, pred, a) == (0.0, 0.0)
+
+
 def test_cli_flags_config_tree_and_scope(tmp_path):
     """fairfedmed_amd.federated_main: the reference's flag names (federated_main.py:791-881), its type=bool quirk
     (any non-empty value is True), config-file merge order, and the scope guard."""
