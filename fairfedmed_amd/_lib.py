@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm
 
 F32, BF16, F32_X3 = 0, 1, 2
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
+EPI_ROWSTATS, EPI_LNIN = 128, 256
 ABI_VERSION = 6
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -32,6 +33,7 @@ class GemmArgs(C.Structure):
         ("rk", _vp), ("S", _vp), ("attr", _vp), ("t_out", _vp), ("ts_out", _vp), ("t_fwd", _vp), ("ds_part", _vp),
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
         ("b_packed", _vp), ("lw_wide", _vp),
+        ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("pad1_", _i32),
     ]
 
 
@@ -50,12 +52,13 @@ SIGNATURES = {
     "ffm_abi_version": [],
     "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
     "ffm_gemm_tiles_m": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "ffm_gemm_tiles_n": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_pack_b": [_vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_multi": [_vp, _i32, _i32, _i32, _vp],
     "ffm_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _i32, _vp],
-    "ffm_embed_lnpre": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "ffm_embed_lnpre": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_slice_blocks": [_i32, _i32],
     "ffm_slice_bwd_ab_blocks": [],
     "ffm_slice_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

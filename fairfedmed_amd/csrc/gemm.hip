@@ -590,6 +590,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         if (!off || dtype == FFM_F32_X3) return ffm_skinny_launch(a, dtype, s);
     }
     if (dtype == FFM_F32_X3) return FFM_EUNSUP;                           // split-operand products: skinny shapes only
+    if (a.flags & (FFM_EPI_ROWSTATS | FFM_EPI_LNIN)) {                    // LayerNorm folding: the panel kernel only
+        const int cfgl = a.b_packed ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
+        return cfgl >= 0 ? ffm_panel_launch(a, cfgl, s) : FFM_EUNSUP;
+    }
     if (a.b_packed) {
         const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);
@@ -686,6 +690,13 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
 extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {
     const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
     return cfg >= 0 ? ffm_panel_ds_rows(M, N, cfg) : (M + BM - 1) / BM;
+}
+
+extern "C" int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dtype, int packed) {
+    const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
+    if (cfg >= 0) return ffm_panel_tiles_n(N, cfg);
+    if (flags & (FFM_EPI_ROWSTATS | FFM_EPI_LNIN)) return FFM_EUNSUP;
+    return (N + BN - 1) / BN;
 }
 
 extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream) {

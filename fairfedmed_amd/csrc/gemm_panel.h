@@ -18,6 +18,7 @@ constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1}, {16,
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);
 // rows of dS partials the chosen kernel writes (tiles_m x tiles_n: every block owns a slice of its tile row)
 int ffm_panel_ds_rows(int M, int N, int cfg);
+int ffm_panel_tiles_n(int N, int cfg);      // column tiles (rows of rowstat_part under FFM_EPI_ROWSTATS)
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s);
 int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s);      // gemm_panel_rk.hip
 

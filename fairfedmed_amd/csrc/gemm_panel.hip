@@ -18,9 +18,24 @@ __global__ __launch_bounds__(256) void pack_b_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// plain epilogues the panel kernel is instantiated for (PANEL_CASE below)
+bool plain_flags_ok(int flags) {
+    switch (flags) {
+        case 0:
+        case FFM_EPI_BIAS:
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL:
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS:      // out-proj forward leaving row sums for ln_2
+        case FFM_EPI_BIAS | FFM_EPI_LNIN: return true;                 // qkv forward with ln_1 folded in
+    }
+    return false;
+}
+
 bool rk_flags_ok(int flags, int rank) {
     if (rank <= 0 || rank > 16) return false;
-    switch (flags & ~FFM_EPI_RANKOP) {
+    if (flags & FFM_EPI_LNIN) return false;
+    if ((flags & FFM_EPI_ROWSTATS) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL))
+        return false;                                          // row sums: the c_proj forward epilogue only
+    switch (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) {
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU:
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL:
         case FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU:
@@ -36,7 +51,7 @@ bool rk_flags_ok(int flags, int rank) {
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed) {
     if (!packed || dtype != FFM_BF16 || K % 128 != 0 || K < 512) return -1;
     const bool rk = (flags & FFM_EPI_RANKOP) != 0;
-    if (rk ? !rk_flags_ok(flags, rank) : (flags & ~(FFM_EPI_BIAS | FFM_EPI_RESIDUAL)) != 0) return -1;
+    if (rk ? !rk_flags_ok(flags, rank) : !plain_flags_ok(flags)) return -1;
     if (const char* f = getenv("FFM_PANEL")) {               // FFM_PANEL=off: always the 128x128 kernel (A/B runs)
         if (f[0] == 'o' || f[0] == '0') return -1;
     }
@@ -46,6 +61,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
     for (int c = 0; c < FFM_PANEL_NCFG; ++c) {
         const int bm = 16 * FFM_PANEL_CFGS[c].mf, bn = 64 * FFM_PANEL_CFGS[c].nf;
         if (N % bn || FFM_PANEL_CFGS[c].rankop != rk) continue;
+        if ((flags & FFM_EPI_ROWSTATS) && (FFM_PANEL_CFGS[c].nf & (FFM_PANEL_CFGS[c].nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
         const int per_cu = FFM_PANEL_CFGS[c].per_cu;
@@ -67,6 +83,8 @@ int ffm_panel_ds_rows(int M, int N, int cfg) {
     return ((M + bm - 1) / bm) * (N / bn);
 }
 
+int ffm_panel_tiles_n(int N, int cfg) { return N / (64 * FFM_PANEL_CFGS[cfg].nf); }
+
 #define PANEL_CASE(F)                                                                      \
     case F:                                                                                \
         switch (cfg) {                                                                     \
@@ -78,11 +96,15 @@ int ffm_panel_ds_rows(int M, int N, int cfg) {
 
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s) {
     if (((uintptr_t)a.b_packed & 15) || a.ldc % 8) return FFM_EINVAL;
+    if ((a.flags & FFM_EPI_ROWSTATS) && !a.rowstat_part) return FFM_EINVAL;
+    if ((a.flags & FFM_EPI_LNIN) && (!a.ln_part || !a.ln_c || a.ln_np <= 0 || !a.bias)) return FFM_EINVAL;
     if (a.flags & FFM_EPI_RANKOP) return ffm_panel_launch_rk(a, cfg, s);
     switch (a.flags) {
         PANEL_CASE(0)
         PANEL_CASE(FFM_EPI_BIAS)
         PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_RESIDUAL)
+        PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS)
+        PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_LNIN)
     }
     return FFM_EINVAL;
 }

@@ -99,8 +99,9 @@ __device__ __forceinline__ void stagger(int wave) {
 __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }                // floats
 // persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
 // f32 | row groups [BM]
-__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk) {
-    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0);
+// | (LNIN) c [BN] f32, row mean / rstd [BM] f32 each
+__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false) {
+    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? PW * 16 * nf * 4 + 2 * 16 * mf * 4 : 0);
 }
 
 // Two blocks per CU (two waves per SIMD) for the 128 x 256 plain tile: 128 accumulator registers and a 64 KiB ring
@@ -114,6 +115,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
     static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
+    static_assert(!(RK && (flags & FFM_EPI_LNIN)), "LayerNorm folding in front of a RANKOP product is not built yet");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -271,8 +273,36 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
     float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
     int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
+    constexpr bool LNIN = (flags & FFM_EPI_LNIN) != 0, ROWST = (flags & FFM_EPI_ROWSTATS) != 0;
+    float* Cv = reinterpret_cast<float*>(smem + G::RING + persist_bytes(MF, NF, RK));     // LNIN: c [BN]
+    float* Mu = Cv + BNp;                                     // row means [BM]
+    float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
     const int r = RK ? p.rank : 0;
     for (int i = tid; i < BNp; i += PT) Bias[i] = (flags & FFM_EPI_BIAS) ? p.bias[n0 + i] : 0.f;
+    if constexpr (LNIN) {
+        // LayerNorm statistics of this tile's A rows from the producer's partial row sums (fixed order over the
+        // partials: deterministic); E[x^2] - mu^2 in f32 is exact enough for K <= 4096 activations of O(1..100)
+        for (int i = tid; i < BNp; i += PT) Cv[i] = p.ln_c[n0 + i];
+        for (int i = tid; i < BMp; i += PT) {
+            const int gm = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
+            float su = 0.f, sq = 0.f;
+            for (int q = 0; q < p.ln_np; ++q) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(p.ln_part + ((size_t)q * p.M + gm) * 2);
+                su += v[0];
+                sq += v[1];
+            }
+            const float mu = su / (float)p.K;
+            float var = sq / (float)p.K - mu * mu;
+            var = var > 0.f ? var : 0.f;
+            const float rs = 1.0f / sqrtf(var + 1e-5f);
+            Mu[i] = mu;
+            Rs[i] = rs;
+            if (tn == 0 && m0 + i < p.M) {
+                if (p.ln_mean) p.ln_mean[gm] = mu;
+                if (p.ln_rstd) p.ln_rstd[gm] = rs;
+            }
+        }
+    }
     if constexpr (RK) {
         if (p.lw_wide) {
             // the tile [BN][32] of the pre-packed LoRA matrix (ffm_lora_pack_multi, dst_wide) is one contiguous
@@ -404,6 +434,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
     float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + wave * (32 * PITCH);
+    // ROWSTATS: per-wave partial row sums [PW][BM][2] behind the four waves' output stages
+    float* RowP = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + PW * (32 * PITCH);
+    static_assert((CPR & (CPR - 1)) == 0 || !(FL & FFM_EPI_ROWSTATS), "row sums: the lanes of a row form a power-of-two group");
     bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
 
     // residual / pre-activation rows of the first row groups: issued now, consumed after the rank-r update
@@ -603,8 +636,21 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8 + 4]);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8]);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8 + 4]);
+            if constexpr (LNIN) {
+                // rstd (x W'^T - mu c) + d: the rows went through the matrix cores un-normalised
+                const int trow = rg * 32 + row < BMp ? rg * 32 + row : BMp - 1;
+                const float mu = Mu[trow], rs = Rs[trow];
+                const f32x4 cv0 = *reinterpret_cast<const f32x4*>(&Cv[wave * WN + ch * 8]);
+                const f32x4 cv1 = *reinterpret_cast<const f32x4*>(&Cv[wave * WN + ch * 8 + 4]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] = c0[c] + b0[c]; v[4 + c] = c1[c] + b1[c]; }
+                for (int c = 0; c < 4; ++c) {
+                    v[c] = rs * (c0[c] - mu * cv0[c]) + b0[c];
+                    v[4 + c] = rs * (c1[c] - mu * cv1[c]) + b1[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v[c] = c0[c] + b0[c]; v[4 + c] = c1[c] + b1[c]; }
+            }
             if constexpr (PRE) {
                 if constexpr (rg < PF) {
                     // issued before the rank-r update: one drain in front of the first use covers the first PF groups
@@ -639,6 +685,25 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] *= Act<bf16_t>::gelu_grad((float)rpre[rg % PF][i][c]);
             }
+            if constexpr (ROWST) {
+                // partial LayerNorm sums of the row AS STORED (bf16): the lanes of a row are adjacent (CPR of them)
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float x = (float)(bf16_t)v[c];
+                    su += x;
+                    sq += x * x;
+                }
+#pragma unroll
+                for (int o = 1; o < CPR; o <<= 1) {
+                    su += __shfl_xor(su, o, 64);
+                    sq += __shfl_xor(sq, o, 64);
+                }
+                if (ch == 0 && rg * 32 + row < BMp) {
+                    RowP[(wave * BMp + rg * 32 + row) * 2] = su;
+                    RowP[(wave * BMp + rg * 32 + row) * 2 + 1] = sq;
+                }
+            }
             if (ok) {
                 const size_t off = (size_t)gm * p.ldc + n0w + ch * 8;
                 Vec8<bf16_t>::store(C + off, v);
@@ -655,6 +720,21 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         }
         fence();
     });
+    if constexpr (ROWST) {
+        __syncthreads();
+        for (int i = tid; i < BMp; i += PT) {
+            if (m0 + i < p.M) {
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < PW; ++w) {
+                    su += RowP[(w * BMp + i) * 2];
+                    sq += RowP[(w * BMp + i) * 2 + 1];
+                }
+                f32x2 o = {su, sq};
+                *reinterpret_cast<f32x2*>(p.rowstat_part + ((size_t)tn * p.M + m0 + i) * 2) = o;
+            }
+        }
+    }
     FFM_STAMP(4);
 #ifdef FFM_PANEL_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // 5: this wave's output stores have been acknowledged
@@ -666,9 +746,10 @@ template <int MF, int NF, bool RK, int FL>
 int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
     using G = PanelGeom<MF, RK>;
     const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (PW * 16 * NF));
-    constexpr int lds = G::RING + persist_bytes(MF, NF, RK);
+    constexpr int lds = G::RING + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert(!RK || 16 * MF * 192 + PW * 32 * stage_pitch(NF) * 4 <= G::RING, "epilogue tiles alias the ring");
+    static_assert((RK ? 16 * MF * 192 : 0) + PW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? PW * 16 * MF * 8 : 0) <= G::RING,
+                  "epilogue tiles alias the ring");
     static bool done = false;                         // one per instantiation
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL>),

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ patch, const T* __restrict__ cls,
                                                           const T* __restrict__ pos, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, T* __restrict__ x, int B,
-                                                          int L, int width) {
+                                                          const float* __restrict__ beta, T* __restrict__ x,
+                                                          float* __restrict__ rowstat, int B, int L, int width) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + 1e-5f);
     T* xr = x + (size_t)row * width;
+    float so = 0.f, qo = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
@@ -197,9 +198,19 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
             const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c * 4);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+                const float st = Elem<T>::to_f(Elem<T>::from_f(o[e]));       // the row as stored
+                so += st;
+                qo += st * st;
+            }
             Vec4<T>::store(xr + c * 4, o);
         }
+    }
+    if (rowstat) {          // {sum, sum of squares} of the OUTPUT row: the first block's ln_1 folded into its qkv GEMM
+        so = wave_sum(so);
+        qo = wave_sum(qo);
+        if (lane == 0) { rowstat[2 * (size_t)row] = so; rowstat[2 * (size_t)row + 1] = qo; }
     }
 }
 
@@ -266,16 +277,16 @@ extern "C" int ffm_patchify(const float* img, void* cols, int B, int H, int W, i
 }
 
 extern "C" int ffm_embed_lnpre(const void* patch, const void* cls, const void* pos, const float* gamma,
-                               const float* beta, void* x, int B, int L, int width, int dtype, void* stream) {
+                               const float* beta, void* x, float* rowstat, int B, int L, int width, int dtype, void* stream) {
     if (!patch || !cls || !pos || !gamma || !beta || !x || B <= 0 || L <= 1 || bad_width(width)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((B * L + 3) / 4), block(256);
     if (dtype == FFM_BF16)
         hipLaunchKernelGGL((embed_lnpre_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)patch, (const bf16_t*)cls,
-                           (const bf16_t*)pos, gamma, beta, (bf16_t*)x, B, L, width);
+                           (const bf16_t*)pos, gamma, beta, (bf16_t*)x, rowstat, B, L, width);
     else if (dtype == FFM_F32)
         hipLaunchKernelGGL((embed_lnpre_kernel<float>), grid, block, 0, s, (const float*)patch, (const float*)cls,
-                           (const float*)pos, gamma, beta, (float*)x, B, L, width);
+                           (const float*)pos, gamma, beta, (float*)x, rowstat, B, L, width);
     else
         return FFM_EINVAL;
     FFM_CHECK_LAUNCH();

@@ -147,7 +147,7 @@ def _ds_rows(rows: int, N: int, K: int, rank: int, dtype, packed: Optional[bool]
     return ops.gemm_tiles_m(rows, N, K, fl, rank, dtype, packed)
 
 
-_PACKED = ("w_in", "w_in_t", "w_out", "w_out_t", "w_fc", "w_fc_t", "w_proj", "w_proj_t")
+_PACKED = ("w_in", "w_in_t", "w_out", "w_out_t", "w_fc", "w_fc_t", "w_proj", "w_proj_t", "w_in_ln")
 
 
 @dataclass
@@ -171,6 +171,11 @@ class _Block:
     b_proj: Tensor
     lora: Optional[Dict[str, str]] = None      # role -> flat key, vision blocks only
     packed: Optional[Dict[str, Tensor]] = None # bf16 vision blocks: the eight weights in MFMA-fragment order (ops.pack_b)
+    # bf16 vision blocks, ln_1 folded into the qkv product (FFM_EPI_LNIN): gamma-scaled in_proj weight, its row sums c
+    # and d = W beta + b (frozen: built once at load time)
+    w_in_ln: Optional[Tensor] = None
+    c_in: Optional[Tensor] = None
+    d_in: Optional[Tensor] = None
 
     def pk(self, name: str) -> Optional[Tensor]:
         return self.packed[name] if self.packed else None
@@ -202,6 +207,10 @@ class _Stack:
         self.h2 = [e(T, w) for _ in range(layers)]
         self.pre = [e(T, 4 * w) for _ in range(layers)]
         self.act = [e(T, 4 * w) for _ in range(layers)]
+        # partial row sums {sum, sum of squares} of every block input, left behind by its producer (FFM_EPI_ROWSTATS /
+        # embed_lnpre) for the ln_1 that is folded into the qkv product: up to 8 column tiles
+        self.rowp = [f(8 * T * 2) for _ in range(layers + 1)] if (rank and dtype == torch.bfloat16) else None
+        self.fold = {}                                       # rows -> (np of the c_proj forward, ok) decision cache
         if rank:
             self.t1 = [f(T, rank) for _ in range(layers)]
             self.ts1 = [f(T, rank) for _ in range(layers)]
@@ -399,6 +408,12 @@ class FairLoRAEngine:
                 w_proj=W(sd[p + pj + "weight"]), w_proj_t=WT(sd[p + pj + "weight"]),
                 b_proj=self._f(sd[p + pj + "bias"]),
             )
+            if lora and stack.dtype == torch.bfloat16:
+                w32 = sd[p + "attn.in_proj_weight"].to(self.device, torch.float32)
+                g1, b1 = blk.ln1_w, blk.ln1_b
+                blk.w_in_ln = W(w32 * g1[None, :])
+                blk.c_in = blk.w_in_ln.float().sum(1).contiguous()        # row sums of the weight AS ROUNDED
+                blk.d_in = (w32 @ b1 + blk.b_in).contiguous()
             if lora:
                 blk.lora = {f"{n}_{m}": f"{p}mlp.c_{n}.lora_{m}.weight" for n in ("fc", "proj") for m in "ASB"}
             if old is not None:
@@ -462,6 +477,20 @@ class FairLoRAEngine:
     def _dS(self, layer: int, which: str) -> Tensor:
         return self.sops.grad(f"image_encoder.transformer.resblocks.{layer}.mlp.c_{which}.")
 
+    def _fold_ln1(self, st: _Stack, rows: int) -> int:
+        """0: ln_1 runs as its own kernel.  Otherwise the number of partial row sums the c_proj forward of this row
+        count leaves per row (its column tiles): both that product and the qkv product are served by the panel kernel
+        with the folding epilogues (bf16, fused rank, frozen weights packed)."""
+        if st.rowp is None or not getattr(self, "fused_rank", False) or getattr(self, "no_ln_fold", False):
+            return 0
+        if rows not in st.fold:
+            w, r = st.width, st.rank
+            f_proj = L.EPI_BIAS | L.EPI_LORA | L.EPI_RESIDUAL | L.EPI_RANKOP | L.EPI_ROWSTATS
+            npj = ops.gemm_tiles_n(rows, w, 4 * w, f_proj, r, st.dtype, True)
+            nq = ops.gemm_tiles_n(rows, 3 * w, w, L.EPI_BIAS | L.EPI_LNIN, 0, st.dtype, True)
+            st.fold[rows] = npj if (npj > 0 and npj <= 8 and nq > 0) else 0
+        return st.fold[rows]
+
     def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
                        save: bool = True) -> Tensor:
         """x[0][:rows] holds the tower input; returns the tower output view."""
@@ -473,8 +502,15 @@ class FairLoRAEngine:
             qkv, o, h2 = st.qkv[i][:rows], st.o[i][:rows], st.h2[i][:rows]
             pre, act = st.pre[i][:rows], st.act[i][:rows]
             h = st.h[:rows]
-            ops.layernorm_fwd(x, h, blk.ln1_w, blk.ln1_b, st.st1[i][0], st.st1[i][1])
-            gemm(h, blk.w_in, qkv, bias=blk.b_in, b_packed=blk.pk("w_in"))
+            fold = self._fold_ln1(st, rows)
+            if fold:
+                # ln_1 rides inside the qkv product: raw rows x gamma-scaled weight, normalised in the epilogue with the
+                # row sums the producer of x left behind (block 0: embed_lnpre, else the previous block's c_proj)
+                ln = ops.LnIn(st.rowp[i], 1 if i == 0 else fold, blk.c_in, st.st1[i][0], st.st1[i][1])
+                gemm(x, blk.w_in_ln, qkv, bias=blk.d_in, b_packed=blk.pk("w_in_ln"), ln_in=ln)
+            else:
+                ops.layernorm_fwd(x, h, blk.ln1_w, blk.ln1_b, st.st1[i][0], st.st1[i][1])
+                gemm(h, blk.w_in, qkv, bias=blk.b_in, b_packed=blk.pk("w_in"))
             ops.attention_fwd(qkv, o, st.lse[i], images, st.L, st.heads, st.causal)
             gemm(o, blk.w_out, xm, bias=blk.b_out, res=x, b_packed=blk.pk("w_out"))
             ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
@@ -487,7 +523,8 @@ class FairLoRAEngine:
                                 lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i],
                                 lw_wide=self.lw_wide[i].get("proj_B"))
                 gemm(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
-                            res=xm, rankop=ro, b_packed=blk.pk("w_proj"))
+                            res=xm, rankop=ro, b_packed=blk.pk("w_proj"),
+                            rowstats=st.rowp[i + 1] if (fold and i + 1 < st.layers) else None)
             elif r:
                 ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._S(i, "fc"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
@@ -757,7 +794,7 @@ class FairLoRAEngine:
             self._glue(self.sops.prepare)             # S_eff = S + S_global
         ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
-                        self.vis.x[0][:rows], images, L)
+                        self.vis.x[0][:rows], images, L, rowstat=self.vis.rowp[0] if self.vis.rowp is not None else None)
         out = self._stack_forward(self.vis, rows, images, a32, L * S)
         ops.layernorm_fwd(out, self.hpost[:rows], self.lnpost[0], self.lnpost[1], self.post_stats[0],
                           self.post_stats[1])

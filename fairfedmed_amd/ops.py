@@ -104,6 +104,21 @@ def gemm_tiles_m(M: int, N: int = 128, K: int = 128, flags: int = 0, rank: int =
     return L.load().ffm_gemm_tiles_m(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
 
 
+def gemm_tiles_n(M: int, N: int, K: int, flags: int = 0, rank: int = 0, dtype=torch.float32, packed: bool = False) -> int:
+    """Column tiles (= rows of a ROWSTATS partial) of that kernel; negative when no kernel serves the flags."""
+    return L.load().ffm_gemm_tiles_n(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
+
+
+class LnIn:
+    """FFM_EPI_LNIN: the LayerNorm in front of a product, folded into it.  part [np, M, 2]: partial row sums of the
+    product's A rows (a producer's `rowstats`, or embed_lnpre's), c [N]: row sums of the gamma-scaled weight;
+    mean / rstd [M]: optional outputs for the LayerNorm backward.  The caller passes the gamma-scaled weight as `b` /
+    `b_packed` and d = W beta + bias as `bias`."""
+
+    def __init__(self, part: Tensor, np_: int, c: Tensor, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None):
+        self.part, self.np, self.c, self.mean, self.rstd = part, np_, c, mean, rstd
+
+
 def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """Frozen bf16 weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
     _dev(w, out)
@@ -118,7 +133,7 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
-            x3: bool = False) -> Tensor:
+            x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
     x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
@@ -159,9 +174,19 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
                  L.ptr(ro.ds_part), ro.S.shape[0], ro.rps, ro.scaling, ro.lam)
     else:
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
+    lnx = (None, None, None, None, 0, 0)
+    if rowstats is not None:                       # [tiles_n, M, 2] fp32 partial row sums of the stored output
+        _dev(rowstats)
+        flags |= L.EPI_ROWSTATS
+        assert _f32(rowstats).numel() >= 2 * M * max(1, gemm_tiles_n(M, N, K, flags, rank, a.dtype, b_packed is not None))
+    if ln_in is not None:
+        _dev(ln_in.part, ln_in.c, ln_in.mean, ln_in.rstd)
+        flags |= L.EPI_LNIN
+        assert _f32(ln_in.part).numel() >= 2 * M * ln_in.np and _f32(ln_in.c).numel() == N and bias is not None
+        lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, 0)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
-                      L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None)
+                      L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx)
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
     _call("ffm_gemm_nt", C.byref(args), L.F32_X3 if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
@@ -200,12 +225,14 @@ def patchify(img: Tensor, cols: Tensor, patch: int, mean3, std3, prenormalised: 
 
 
 def embed_lnpre(patch: Tensor, cls: Tensor, pos: Tensor, gamma: Tensor, beta: Tensor, x: Tensor, B: int,
-                Ltok: int) -> Tensor:
-    _dev(patch, cls, pos, gamma, beta, x)
+                Ltok: int, rowstat: Optional[Tensor] = None) -> Tensor:
+    """rowstat: optional fp32 [>= B*Ltok, 2], receives {sum, sum of squares} of every output row (LnIn.part, np = 1)."""
+    _dev(patch, cls, pos, gamma, beta, x, rowstat)
     width = x.shape[1]
     assert patch.dtype == cls.dtype == pos.dtype == x.dtype
+    assert rowstat is None or rowstat.numel() >= 2 * B * Ltok
     _call("ffm_embed_lnpre", L.ptr(patch), L.ptr(cls), L.ptr(pos), L.ptr(_f32(gamma)), L.ptr(_f32(beta)),
-                                     L.ptr(x), B, Ltok, width, L.dtype_code(x.dtype), L.stream_ptr())
+                                     L.ptr(x), L.ptr(_f32(rowstat)), B, Ltok, width, L.dtype_code(x.dtype), L.stream_ptr())
     return x
 
 

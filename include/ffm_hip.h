@@ -44,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -55,6 +55,14 @@ int ffm_abi_version(void);
 #define FFM_EPI_GELU      16  /* also write c2 = quick_gelu(c)                        */
 #define FFM_EPI_DGELU     32  /* c *= quick_gelu'(aux[m][n])       (aux dtype, ldc)  */
 #define FFM_EPI_RANKOP    64  /* with LORA: ts is computed in-kernel from the packed rank operand rk  */
+/* LayerNorm folded into the two GEMMs around it (bf16 panel kernel only; clip/model.py:354-357 ln_1 / ln_2 in front
+ * of attn.in_proj and mlp.c_fc).  With y = LayerNorm(x) = (x - mu) rstd gamma + beta,
+ *     y W^T + b = rstd (x W'^T - mu c) + d,   W' = gamma (.) W,  c_n = sum_k W'[n][k],  d_n = sum_k beta_k W[n][k] + b_n,
+ * so the consumer multiplies the RAW rows by the gamma-scaled frozen weight and corrects in its epilogue, and the
+ * per-row (mu, rstd) come from partial row sums that the producer of x left behind: no LayerNorm launch, no
+ * normalised copy of x in HBM. */
+#define FFM_EPI_ROWSTATS  128 /* producer: rowstat_part[tn][m] = {sum, sum of squares} of the stored row over this block's columns */
+#define FFM_EPI_LNIN      256 /* consumer: b / b_packed hold W', bias holds d, ln_c holds c; rows are normalised in the epilogue */
 
 typedef struct ffm_gemm_args {
     const void* a;      /* [M, K] dtype, row stride lda (elements) */
@@ -89,6 +97,15 @@ typedef struct ffm_gemm_args {
      * column n followed by zeros (ffm_lora_pack_multi's dst_wide): the panel kernel copies its tile of it straight
      * into LDS instead of converting `lw`; `lw` must still be valid. */
     const void*  lw_wide;
+    /* FFM_EPI_ROWSTATS: [ffm_gemm_tiles_n][M][2] fp32, written once per call (no accumulation) */
+    float*       rowstat_part;
+    /* FFM_EPI_LNIN: partial row sums of A [ln_np][M][2] (a producer's rowstat_part, or ffm_embed_lnpre's), c [N];
+     * optional outputs mean / rstd [M] (for the LayerNorm backward), eps = 1e-5 */
+    const float* ln_part;
+    const float* ln_c;
+    float*       ln_mean;
+    float*       ln_rstd;
+    int32_t      ln_np, pad1_;
 } ffm_gemm_args;
 
 /*
@@ -103,6 +120,9 @@ typedef struct ffm_gemm_args {
 int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
 /* row tiles (= dS partial rows written under FFM_EPI_RANKOP) of the kernel ffm_gemm_nt picks for this call */
 int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed);
+/* column tiles (= rows of rowstat_part under FFM_EPI_ROWSTATS) of that kernel; FFM_EUNSUP when no kernel serves the
+ * flags for this shape (FFM_EPI_ROWSTATS / FFM_EPI_LNIN exist in the bf16 panel kernel only: ask before relying on them) */
+int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dtype, int packed);
 /*
  * dst = src [N, K] bf16 (row stride ld) in MFMA-fragment order: [N/16][K/32][64 lanes][8] with lane l holding
  * row (l & 15), k-group (l >> 4).  N % 16 == 0, K % 32 == 0.  Load-time only (weights are frozen).
@@ -155,7 +175,9 @@ int ffm_patchify(const float* img, void* cols, int B, int H, int W, int patch,
  * cls [width] / pos [L, width] are dtype; gamma/beta fp32.
  */
 int ffm_embed_lnpre(const void* patch, const void* cls, const void* pos, const float* gamma,
-                    const float* beta, void* x, int B, int L, int width, int dtype, void* stream);
+                    const float* beta, void* x, float* rowstat, int B, int L, int width, int dtype, void* stream);
+/* rowstat: optional [B*L][2] = {sum, sum of squares} of every output row as stored (the ln_part of a following
+ * FFM_EPI_LNIN product, ln_np = 1) */
 
 /*
  * 3D OCT input path (trainers/GLP_OT_SVLoRA.py:585-595, 681-693; BASELINE.json configs[3]).

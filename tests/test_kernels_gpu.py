@@ -604,3 +604,73 @@ def test_x3_gemm_rejects_large_products():
     w = torch.randn(512, 512, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gemm_nt(a, w, torch.empty(256, 512, device="cuda"), x3=True)
+
+
+# ------------------------------------------------ LayerNorm folded into the GEMMs around it ---
+def test_gemm_rowstats_partials():
+    """FFM_EPI_ROWSTATS (out-proj forward shape): the partial {sum, sum of squares} of every STORED output row, one
+    partial per column tile, add up to the row sums of the bf16 output."""
+    from fairfedmed_amd import ops, _lib as L
+    M, N, K = 6304, 768, 768
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = (3 + torch.randn(M, N, device="cuda", generator=g)).to(torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    bp = ops.pack_b(w)
+    tn = ops.gemm_tiles_n(M, N, K, L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_ROWSTATS, 0, torch.bfloat16, True)
+    assert tn > 0
+    part = torch.full((tn, M, 2), float("nan"), device="cuda")
+    ops.gemm_nt(a, w, out, bias=bias, res=res, b_packed=bp, rowstats=part)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert float((out.float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    o = out.double()
+    got = part.double().sum(0)
+    assert not torch.isnan(part).any()
+    assert float((got[:, 0] - o.sum(1)).abs().max() / o.sum(1).abs().max()) < 1e-5
+    assert float((got[:, 1] - (o * o).sum(1)).abs().max() / (o * o).sum(1).abs().max()) < 1e-5
+    # without the packed weight no kernel serves the flag: refused, not computed some other way
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, w, out, bias=bias, res=res, rowstats=part)
+
+
+@pytest.mark.parametrize("np_", [1, 6])
+def test_gemm_layernorm_folded_in(np_):
+    """FFM_EPI_LNIN (qkv forward shape): raw rows x gamma-scaled weight, corrected in the epilogue with the row statistics
+    assembled from np partial sums, equals LayerNorm(x) W^T + b; mean / rstd come out for the LayerNorm backward."""
+    from fairfedmed_amd import ops
+    M, N, K = 6304, 2304, 768
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = (1.5 + 2.0 * torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)     # a row mean far from 0
+    x[:, 5] += 40.0                                                                          # one outlier channel
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    gamma = 1 + 0.2 * torch.randn(K, device="cuda", generator=g)
+    beta = 0.3 * torch.randn(K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    wg = (w * gamma).to(torch.bfloat16)
+    c = wg.float().sum(1).contiguous()
+    d = (w @ beta + bias).contiguous()
+    xf = x.float()
+    cols = torch.tensor_split(torch.arange(K, device="cuda"), np_)
+    part = torch.stack([torch.stack([xf[:, ix].sum(1), (xf[:, ix] ** 2).sum(1)], 1) for ix in cols]).contiguous()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    ops.gemm_nt(x, wg, out, bias=d, b_packed=ops.pack_b(wg), ln_in=ops.LnIn(part, np_, c, mean, rstd))
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    ref = ((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ w.double().t() + bias.double()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 1.5e-2           # bf16 weights and output
+    assert float((mean.double() - mu[:, 0]).abs().max()) < 1e-4
+    assert float((rstd.double() * torch.sqrt(var[:, 0] + 1e-5) - 1).abs().max()) < 1e-4
+    # against the unfolded bf16 path (LayerNorm kernel, then the product): the folded form is no less accurate
+    h = torch.empty_like(x)
+    ops.layernorm_fwd(x, h, gamma, beta, torch.empty(M, device="cuda"), torch.empty(M, device="cuda"))
+    wb = w.to(torch.bfloat16)
+    out2 = torch.empty_like(out)
+    ops.gemm_nt(h, wb, out2, bias=bias, b_packed=ops.pack_b(wb))
+    e_fold = float((out.double() - ref).abs().mean())
+    e_plain = float((out2.double() - ref).abs().mean())
+    print(f"mean abs error: folded {e_fold:.3e}, LayerNorm kernel + GEMM {e_plain:.3e}")
+    assert e_fold < 1.5 * e_plain
