@@ -34,12 +34,13 @@ class GemmArgs(C.Structure):
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
         ("b_packed", _vp), ("lw_wide", _vp),
         ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("pad1_", _i32),
+        ("ln_rk", _vp),
     ]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("K", _i32), ("r", _i32), ("layout_rk", _i32), ("pad_", _i32),
-                ("dst_wide", _vp)]
+                ("dst_wide", _vp), ("gamma", _vp), ("beta", _vp), ("ln_rk", _vp)]
 
 
 class ReduceDesc(C.Structure):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "ffm_gemm_tiles_n": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_pack_b": [_vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_multi": [_vp, _i32, _i32, _i32, _vp],
+    "ffm_lora_pack_ln": [_vp, _i32, _i32, _vp],
     "ffm_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _i32, _vp],
@@ -89,6 +91,7 @@ SIGNATURES = {
                       _i32, _vp],
     "ffm_lora_down_blocks": [_i32, _i32, _i32, _i32],
     "ffm_lora_grad_partial": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
+    "ffm_lora_grad_partial_ln": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_lora_grad_splits": [_i32],
     "ffm_reduce_partials": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp],
     "ffm_reduce_partials_multi": [_vp, _i32, _i32, _vp],

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const ffm_pack_desc* __r
         const int j = i / d.K, k = i % d.K;
         float v = 0.f;
         if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
+        if (d.gamma) v *= d.gamma[k];                      // LayerNorm folded into the product (ffm_gemm_args.ln_rk)
         dst[i] = Elem<T>::from_f(v);
     }
     if (d.dst_wide) {                                      // [K][32]: the `lw` tile form of the panel GEMM's rank-r update
@@ -557,6 +558,30 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const ffm_pack_desc* __r
             if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
             wide[i] = Elem<T>::from_f(v);
         }
+    }
+}
+
+// ln_rk[j] = sum_k dst[j][k] (the gamma-scaled operand as rounded), ln_rk[16 + j] = sum_k beta[k] lora_A[k][j]:
+// one block per descriptor, 16 lanes per rank slot, fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void lora_pack_ln_kernel(const ffm_pack_desc* __restrict__ descs) {
+    const ffm_pack_desc d = descs[blockIdx.x];
+    if (!d.ln_rk || !d.gamma || !d.beta || d.layout_rk) return;
+    const int j = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const T* dst = reinterpret_cast<const T*>(d.dst);
+    float c = 0.f, b = 0.f;
+    for (int k = q; k < d.K; k += 16) {
+        c += Elem<T>::to_f(dst[(size_t)j * d.K + k]);
+        if (j < d.r) b += d.beta[k] * d.src[(size_t)k * d.r + j];
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        c += __shfl_xor(c, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (q == 0) {
+        d.ln_rk[j] = c;
+        d.ln_rk[16 + j] = b;
     }
 }
 
@@ -706,6 +731,18 @@ extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, in
         hipLaunchKernelGGL((lora_pack_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, descs_dev);
     else if (dtype == FFM_F32)
         hipLaunchKernelGGL((lora_pack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, descs_dev);
+    else
+        return FFM_EINVAL;
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_lora_pack_ln(const ffm_pack_desc* descs_dev, int ndesc, int dtype, void* stream) {
+    if (!descs_dev || ndesc <= 0) return FFM_EINVAL;
+    if (dtype == FFM_BF16)
+        hipLaunchKernelGGL((lora_pack_ln_kernel<bf16_t>), dim3(ndesc), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    else if (dtype == FFM_F32)
+        hipLaunchKernelGGL((lora_pack_ln_kernel<float>), dim3(ndesc), dim3(256), 0, (hipStream_t)stream, descs_dev);
     else
         return FFM_EINVAL;
     FFM_CHECK_LAUNCH();

@@ -32,10 +32,11 @@ bool plain_flags_ok(int flags) {
 
 bool rk_flags_ok(int flags, int rank) {
     if (rank <= 0 || rank > 16) return false;
-    if (flags & FFM_EPI_LNIN) return false;
+    if ((flags & FFM_EPI_LNIN) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_LNIN)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU))
+        return false;                                          // ln_2 folded in: the c_fc forward epilogue only
     if ((flags & FFM_EPI_ROWSTATS) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL))
         return false;                                          // row sums: the c_proj forward epilogue only
-    switch (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) {
+    switch (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS | FFM_EPI_LNIN)) {
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU:
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL:
         case FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU:
@@ -98,6 +99,7 @@ int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s) {
     if (((uintptr_t)a.b_packed & 15) || a.ldc % 8) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_ROWSTATS) && !a.rowstat_part) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_LNIN) && (!a.ln_part || !a.ln_c || a.ln_np <= 0 || !a.bias)) return FFM_EINVAL;
+    if ((a.flags & FFM_EPI_LNIN) && (a.flags & FFM_EPI_RANKOP) && !a.ln_rk) return FFM_EINVAL;
     if (a.flags & FFM_EPI_RANKOP) return ffm_panel_launch_rk(a, cfg, s);
     switch (a.flags) {
         PANEL_CASE(0)

@@ -115,7 +115,6 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
     static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
-    static_assert(!(RK && (flags & FFM_EPI_LNIN)), "LayerNorm folding in front of a RANKOP product is not built yet");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -485,6 +484,12 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         // summed the dS products row by row: 4-10 us per launch (tools/panel_stamps.py), now one barrier.
         const int j = frow;
         const bool jok = j < r;
+        // LNIN: rk holds (gamma (.) lora_A)^T, so t = rstd (acc - mu c_j) + d_j = LayerNorm(x) lora_A
+        float lncj = 0.f, lndj = 0.f;
+        if constexpr (LNIN) {
+            lncj = p.ln_rk[j];
+            lndj = jok ? p.ln_rk[16 + j] : 0.f;
+        }
         float ssum = 0.f;
 #pragma unroll
         for (int g = 0; g < FFM_MAX_GROUPS; ++g)
@@ -514,10 +519,18 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sgv[e] = (jok && ga[e] >= 0) ? Sg[ga[e] * r + j] : 0.f;
                 float tsv[4];
+                if constexpr (LNIN) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tacc[i][e] = Rs[row0 + e] * (tacc[i][e] - Mu[row0 + e] * lncj) + lndj;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float sb = ga[e] < 0 ? w_uni * ssum : w_oth * ssum + (w_own - w_oth) * sgv[e];
                     tsv[e] = (jok && m0 + row0 + e < p.M) ? p.scaling * tacc[i][e] * sb : 0.f;
+                    // LNIN: the output epilogue multiplies the WHOLE accumulator by rstd (rstd (x W'^T - mu c) + d), so
+                    // the rank-r term enters divided by it: rstd (x W'^T - mu c + (ts / rstd) lw) + d
+                    if constexpr (LNIN) TsA[(row0 + e) * 32 + j] = (bf16_t)(tsv[e] / Rs[row0 + e]);
+                    else
                     TsA[(row0 + e) * 32 + j] = (bf16_t)tsv[e];
                     TsA[(row0 + e) * 32 + 16 + j] = (bf16_t)0.f;
                 }

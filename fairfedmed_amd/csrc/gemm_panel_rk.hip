@@ -13,6 +13,7 @@ int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s) {
     if (!a.rk || ((uintptr_t)a.rk & 15) || !a.S || !a.lw || a.rank <= 0 || a.rank > 16) return FFM_EINVAL;
     switch (a.flags & ~FFM_EPI_RANKOP) {
         PANEL_RK_CASE(FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU)                          // c_fc forward
+        PANEL_RK_CASE(FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU | FFM_EPI_LNIN)           // ... with ln_2 folded in
         PANEL_RK_CASE(FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)                      // c_proj forward
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS:            // ... leaving row sums for ln_1
             // (the 128-column tiles only: a row's lanes must form a power-of-two group)

@@ -333,10 +333,16 @@ constexpr int LGM_ROWS = 128, LGM_COLS = 128;
 
 __device__ __forceinline__ int lgm_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <int RP>   // RP unused slots of the 16 rank slots are zero
+// LN: x holds RAW rows of a LayerNorm input whose normalised copy was never written (FFM_EPI_LNIN); the row factor
+// rstd goes onto v, and the two rank-r row sums of the correction are formed from the v rows every block loads anyway.
+struct lgm_ln {
+    const float *mean, *rstd, *gamma, *beta;
+};
+
+template <int RP, bool LN>   // RP unused slots of the 16 rank slots are zero
 __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ v, int M, int K, int r,
-                                                            float* __restrict__ part, int rs, int j0) {
+                                                            float* __restrict__ part, int rs, int j0, lgm_ln ln) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int k0 = blockIdx.x * LGM_COLS, split = blockIdx.y, m0 = split * LGM_ROWS;
@@ -355,6 +361,7 @@ __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __rest
     // ---- v -> A fragments (rank slot j = lane & 15, rows 8*(lane >> 4) .. +7 of each 32-row block), hi + lo
     const int j = lane & 15, kg = lane >> 4;
     bf16x8 ahi[4], alo[4];
+    float s1 = 0.f, s2 = 0.f;                                  // LN: sum_m mean rstd v, sum_m v (this lane's rows)
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         float vv[8];
@@ -362,6 +369,13 @@ __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __rest
         for (int t = 0; t < 8; ++t) {
             const int gm = m0 + rb * 32 + kg * 8 + t;
             vv[t] = (j < r && gm < M) ? v[(size_t)gm * rs + j0 + j] : 0.f;
+            if constexpr (LN) {
+                const int gc = gm < M ? gm : M - 1;
+                const float rsd = ln.rstd[gc];
+                s2 += vv[t];
+                vv[t] *= rsd;
+                s1 += ln.mean[gc] * vv[t];
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -406,22 +420,43 @@ __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __rest
     }
     // ---- D[jrow = 4*(lane>>4) + e][col = lane & 15] -> part[split][k0 + 16 cf + col][j0 + jrow]
     (void)RP;
+    float c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        // the four row groups of the wave hold disjoint rows of rank slot j: after the butterfly every lane has the sums
+        // of slot (lane & 15); slot jj = 4 kg + e is fetched from lane jj
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c1[e] = __shfl(s1, 4 * kg + e, 64);
+            c2[e] = __shfl(s2, 4 * kg + e, 64);
+        }
+    }
 #pragma unroll
     for (int cf = 0; cf < LGM_COLS / 16; ++cf) {
-        float* dst = part + ((size_t)split * K + k0 + cf * 16 + (lane & 15)) * rs + j0;
+        const int k = k0 + cf * 16 + (lane & 15);
+        float* dst = part + ((size_t)split * K + k) * rs + j0;
+        float gk = 1.f, bk = 0.f;
+        if constexpr (LN) { gk = ln.gamma[k]; bk = ln.beta[k]; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int jj = 4 * kg + e;
-            if (jj < r) dst[jj] = acc[cf][e];
+            if (jj < r) dst[jj] = LN ? gk * (acc[cf][e] - c1[e]) + bk * c2[e] : acc[cf][e];
         }
     }
 }
 
 int launch_grad_mfma(const void* x, int ldx, const float* v, int M, int K, int r, float* part, int rs, int j0,
-                     hipStream_t s) {
+                     hipStream_t s, const lgm_ln* ln = nullptr) {
     dim3 grid(K / LGM_COLS, (M + LGM_ROWS - 1) / LGM_ROWS);
-    hipLaunchKernelGGL((lora_grad_mfma_kernel<16>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx, v, M,
-                       K, r, part, rs, j0);
+    if (ln)
+        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, true>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx,
+                           v, M, K, r, part, rs, j0, *ln);
+    else
+        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, false>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx,
+                           v, M, K, r, part, rs, j0, lgm_ln{});
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -530,6 +565,16 @@ extern "C" int ffm_lora_grad_partial(const void* x, int ldx, const float* v, int
     if (dtype == FFM_BF16) return r <= 4 ? GRAD(bf16_t, 4, r, 0) : r <= 8 ? GRAD(bf16_t, 8, r, 0) : GRAD(bf16_t, 16, r, 0);
     return r <= 4 ? GRAD(float, 4, r, 0) : r <= 8 ? GRAD(float, 8, r, 0) : GRAD(float, 16, r, 0);
 #undef GRAD
+}
+
+extern "C" int ffm_lora_grad_partial_ln(const void* x, int ldx, const float* v, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, int M, int K, int r, float* part,
+                                        int dtype, void* stream) {
+    if (!x || !v || !mean || !rstd || !gamma || !beta || !part || M <= 0 || K <= 0 || r <= 0) return FFM_EINVAL;
+    if (dtype != FFM_BF16 || K % LGM_COLS || r > 16) return FFM_EUNSUP;
+    if (((size_t)ldx * 2) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
+    const lgm_ln ln = {mean, rstd, gamma, beta};
+    return launch_grad_mfma(x, ldx, v, M, K, r, part, r, 0, (hipStream_t)stream, &ln);
 }
 
 extern "C" int ffm_reduce_partials_multi(const ffm_reduce_desc* descs_dev, int ndesc, int max_n, void* stream) {

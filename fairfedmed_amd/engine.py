@@ -147,7 +147,7 @@ def _ds_rows(rows: int, N: int, K: int, rank: int, dtype, packed: Optional[bool]
     return ops.gemm_tiles_m(rows, N, K, fl, rank, dtype, packed)
 
 
-_PACKED = ("w_in", "w_in_t", "w_out", "w_out_t", "w_fc", "w_fc_t", "w_proj", "w_proj_t", "w_in_ln")
+_PACKED = ("w_in", "w_in_t", "w_out", "w_out_t", "w_fc", "w_fc_t", "w_proj", "w_proj_t", "w_in_ln", "w_fc_ln")
 
 
 @dataclass
@@ -176,6 +176,10 @@ class _Block:
     w_in_ln: Optional[Tensor] = None
     c_in: Optional[Tensor] = None
     d_in: Optional[Tensor] = None
+    # ... and ln_2 folded into the c_fc product
+    w_fc_ln: Optional[Tensor] = None
+    c_fc: Optional[Tensor] = None
+    d_fc: Optional[Tensor] = None
 
     def pk(self, name: str) -> Optional[Tensor]:
         return self.packed[name] if self.packed else None
@@ -210,7 +214,9 @@ class _Stack:
         # partial row sums {sum, sum of squares} of every block input, left behind by its producer (FFM_EPI_ROWSTATS /
         # embed_lnpre) for the ln_1 that is folded into the qkv product: up to 8 column tiles
         self.rowp = [f(8 * T * 2) for _ in range(layers + 1)] if (rank and dtype == torch.bfloat16) else None
+        self.rowp2 = [f(8 * T * 2) for _ in range(layers)] if (rank and dtype == torch.bfloat16) else None   # ... of xm (ln_2)
         self.fold = {}                                       # rows -> (np of the c_proj forward, ok) decision cache
+        self.fold2 = {}                                      # rows -> np of the out-proj forward (ln_2 into c_fc)
         if rank:
             self.t1 = [f(T, rank) for _ in range(layers)]
             self.ts1 = [f(T, rank) for _ in range(layers)]
@@ -372,6 +378,12 @@ class FairLoRAEngine:
                 self.lw_wide.append(wd)
                 for role, buf in pk.items():
                     ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf, wd.get(role)))
+                if dtype == torch.bfloat16:
+                    # ln_2 folded into c_fc: the rank operand gamma-scaled, and its two correction rows (ops.LnIn.rk)
+                    pk["fc_A_ln"] = torch.zeros(16, w, device=dev, dtype=dtype)
+                    pk["fc_A_lnrk"] = torch.zeros(32, device=dev, dtype=torch.float32)
+                    ent.append((self.params.view(blk.lora["fc_A"]), False, pk["fc_A_ln"], None,
+                                (blk.ln2_w, blk.ln2_b, pk["fc_A_lnrk"])))
             self.pack_plan = ops.PackPlan(ent, dtype, dev)
 
     def _n_layer_events(self) -> int:
@@ -414,6 +426,10 @@ class FairLoRAEngine:
                 blk.w_in_ln = W(w32 * g1[None, :])
                 blk.c_in = blk.w_in_ln.float().sum(1).contiguous()        # row sums of the weight AS ROUNDED
                 blk.d_in = (w32 @ b1 + blk.b_in).contiguous()
+                wf32 = sd[p + fc + "weight"].to(self.device, torch.float32)
+                blk.w_fc_ln = W(wf32 * blk.ln2_w[None, :])
+                blk.c_fc = blk.w_fc_ln.float().sum(1).contiguous()
+                blk.d_fc = (wf32 @ blk.ln2_b + blk.b_fc).contiguous()
             if lora:
                 blk.lora = {f"{n}_{m}": f"{p}mlp.c_{n}.lora_{m}.weight" for n in ("fc", "proj") for m in "ASB"}
             if old is not None:
@@ -491,6 +507,19 @@ class FairLoRAEngine:
             st.fold[rows] = npj if (npj > 0 and npj <= 8 and nq > 0) else 0
         return st.fold[rows]
 
+    def _fold_ln2(self, st: _Stack, rows: int) -> int:
+        """The same for ln_2 in front of c_fc: partial row sums from the out-proj forward, the FairLoRA c_fc product with
+        the folding epilogue (its rank operand gamma-scaled), and dA(c_fc) from the raw rows (ffm_lora_grad_partial_ln)."""
+        if st.rowp2 is None or not getattr(self, "fused_rank", False) or getattr(self, "no_ln_fold", False):
+            return 0
+        if rows not in st.fold2:
+            w, r = st.width, st.rank
+            npo = ops.gemm_tiles_n(rows, w, w, L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_ROWSTATS, 0, st.dtype, True)
+            f_fc = L.EPI_BIAS | L.EPI_LORA | L.EPI_GELU | L.EPI_RANKOP | L.EPI_LNIN
+            nf = ops.gemm_tiles_n(rows, 4 * w, w, f_fc, r, st.dtype, True)
+            st.fold2[rows] = npo if (npo > 0 and npo <= 8 and nf > 0 and w % 128 == 0 and r <= 16) else 0
+        return st.fold2[rows]
+
     def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
                        save: bool = True) -> Tensor:
         """x[0][:rows] holds the tower input; returns the tower output view."""
@@ -512,19 +541,29 @@ class FairLoRAEngine:
                 ops.layernorm_fwd(x, h, blk.ln1_w, blk.ln1_b, st.st1[i][0], st.st1[i][1])
                 gemm(h, blk.w_in, qkv, bias=blk.b_in, b_packed=blk.pk("w_in"))
             ops.attention_fwd(qkv, o, st.lse[i], images, st.L, st.heads, st.causal)
-            gemm(o, blk.w_out, xm, bias=blk.b_out, res=x, b_packed=blk.pk("w_out"))
-            ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
+            fold2 = self._fold_ln2(st, rows) if r else 0
+            gemm(o, blk.w_out, xm, bias=blk.b_out, res=x, b_packed=blk.pk("w_out"), rowstats=st.rowp2[i] if fold2 else None)
+            if not fold2:
+                ops.layernorm_fwd(xm, h2, blk.ln2_w, blk.ln2_b, st.st2[i][0], st.st2[i][1])
             if r and self.fused_rank:
-                ro = ops.RankOp(self.rk[i]["fc_A"], self._S(i, "fc"), attr, rows_per_sample, lo.scaling,
-                                lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i], lw_wide=self.lw_wide[i].get("fc_B"))
-                gemm(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
-                            b_packed=blk.pk("w_fc"))
+                if fold2:
+                    # ln_2 rides inside the c_fc product (h2 is never written; dA(c_fc) takes the raw rows, _stack_backward)
+                    ro = ops.RankOp(self.rk[i]["fc_A_ln"], self._S(i, "fc"), attr, rows_per_sample, lo.scaling,
+                                    lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i], lw_wide=self.lw_wide[i].get("fc_B"))
+                    ln = ops.LnIn(st.rowp2[i], fold2, blk.c_fc, st.st2[i][0], st.st2[i][1], rk=self.rk[i]["fc_A_lnrk"])
+                    gemm(xm, blk.w_fc_ln, pre, bias=blk.d_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
+                         b_packed=blk.pk("w_fc_ln"), ln_in=ln)
+                else:
+                    ro = ops.RankOp(self.rk[i]["fc_A"], self._S(i, "fc"), attr, rows_per_sample, lo.scaling,
+                                    lo.lambda_group, t_out=st.t1[i], ts_out=st.ts1[i], lw_wide=self.lw_wide[i].get("fc_B"))
+                    gemm(h2, blk.w_fc, pre, bias=blk.b_fc, lw=self._lora_view(blk, "fc_B"), gelu_out=act, rankop=ro,
+                         b_packed=blk.pk("w_fc"))
                 ro = ops.RankOp(self.rk[i]["proj_A"], self._S(i, "proj"), attr, rows_per_sample,
                                 lo.scaling, lo.lambda_group, t_out=st.t2[i], ts_out=st.ts2[i],
                                 lw_wide=self.lw_wide[i].get("proj_B"))
                 gemm(act, blk.w_proj, st.x[i + 1][:rows], bias=blk.b_proj, lw=self._lora_view(blk, "proj_B"),
-                            res=xm, rankop=ro, b_packed=blk.pk("w_proj"),
-                            rowstats=st.rowp[i + 1] if (fold and i + 1 < st.layers) else None)
+                     res=xm, rankop=ro, b_packed=blk.pk("w_proj"),
+                     rowstats=st.rowp[i + 1] if (fold and i + 1 < st.layers) else None)
             elif r:
                 ops.lora_down(h2, self._lora_view(blk, "fc_A"), False, self._S(i, "fc"), attr, r, G,
                               rows_per_sample, lo.scaling, lo.lambda_group, st.t1[i], st.ts1[i])
@@ -590,7 +629,10 @@ class FairLoRAEngine:
                     ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
                     ops.lora_grad_partial(act, us2, r, pt["proj_A"])
                     ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
-                    ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
+                    if self._fold_ln2(st, rows):
+                        ops.lora_grad_partial_ln(xm, us1, st.st2[i][0], st.st2[i][1], blk.ln2_w, blk.ln2_b, r, pt["fc_A"])
+                    else:
+                        ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
                 if last:
                     break
                 if not fused:

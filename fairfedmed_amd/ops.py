@@ -115,8 +115,10 @@ class LnIn:
     mean / rstd [M]: optional outputs for the LayerNorm backward.  The caller passes the gamma-scaled weight as `b` /
     `b_packed` and d = W beta + bias as `bias`."""
 
-    def __init__(self, part: Tensor, np_: int, c: Tensor, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None):
+    def __init__(self, part: Tensor, np_: int, c: Tensor, mean: Optional[Tensor] = None, rstd: Optional[Tensor] = None,
+                 rk: Optional[Tensor] = None):
         self.part, self.np, self.c, self.mean, self.rstd = part, np_, c, mean, rstd
+        self.rk = rk          # with a RankOp: [2, 16] corrections of its gamma-scaled rank operand (PackPlan's ln output)
 
 
 def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -174,7 +176,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
                  L.ptr(ro.ds_part), ro.S.shape[0], ro.rps, ro.scaling, ro.lam)
     else:
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
-    lnx = (None, None, None, None, 0, 0)
+    lnx = (None, None, None, None, 0, 0, None)
     if rowstats is not None:                       # [tiles_n, M, 2] fp32 partial row sums of the stored output
         _dev(rowstats)
         flags |= L.EPI_ROWSTATS
@@ -183,7 +185,10 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         _dev(ln_in.part, ln_in.c, ln_in.mean, ln_in.rstd)
         flags |= L.EPI_LNIN
         assert _f32(ln_in.part).numel() >= 2 * M * ln_in.np and _f32(ln_in.c).numel() == N and bias is not None
-        lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, 0)
+        _dev(ln_in.rk)
+        assert (ro is None) == (ln_in.rk is None) and (ln_in.rk is None or _f32(ln_in.rk).numel() == 32)
+        lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, 0,
+               L.ptr(ln_in.rk))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx)
@@ -486,18 +491,28 @@ class PackPlan:
     """Device-resident descriptor table for ffm_lora_pack_multi (all adapters in one launch)."""
 
     def __init__(self, entries, dtype, device):
-        # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype[, wide [K,32] dtype])
+        # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype[, wide [K,32] dtype[, ln]]);
+        # ln = (gamma [K], beta [K], ln_rk [2,16]): a LayerNorm folded into the product dst rides in (layout_rk False):
+        # dst is gamma-scaled and ln_rk receives its corrections (ffm_lora_pack_ln)
         arr = (L.PackDesc * len(entries))()
         self.keep, self.max_K, self.dtype = entries, 0, dtype
+        self.any_ln = False
         for i, ent in enumerate(entries):
             src, layout_rk, dst = ent[:3]
             wide = ent[3] if len(ent) > 3 else None
+            ln = ent[4] if len(ent) > 4 else None
             _dev(src, dst, wide)
             K = dst.shape[1]
             r = src.shape[0] if layout_rk else src.shape[1]
             assert dst.dtype == dtype and dst.shape[0] == 16 and dst.is_contiguous() and src.is_contiguous()
             assert wide is None or (wide.dtype == dtype and tuple(wide.shape) == (K, 32) and wide.is_contiguous())
-            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0, L.ptr(wide))
+            lnp = (None, None, None)
+            if ln is not None:
+                assert not layout_rk and _f32(ln[0]).numel() == K and _f32(ln[1]).numel() == K and _f32(ln[2]).numel() == 32
+                _dev(*ln)
+                lnp = tuple(t.data_ptr() for t in ln)
+                self.any_ln = True
+            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0, L.ptr(wide), *lnp)
             self.max_K = max(self.max_K, K)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n = len(entries)
@@ -505,6 +520,18 @@ class PackPlan:
     def run(self) -> None:
         _call("ffm_lora_pack_multi", self.table.data_ptr(), self.n, self.max_K, L.dtype_code(self.dtype),
                                              L.stream_ptr())
+        if self.any_ln:
+            _call("ffm_lora_pack_ln", self.table.data_ptr(), self.n, L.dtype_code(self.dtype), L.stream_ptr())
+
+
+def lora_grad_partial_ln(x: Tensor, v: Tensor, mean: Tensor, rstd: Tensor, gamma: Tensor, beta: Tensor, r: int,
+                         part: Tensor) -> None:
+    """lora_grad_partial for x = LayerNorm(x_raw) that was folded into its consumer: x holds the RAW rows."""
+    _dev(x, v, mean, rstd, gamma, beta, part)
+    M, K = x.shape
+    assert x.dtype == torch.bfloat16 and K % 128 == 0 and r <= 16
+    _call("ffm_lora_grad_partial_ln", L.ptr(x), _ld(x), L.ptr(_f32(v)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
+          L.ptr(_f32(gamma)), L.ptr(_f32(beta)), M, K, r, L.ptr(_f32(part)), L.dtype_code(x.dtype), L.stream_ptr())
 
 
 def lora_grad_splits(M: int) -> int:

@@ -106,6 +106,10 @@ typedef struct ffm_gemm_args {
     float*       ln_mean;
     float*       ln_rstd;
     int32_t      ln_np, pad1_;
+    /* FFM_EPI_LNIN with FFM_EPI_RANKOP: rk holds (gamma (.) lora_A)^T and ln_rk [2][16] its corrections
+     * {c_j = sum_k rk[j][k], d_j = sum_k beta_k lora_A[k][j]} (ffm_lora_pack_multi writes both):
+     * t = rstd (x rk^T - mu c) + d = LayerNorm(x) lora_A */
+    const float* ln_rk;
 } ffm_gemm_args;
 
 /*
@@ -139,8 +143,17 @@ typedef struct ffm_pack_desc {
     void* dst;
     int32_t K, r, layout_rk, pad_;
     void* dst_wide;     /* optional [K, 32] dtype: dst_wide[k][j] = the same element as dst[j][k], columns >= r zero */
+    /* optional (layout_rk = 0): a LayerNorm folded into the product this operand rides in (ffm_gemm_args.ln_rk):
+     * dst[j][k] = gamma[k] * src[k][j], ln_rk[j] = sum_k dst[j][k] (as rounded), ln_rk[16 + j] = sum_k beta[k] src[k][j];
+     * dst_wide keeps the unscaled matrix */
+    const float* gamma;
+    const float* beta;
+    float* ln_rk;
 } ffm_pack_desc;
 int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream);
+/* second pass for the descriptors that carry gamma / beta / ln_rk (others return at once): the ln_rk sums, which read
+ * what ffm_lora_pack_multi has just written (call it after, on the same stream) */
+int ffm_lora_pack_ln(const ffm_pack_desc* descs_dev, int ndesc, int dtype, void* stream);
 
 /*
  * LayerNorm over the last dimension, fp32 statistics, eps 1e-5
@@ -293,6 +306,13 @@ int ffm_lora_down_blocks(int M, int K, int r, int dtype);   /* blocks (= dS part
  */
 int ffm_lora_grad_partial(const void* x, int ldx, const float* v, int M, int K, int r,
                           float* part, int dtype, void* stream);
+/* The same for x = LayerNorm(x_raw) that was never materialised (ln_2 folded into c_fc): x is the RAW rows,
+ * mean / rstd [M] and gamma / beta [K] the LayerNorm, and with y = (x_raw - mean) rstd gamma + beta
+ *   part[split][k][j] = gamma[k] (sum_m x_raw[m][k] rstd[m] v[m][j] - sum_m mean[m] rstd[m] v[m][j]) + beta[k] sum_m v[m][j].
+ * bf16, K % 128 == 0, r <= 16. */
+int ffm_lora_grad_partial_ln(const void* x, int ldx, const float* v, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int M, int K, int r, float* part, int dtype,
+                             void* stream);
 int ffm_lora_grad_splits(int M);
 
 /*

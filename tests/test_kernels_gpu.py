@@ -674,3 +674,26 @@ def test_gemm_layernorm_folded_in(np_):
     e_plain = float((out2.double() - ref).abs().mean())
     print(f"mean abs error: folded {e_fold:.3e}, LayerNorm kernel + GEMM {e_plain:.3e}")
     assert e_fold < 1.5 * e_plain
+
+
+def test_lora_grad_partial_through_a_folded_layernorm():
+    """ffm_lora_grad_partial_ln: dA = LayerNorm(x)^T v from the RAW rows (the normalised copy is never written when ln_2
+    rides inside the c_fc product) equals the plain reduction on a materialised LayerNorm output."""
+    from fairfedmed_amd import ops
+    M, K, r = 6304, 768, 8
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (0.7 + 1.5 * torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    v = torch.randn(M, r, device="cuda", generator=g)
+    gamma = 1 + 0.2 * torch.randn(K, device="cuda", generator=g)
+    beta = 0.3 * torch.randn(K, device="cuda", generator=g)
+    xd = x.double()
+    mu, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    ns = ops.lora_grad_splits(M)
+    part = torch.full((ns, K, r), float("nan"), device="cuda")
+    ops.lora_grad_partial_ln(x, v, mu.float(), rstd.float(), gamma, beta, r, part)
+    got = part.double().sum(0)
+    y = (xd - mu[:, None]) * rstd[:, None] * gamma.double() + beta.double()
+    ref = y.t() @ v.double()
+    assert not torch.isnan(part).any()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4      # v enters as a bf16 hi + lo pair
