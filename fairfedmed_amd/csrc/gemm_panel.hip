@@ -98,7 +98,7 @@ int ffm_panel_tiles_n(int N, int cfg) { return N / (64 * FFM_PANEL_CFGS[cfg].nf)
 int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s) {
     if (((uintptr_t)a.b_packed & 15) || a.ldc % 8) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_ROWSTATS) && !a.rowstat_part) return FFM_EINVAL;
-    if ((a.flags & FFM_EPI_LNIN) && (!a.ln_part || !a.ln_c || a.ln_np <= 0 || !a.bias)) return FFM_EINVAL;
+    if ((a.flags & FFM_EPI_LNIN) && (!a.ln_part || !a.ln_c || a.ln_np <= 0 || a.ln_np > 8 || !a.bias)) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_LNIN) && (a.flags & FFM_EPI_RANKOP) && !a.ln_rk) return FFM_EINVAL;
     if (a.flags & FFM_EPI_RANKOP) return ffm_panel_launch_rk(a, cfg, s);
     switch (a.flags) {

@@ -255,6 +255,23 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     };
     static_assert(NF + G::NI <= MF, "one VMEM slot per fragment row");
 
+    // LNIN: the partial row sums of this thread's tile row are requested FIRST: behind the ring fills each of these
+    // small loads waits ~150 cycles for an issue slot (3 us per block, tools/panel_stamps.py)
+    constexpr bool LNIN_ = (FL & FFM_EPI_LNIN) != 0;
+    f32x2 lnpv[8];
+    if constexpr (LNIN_) {
+        static_assert(16 * MF <= PT, "one tile row per thread");
+        const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+        // (inline asm, consumed behind the prologue's own vmcnt(0): a compiler-visible load in front of the LDS-DMA
+        // builtins is answered with s_waitcnt vmcnt(0) before the first of them, i.e. a full HBM round trip up front)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int qq = q < p.ln_np ? q : 0;                // always a valid address; surplus slots are not summed
+            const float* src = p.ln_part + ((size_t)qq * p.M + gm) * 2;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lnpv[q]) : "v"(src) : "memory");
+        }
+    }
+
     // ---- prologue: ring stages 0..2 and the B fragments of half-steps 0..2, drained once before the loop
     dma(0);
     dma(1);
@@ -282,25 +299,6 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         // LayerNorm statistics of this tile's A rows from the producer's partial row sums (fixed order over the
         // partials: deterministic); E[x^2] - mu^2 in f32 is exact enough for K <= 4096 activations of O(1..100)
         for (int i = tid; i < BNp; i += PT) Cv[i] = p.ln_c[n0 + i];
-        for (int i = tid; i < BMp; i += PT) {
-            const int gm = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
-            float su = 0.f, sq = 0.f;
-            for (int q = 0; q < p.ln_np; ++q) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(p.ln_part + ((size_t)q * p.M + gm) * 2);
-                su += v[0];
-                sq += v[1];
-            }
-            const float mu = su / (float)p.K;
-            float var = sq / (float)p.K - mu * mu;
-            var = var > 0.f ? var : 0.f;
-            const float rs = 1.0f / sqrtf(var + 1e-5f);
-            Mu[i] = mu;
-            Rs[i] = rs;
-            if (tn == 0 && m0 + i < p.M) {
-                if (p.ln_mean) p.ln_mean[gm] = mu;
-                if (p.ln_rstd) p.ln_rstd[gm] = rs;
-            }
-        }
     }
     if constexpr (RK) {
         if (p.lw_wide) {
@@ -347,6 +345,32 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     }
     FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (LNIN) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(lnpv[q]));
+        if (tid < BMp) {
+            const int i = tid;
+            const int gm = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                  // fixed order over the partials
+                if (q < p.ln_np) {
+                    su += lnpv[q][0];
+                    sq += lnpv[q][1];
+                }
+            }
+            const float mu = su / (float)p.K;
+            float var = sq / (float)p.K - mu * mu;
+            var = var > 0.f ? var : 0.f;
+            const float rs = 1.0f / sqrtf(var + 1e-5f);
+            Mu[i] = mu;
+            Rs[i] = rs;
+            if (tn == 0 && m0 + i < p.M) {
+                if (p.ln_mean) p.ln_mean[gm] = mu;
+                if (p.ln_rstd) p.ln_rstd[gm] = rs;
+            }
+        }
+    }
     __syncthreads();
     stagger(wave);
     FFM_STAMP(1);

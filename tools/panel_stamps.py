@@ -72,6 +72,11 @@ def case(name, N, K, mode):
                             ds_part=torch.empty(rows, G, R, device="cuda") if kr else None,
                             lw_wide=None if "nowide" in sys.argv else wide)
             kw.update(lw=lwsrc, lw_is_kr=kr, rankop=ro)
+        if "n" in mode:                                             # LayerNorm folded in (FFM_EPI_LNIN), 6 partials per row
+            part = torch.randn(6, M, 2, device="cuda", generator=g).abs() + 1.0
+            part[:, :, 1] = part[:, :, 0] ** 2 * 3 + 5
+            kw["ln_in"] = ops.LnIn(part.contiguous(), 6, torch.randn(N, device="cuda", generator=g), torch.empty(M, device="cuda"),
+                                   torch.empty(M, device="cuda"), rk=torch.randn(32, device="cuda", generator=g) if "l" in mode else None)
         sets.append((a, b, out, ops.pack_b(b), kw))
     stamps = torch.zeros(1024 * NST * 2, device="cuda", dtype=torch.int64)
     nostamp = None
@@ -114,6 +119,6 @@ def case(name, N, K, mode):
 
 
 if __name__ == "__main__":
-    for name, N, K, mode in [("fc fwd", 4 * W, W, "blg"), ("proj fwd", W, 4 * W, "blr"), ("proj dX", 4 * W, W, "lkd"),
+    for name, N, K, mode in [("fc fwd+ln", 4 * W, W, "blgn"), ("fc fwd", 4 * W, W, "blg"), ("proj fwd", W, 4 * W, "blr"), ("proj dX", 4 * W, W, "lkd"),
                              ("fc dX", W, 4 * W, "lk"), ("out fwd", W, W, "br"), ("qkv dX", W, 3 * W, "")]:
         case(name, N, K, mode)
