@@ -697,3 +697,19 @@ def test_lora_grad_partial_through_a_folded_layernorm():
     ref = y.t() @ v.double()
     assert not torch.isnan(part).any()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4      # v enters as a bf16 hi + lo pair
+
+
+def test_reduce_partials_many_rows_of_a_short_tensor():
+    """ffm_reduce_partials on the 3D OCT shape (19 600 partial rows of 603 outputs: the tall kernel) and on a short
+    stack of a long tensor (the 4-lane kernel): both equal the float64 column sums, also transposing and accumulating."""
+    from fairfedmed_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for ns, n, tk, tr in ((19600, 603, 0, 0), (700, 96, 12, 8), (50, 24576, 3072, 8)):
+        part = torch.randn(ns, n, device="cuda", generator=g)
+        out = torch.full((n,), 2.0, device="cuda")
+        ops.reduce_partials(part, ns, n, out, transpose_K=tk, transpose_r=tr, accumulate=True)
+        ref = part.double().sum(0)
+        if tk:
+            ref = ref.view(tk, tr).t().reshape(-1)
+        ref = ref + 2.0
+        assert float((out.double() - ref).abs().max()) < 2e-3 * (ns ** 0.5) / 10, (ns, n)
