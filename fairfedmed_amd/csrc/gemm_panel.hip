@@ -70,9 +70,9 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
         // more than one round of tiles loses to the 128x128 kernel, whose two blocks per CU overlap one tile's epilogue
         // with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
-        // ... except the 208x384 FairLoRA tile at several FULL rounds (3D OCT: 19 700 rows -> 760 blocks): its epilogues
+        // ... except the 208x384 FairLoRA tile at several rounds (bs 64: 488 blocks, 3D OCT: 19 700 rows -> 760 blocks): its epilogues
         // run at the HBM rate since round 2, and three rounds of it (~160 us) beat the 128x128 kernel's 206-228 us
-        const bool multi = rk && FFM_PANEL_CFGS[c].nf == 6 && blocks > 512;
+        const bool multi = rk && FFM_PANEL_CFGS[c].nf == 6 && blocks > 256;
         if (blocks > 256 * per_cu && !multi) continue;
         // (a two-per-CU tile that fills less than half of its slots is a one-per-CU tile with a worse shape)
         if (per_cu > 1 && blocks <= 256) continue;

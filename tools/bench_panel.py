@@ -9,7 +9,7 @@ import torch
 from fairfedmed_amd import ops
 
 dt = torch.bfloat16
-M, W, R, G, RPS = 6304, 768, 8, 3, 197
+M, W, R, G, RPS = int(os.environ.get('FFM_BENCH_M', 6304)), 768, 8, 3, 197
 
 
 def bench(fn, iters=40):
@@ -44,7 +44,7 @@ def case(name, N, K, mode):
         P = torch.randn(K, R, device="cuda", generator=g) * 0.1
         rk = torch.zeros(16, K, device="cuda", dtype=dt)
         ops.PackPlan([(P, False, rk)], dt, "cuda").run()
-        attr = torch.randint(0, G, (32,), device="cuda", dtype=torch.int32)
+        attr = torch.randint(0, G, ((M + RPS - 1) // RPS,), device="cuda", dtype=torch.int32)
         t, ts = torch.empty(M, R, device="cuda"), torch.empty(M, R, device="cuda")
         bwd = kr
         rows = max(ops.gemm_tiles_m(M, N, K, 0, 0, dt, False), 512)
