@@ -15,7 +15,11 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
     for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
 }
 
-template <typename T>
+// MC: 8-element chunks per lane (width <= 8 * 64 * MC).  ViT widths (<= 1024) take MC = 2: half the registers of the
+// general MC = 4 form (backward: 74 instead of 126).  It does not make the kernels faster - they are one wave
+// generation of dependent latency (load, two wave reductions, store), not occupancy-bound: 10.4 -> 10.4 us measured,
+// and forcing 7 waves per SIMD made it 11.1.
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -26,10 +30,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     if (row >= rows) return;
     const int nchunk = width >> 3;
     const T* xr = x + (size_t)row * width;
-    float v[MAXC][8];
+    float v[MC][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             Vec8<T>::load(xr + c * 8, v[i]);
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float mean = wave_sum(s) / (float)width;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
 #pragma unroll
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     T* yr = y + (size_t)row * width;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float g[8], b[8], o[8];
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // dx = rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  gy = gamma * dy
-template <typename T>
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in,
@@ -82,10 +86,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int nchunk = width >> 3;
     const float mean = mean_in[row], rstd = rstd_in[row];
     const size_t base = (size_t)row * width;
-    float gy[MAXC][8], xh[MAXC][8], rr[MAXC][8];
+    float gy[MC][8], xh[MC][8], rr[MC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float d[8], xv[8], g[8];
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const float m1 = wave_sum(s1) / (float)width;
     const float m2 = wave_sum(s2) / (float)width;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < MC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
             float o[8];
@@ -223,14 +227,16 @@ extern "C" int ffm_layernorm_fwd(const void* x, void* y, const float* gamma, con
     if (!x || !y || !gamma || !beta || rows <= 0 || bad_width(width)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((rows + 3) / 4), block(256);
-    if (dtype == FFM_BF16)
-        hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, (bf16_t*)y, gamma,
-                           beta, mean, rstd, rows, width);
-    else if (dtype == FFM_F32)
-        hipLaunchKernelGGL((layernorm_fwd_kernel<float>), grid, block, 0, s, (const float*)x, (float*)y, gamma, beta,
-                           mean, rstd, rows, width);
-    else
+    const bool narrow = width <= 8 * 64 * 2;
+#define LN_FWD(T, MC) hipLaunchKernelGGL((layernorm_fwd_kernel<T, MC>), grid, block, 0, s, (const T*)x, (T*)y, gamma, beta, mean, rstd, rows, width)
+    if (dtype == FFM_BF16) {
+        if (narrow) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4);
+    } else if (dtype == FFM_F32) {
+        if (narrow) LN_FWD(float, 2); else LN_FWD(float, 4);
+    } else {
         return FFM_EINVAL;
+    }
+#undef LN_FWD
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -241,14 +247,16 @@ extern "C" int ffm_layernorm_bwd(const void* dy, const void* x, const float* gam
     if (!dy || !x || !gamma || !mean || !rstd || !out || rows <= 0 || bad_width(width)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((rows + 3) / 4), block(256);
-    if (dtype == FFM_BF16)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                           gamma, mean, rstd, (const bf16_t*)res, (bf16_t*)out, rows, width);
-    else if (dtype == FFM_F32)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<float>), grid, block, 0, s, (const float*)dy, (const float*)x, gamma,
-                           mean, rstd, (const float*)res, (float*)out, rows, width);
-    else
+    const bool narrow = width <= 8 * 64 * 2;
+#define LN_BWD(T, MC) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MC>), grid, block, 0, s, (const T*)dy, (const T*)x, gamma, mean, rstd, (const T*)res, (T*)out, rows, width)
+    if (dtype == FFM_BF16) {
+        if (narrow) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4);
+    } else if (dtype == FFM_F32) {
+        if (narrow) LN_BWD(float, 2); else LN_BWD(float, 4);
+    } else {
         return FFM_EINVAL;
+    }
+#undef LN_BWD
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
