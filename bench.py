@@ -394,7 +394,8 @@ def main():
             pass
         roof = {"bound": "mfma",
                 "kernel": "ffm_gemm_nt on the vision tower (M=%d): gemm_panel_kernel<%s> on fragment-packed frozen "
-                          "weights (bf16), gemm_nt_kernel otherwise" % (BATCH * 197, args.dtype),
+                          "weights (bf16; the qkv / c_fc launches also carry ln_1 / ln_2, FFM_EPI_LNIN, whose flops are "
+                          "not counted), gemm_nt_kernel otherwise" % (BATCH * 197, args.dtype),
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), algorithmic mean 54.4e6",
                 "traffic_source": tsrc,
