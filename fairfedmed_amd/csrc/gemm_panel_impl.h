@@ -79,22 +79,11 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// The four waves of a block leave a barrier together and run the same instruction stream, so their vector-memory
-// instructions reach the CU's one texture path in the same cycle and three of them wait (an MFMA cannot issue behind
-// a stalled VMEM instruction).  Wave w idles w * FFM_PANEL_STAGGER * 8 cycles after every barrier.
-#ifndef FFM_PANEL_STAGGER
-#define FFM_PANEL_STAGGER 0
-#endif
 // Diagnostic builds only (tools/panel_stamps.py): drop parts of the main loop to price them.  1: no weight-fragment
 // loads, 2: no LDS-DMA of the activation ring, 4: no MFMAs, 8: no LDS fragment reads (results are garbage).
 #ifndef FFM_PANEL_ABL
 #define FFM_PANEL_ABL 0
 #endif
-__device__ __forceinline__ void stagger(int wave) {
-    if constexpr (FFM_PANEL_STAGGER > 0) {
-        for (int q = 0; q < wave * FFM_PANEL_STAGGER; ++q) asm volatile("s_nop 7");
-    }
-}
 
 __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }                // floats
 // persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
@@ -372,7 +361,6 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         }
     }
     __syncthreads();
-    stagger(wave);
     FFM_STAMP(1);
 
     // VMEM issue order of step kt (nA = G::NI pieces, the same on every wave):
@@ -422,7 +410,6 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
             else if (rem == 3) wait_vm<5 * NF + nA>();
             else wait_vm<4 * NF>();
             block_barrier();
-            stagger(wave);
         }
     };
     auto main_loop = [&](auto W_) {
