@@ -633,6 +633,10 @@ class FairLoRAEngine:
                         ops.lora_grad_partial_ln(xm, us1, st.st2[i][0], st.st2[i][1], blk.ln2_w, blk.ln2_b, r, pt["fc_A"])
                     else:
                         ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
+                    # this block's six gradient tensors are complete: sum their partials now, behind the four reductions
+                    # on the same side stream (one launch per block; only block 0's is left when the dX chain ends -
+                    # ONE launch for all 72 tensors at the end sat in the step's tail for ~50 us)
+                    self._reduce_plan(st, rows, need_input_grad, i).run()
                 if last:
                     break
                 if not fused:
@@ -650,22 +654,22 @@ class FairLoRAEngine:
             gemm(st.dqkv[:rows], blk.w_in_t, st.dh[:rows], b_packed=blk.pk("w_in_t"))
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
         if r:
-            with self._on(self.grad_stream):
-                self._reduce_plan(st, rows, need_input_grad).run()
             if self.sops.glob:
                 self._glue(self.sops.finish, self.grad_stream)     # dS_eff -> dS, dS_global
             self._ev_record(self.ev_grads, self.grad_stream)
             self._ev_wait(main, self.ev_grads)
         return g
 
-    def _reduce_plan(self, st: _Stack, rows: int, full_bwd: bool = False):
-        """Descriptor table (built once per row count) that sums every layer's partials into params.grad."""
-        key = (rows, full_bwd)
+    def _reduce_plan(self, st: _Stack, rows: int, full_bwd: bool, layer: int):
+        """Descriptor table (built once per row count and block) that sums the block's partials into params.grad."""
+        key = (rows, full_bwd, layer)
         if key not in st.plans:
             r, G, w = st.rank, self.cfg.lora.num_groups, st.width
             nsp = ops.lora_grad_splits(rows)
             ent = []
             for li, (blk, pt) in enumerate(zip(st.blocks, st.part)):
+                if li != layer:
+                    continue
                 gv = lambda role: self.params.view(blk.lora[role], "grad")
                 # dS partial rows: GEMM row tiles when the down projection is fused, lora_down blocks otherwise
                 # (block 0's c_fc has no dX GEMM, so it always uses the stand-alone kernel)
