@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
     lib = LIB.replace(".so", "_stamps.so") if stamps else LIB
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        special = stamps and src.startswith("gemm_panel")
+        special = stamps and (src.startswith("gemm_panel") or src == "lora.hip")
         o = os.path.join(CSRC, src.replace(".hip", ".stamps.o" if special else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS) or (special and os.environ.get("FFM_STAMPS_DEFS")):

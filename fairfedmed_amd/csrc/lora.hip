@@ -347,6 +347,24 @@ __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __rest
     const int lane = threadIdx.x;
     const int k0 = blockIdx.x * LGM_COLS, split = blockIdx.y, m0 = split * LGM_ROWS;
 
+#ifdef FFM_LGM_NOLDS
+    // diagnostic build (tools/step_ablate2.py): the same bytes through registers, no LDS (the result is garbage) - is it
+    // the kernel's HBM traffic or its LDS footprint that slows the vision chain down?
+    {
+        bf16x8 sink = {};
+#pragma unroll 8
+        for (int piece = 0; piece < LGM_ROWS / 4; ++piece) {
+            const int row = piece * 4 + (lane >> 4);
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (size_t)gm * ldx + k0 + (lane & 15) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sink[e] = (bf16_t)((float)sink[e] + (float)t[e]);
+        }
+        if (v[0] == 123456.f) part[lane] = (float)sink[0];
+        return;
+    }
+#endif
     // ---- X tile -> LDS: piece = 4 rows; lane -> row 4*piece + (lane >> 4), LDS slot lane & 15
 #pragma unroll
     for (int piece = 0; piece < LGM_ROWS / 4; ++piece) {
@@ -451,11 +469,16 @@ __global__ __launch_bounds__(64) void lora_grad_mfma_kernel(const bf16_t* __rest
 int launch_grad_mfma(const void* x, int ldx, const float* v, int M, int K, int r, float* part, int rs, int j0,
                      hipStream_t s, const lgm_ln* ln = nullptr) {
     dim3 grid(K / LGM_COLS, (M + LGM_ROWS - 1) / LGM_ROWS);
+#ifdef FFM_LGM_NOLDS
+#define LGM_LDS 0
+#else
+#define LGM_LDS (LGM_ROWS * LGM_COLS * 2)
+#endif
     if (ln)
-        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, true>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx,
+        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, true>), grid, dim3(64), LGM_LDS, s, (const bf16_t*)x, ldx,
                            v, M, K, r, part, rs, j0, *ln);
     else
-        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, false>), grid, dim3(64), LGM_ROWS * LGM_COLS * 2, s, (const bf16_t*)x, ldx,
+        hipLaunchKernelGGL((lora_grad_mfma_kernel<16, false>), grid, dim3(64), LGM_LDS, s, (const bf16_t*)x, ldx,
                            v, M, K, r, part, rs, j0, lgm_ln{});
     FFM_CHECK_LAUNCH();
     return FFM_OK;
