@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
         ("b_packed", _vp), ("lw_wide", _vp),
         ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("pad1_", _i32),
-        ("ln_rk", _vp),
+        ("ln_rk", _vp), ("colstat_part", _vp),
     ]
 
 
@@ -72,13 +72,14 @@ SIGNATURES = {
     "ffm_im2col3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_bn_blocks": [_i32],
-    "ffm_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_avgpool2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i32, _vp],
+    "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp],
+    "ffm_conv3x3_colstat_rows": [_i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "ffm_eval_counts_ws_bytes": [_i32],
     "ffm_eval_counts_sorted": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp],

@@ -473,12 +473,17 @@ extern "C" int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, i
 extern "C" int ffm_bn_blocks(int rows) { return cs_blocks(rows); }
 
 extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
-                          float* mean, float* rstd, float* part, const void* res, void* y, int rows, int C, int training,
-                          int relu, int dtype, void* stream) {
+                          float* mean, float* rstd, float* part, int part_rows, const void* res, void* y, int rows, int C,
+                          int training, int relu, int dtype, void* stream) {
     if (!x || !gamma || !beta || !run_mean || !run_var || !mean || !rstd || !y || rows <= 0 || C <= 0) return FFM_EINVAL;
     if (C % (dtype == FFM_BF16 ? 8 : 4) || (training && !part)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (training) {
+    if (training && part_rows > 0) {
+        // the producer of x left the column sums of its row tiles behind (ffm_gemm_args.colstat_part)
+        if (part_rows > CS_MAXBLK) return FFM_EINVAL;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, part_rows, rows, C, mean, rstd, run_mean,
+                           run_var, 0.1f, 1e-5f);
+    } else if (training) {
         const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
         dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
         DISPATCH_T(dtype,

@@ -394,6 +394,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
 
     const int ecol = (tid & 15) * 8;                  // this thread's 8 columns
     const int erow0 = tid >> 4;                       // rows erow0 + 16*i
+    // colstat_part: column sums of the stored tile (the BatchNorm statistics of RN50's convolutions)
+    const bool cst = p.colstat_part != nullptr;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[c] = cq[c] = 0.f;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         // this half's residual / pre-activation rows: issue the global loads now, consume after the barrier
@@ -501,6 +506,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(Elem<T>::to_f(raux[i][c / EPC][c % EPC]));
                 }
                 Vec8<T>::store(C + off, v[i]);
+                if (cst) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float st = Elem<T>::to_f(Elem<T>::from_f(v[i][c]));
+                        cs[c] += st;
+                        cq[c] += st * st;
+                    }
+                }
                 if (flags & FFM_EPI_GELU) {
                     float a[8];
 #pragma unroll
@@ -510,6 +523,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             }
         }
         __syncthreads();
+    }
+    if (cst) {
+        // the 16 row lanes of a column chunk meet in LDS and are added in a fixed order: part[tm][0 / 1][n0 + col]
+        float* R0 = Cs;
+        float* R1 = Cs + 16 * BN;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            R0[erow0 * BN + ecol + c] = cs[c];
+            R1[erow0 * BN + ecol + c] = cq[c];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                s0 += R0[l * BN + tid];
+                s1 += R1[l * BN + tid];
+            }
+            p.colstat_part[((size_t)tm * 2) * p.N + n0 + tid] = s0;
+            p.colstat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = s1;
+        }
     }
 }
 
@@ -610,7 +644,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (ffm_skinny_ok(a, dtype)) {
+    if (ffm_skinny_ok(a, dtype) && !a.colstat_part) {                    // (column sums: the 128x128 kernel's epilogue)
         static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
         if (!off || dtype == FFM_F32_X3) return ffm_skinny_launch(a, dtype, s);
     }
@@ -668,8 +702,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+namespace {
+// K slices ffm_conv3x3_nhwc will use (1: one launch with the full epilogue)
+int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_elems) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
+    if (!(scratch && tiles < 160 && nk >= 16 && N % 4 == 0)) return 1;
+    int S = 512 / tiles;
+    if (S > 8) S = 8;
+    if (S > nk / 4) S = nk / 4;
+    while (S > 1 && (int64_t)S * M * N > scratch_elems) --S;
+    if (S <= 1) return 1;
+    const int per = (nk + S - 1) / S;
+    return (nk + per - 1) / per;                                    // no empty slice
+}
+}  // namespace
+
+extern "C" int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int Kp, int64_t scratch_elems, int dtype) {
+    if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || (dtype != FFM_BF16 && dtype != FFM_F32)) return FFM_EINVAL;
+    const int M = B * H * W;
+    return conv_ksplit(M, N, Kp, dtype == FFM_BF16 ? 2 : 4, scratch_elems > 0, scratch_elems) > 1 ? 0 : (M + BM - 1) / BM;
+}
+
 extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
-                                const void* zeros, float* splitk_scratch, int64_t scratch_elems, int dtype, void* stream) {
+                                const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part,
+                                int dtype, void* stream) {
     if (!x || !w || !y || !zeros || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return FFM_EINVAL;
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
@@ -687,18 +743,9 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
     hipStream_t s = (hipStream_t)stream;
     // Few output tiles and a long K (layer3 / layer4: 14 x 14 and 7 x 7 maps, K = 2304 / 4608): split K over grid.y so
     // that the launch fills the chip; the fp32 partial tiles are summed by one more small kernel.
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
-    if (splitk_scratch && tiles < 160 && nk >= 16 && a.N % 4 == 0) {
-        int S = 512 / tiles;
-        if (S > 8) S = 8;
-        if (S > nk / 4) S = nk / 4;
-        while (S > 1 && (int64_t)S * a.M * a.N > scratch_elems) --S;
-        if (S > 1) {
-            const int per = (nk + S - 1) / S;
-            S = (nk + per - 1) / per;                               // no empty slice
-            ka.ksplit = S; ka.part = splitk_scratch;
-        }
-    }
+    const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems);
+    if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
+    a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: no epilogue, no statistics)
     const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
     if (e || ka.ksplit <= 1) return e;
     const size_t total = (size_t)a.M * a.N, total4 = total / 4;

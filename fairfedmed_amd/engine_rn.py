@@ -61,18 +61,20 @@ class _Lora:
         e = self.eng
         return (e.sops.op(self.prefix), e.cfg.lora.num_groups) if self.fair else (e.ones_s, 1)
 
-    def fwd(self, x: Tensor, W: Tensor, out: Tensor, attr: Optional[Tensor], rps: int, bias=None, res=None) -> None:
+    def fwd(self, x: Tensor, W: Tensor, out: Tensor, attr: Optional[Tensor], rps: int, bias=None, res=None,
+            colstats: Optional[Tensor] = None) -> None:
+        """colstats: the GEMM also leaves the column sums of its row tiles there (the BatchNorm that follows)."""
         e, lo = self.eng, self.eng.cfg.lora
         rows = x.shape[0]
         S, G = self._s()
         attr = attr if self.fair else None
         if self.fused:
             ro = ops.RankOp(self.rkA, S, attr, rps, lo.scaling, lo.lambda_group, t_out=self.t[:rows], ts_out=self.ts[:rows])
-            ops.gemm_nt(x, W, out, bias=bias, lw=e.params.view(self.kB), res=res, rankop=ro)
+            ops.gemm_nt(x, W, out, bias=bias, lw=e.params.view(self.kB), res=res, rankop=ro, colstats=colstats)
             return
         ops.lora_down(x, e.params.view(self.kA), False, S, attr, lo.rank, G, rps, lo.scaling,
                       lo.lambda_group, self.t[:rows], self.ts[:rows])
-        ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res)
+        ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res, colstats=colstats)
 
     def bwd(self, g: Tensor, Wt: Tensor, dx: Tensor, x: Tensor, attr: Optional[Tensor], rps: int, res=None) -> None:
         """g = dL/dy; writes dx = g W (+ LoRA term) (+ res) and the partial sums of dA, dB, dS."""
@@ -111,12 +113,18 @@ class _BN:
         self.run_mean, self.run_var, self.mean, self.rstd = f(), f(), f(), f()
         eng.bn_scratch = max(eng.bn_scratch, ops.bn_blocks(max_rows) * 2 * C)
         eng.bn_cmax = max(eng.bn_cmax, C)
+        t = (max_rows + 127) // 128                                # row tiles of the GEMM that produces this layer's input
+        if t <= 1024:
+            eng.stat_scratch = max(eng.stat_scratch, 2 * t * C)
         eng.bns.append(self)
 
-    def fwd(self, x: Tensor, y: Tensor, relu: bool, res: Optional[Tensor] = None) -> None:
+    def fwd(self, x: Tensor, y: Tensor, relu: bool, res: Optional[Tensor] = None, part: Optional[Tensor] = None,
+            part_rows: int = 0) -> None:
+        """part / part_rows: the column sums the producing GEMM left behind (RN50Engine.stat_buf); else own pass over x."""
         e = self.eng
         ops.bn_fwd(x, e.params.view(self.prefix + "weight"), e.params.view(self.prefix + "bias"), self.run_mean,
-                   self.run_var, self.mean, self.rstd, e.bn_part, y, e.bn_training, relu, res)
+                   self.run_var, self.mean, self.rstd, part if part_rows else e.bn_part, y, e.bn_training, relu, res,
+                   part_rows=part_rows)
 
     def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor) -> None:
         e = self.eng
@@ -172,25 +180,29 @@ class _Bneck:
         Hi, Ho = self.Hin, self.Hout
         ri, ro = images * Hi * Hi, images * Ho * Ho
         z1, a1, z2, a2, z3, out = self.z1[:ri], self.a1[:ri], self.z2[:ri], self.a2[:ri], self.z3[:ro], self.out[:ro]
-        self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi)
-        self.bn1.fwd(z1, a1, True)
-        ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16, e.splitk)          # implicit GEMM: no im2col buffer
-        self.bn2.fwd(z2, a2, True)
+        # BatchNorm statistics (training): the producing GEMM's epilogue leaves the column sums of its row tiles in
+        # stat_buf[k], and the BatchNorm skips its own pass over the tensor (split-K convolutions excepted)
+        sb, nt = e.stat_buf, e.stat_rows
+        t_i, t_o = nt(ri), nt(ro)
+        self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi, colstats=sb[0] if t_i else None)
+        self.bn1.fwd(z1, a1, True, part=sb[0], part_rows=t_i)
+        t2 = ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16, e.splitk, colstats=sb[0] if t_i else None)
+        self.bn2.fwd(z2, a2, True, part=sb[0], part_rows=t2)
         a = a2
         if self.stride > 1:
             a = self.a2p[:ro]
             ops.avgpool2(a2, a, images, Hi, Hi)
-        self.c3.fwd(a, W[p + "w3"], z3, attr, Ho * Ho)
+        self.c3.fwd(a, W[p + "w3"], z3, attr, Ho * Ho, colstats=sb[0] if t_o else None)
         idn = x
         if self.has_down:
             xi = x
             if self.stride > 1:
                 xi = self.xp[:ro]
                 ops.avgpool2(x, xi, images, Hi, Hi)
-            ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro])
+            ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro], colstats=sb[1] if t_o else None)
             idn = self.idn[:ro]
-            self.bnd.fwd(self.zd[:ro], idn, False)
-        self.bn3.fwd(z3, out, True, res=idn)                       # relu(bn3(conv3) + identity)
+            self.bnd.fwd(self.zd[:ro], idn, False, part=sb[1], part_rows=t_o)
+        self.bn3.fwd(z3, out, True, res=idn, part=sb[0], part_rows=t_o)   # relu(bn3(conv3) + identity)
         return out
 
     def backward(self, g: Tensor, x: Tensor, images: int, attr: Optional[Tensor]) -> Tensor:
@@ -241,7 +253,7 @@ class RN50Engine(FairLoRAEngine):
         self.kq = 64 if dt == torch.bfloat16 else 32             # GEMM K granularity (128 bytes)
         self.rnw: Dict[str, Tensor] = {}
         self.bns: List[_BN] = []
-        self.bn_scratch = self.bn_cmax = 0
+        self.bn_scratch = self.bn_cmax = self.stat_scratch = 0
         self.bn_training = False
         self.pack_entries: list = []
         e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)
@@ -283,6 +295,9 @@ class RN50Engine(FairLoRAEngine):
         self.d_o, self.dqkv, self.dtok = e(T, E), e(T, 3 * E), [e(T, E), e(T, E)]
         self.dx4 = e(max_images * v.spacial * v.spacial, E)
         self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
+        # column sums left behind by the GEMMs that produce a BatchNorm's input ([1]: the downsample branch, whose
+        # product sits between conv3 and bn3)
+        self.stat_buf = [torch.zeros(max(self.stat_scratch, 1), device=dev, dtype=torch.float32) for _ in range(2)]
         self.bn_k12 = torch.zeros(2 * self.bn_cmax, device=dev, dtype=torch.float32)
         self.rn_plans: Dict[int, ops.ReducePlan] = {}
         # num_batches_tracked of every BatchNorm2d, in self.bns order (one add per training step for all of them)
@@ -401,6 +416,12 @@ class RN50Engine(FairLoRAEngine):
         return b, S
 
     # ---------------------------------------------------------------- forward --
+    def stat_rows(self, rows: int) -> int:
+        """Row tiles of the 128x128 GEMM over `rows` rows when its epilogue should leave the BatchNorm column sums behind
+        (training mode, at most 1024 partial rows: ffm_bn_fwd's limit); else 0."""
+        t = (rows + 127) // 128
+        return t if (self.bn_training and 0 < t <= 1024 and not getattr(self, "no_colstats", False)) else 0
+
     def _vision_forward(self, b: int, S: int, has_attr: bool, wait=None) -> None:
         cfg, v, W = self.cfg, self.cfg.vision, self.rnw
         H1, H2 = self.H1, self.H2
@@ -411,11 +432,12 @@ class RN50Engine(FairLoRAEngine):
             self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
         if self.sops.glob:
             self._glue(self.sops.prepare)             # S_eff = S + S_global (GLOBAL_S)
-        ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0])
-        self.sbn[0].fwd(sz[0], sa[0], True)
+        t1 = self.stat_rows(r1)
+        ops.gemm_nt(self.cols1[:r1], W["s1"], sz[0], colstats=self.stat_buf[0] if t1 else None)
+        self.sbn[0].fwd(sz[0], sa[0], True, part=self.stat_buf[0], part_rows=t1)
         for i, wn in ((1, "s2"), (2, "s3")):
-            ops.conv3x3(sa[i - 1], W[wn], sz[i], b, H1, H1, self.zero16)
-            self.sbn[i].fwd(sz[i], sa[i], True)
+            ti = ops.conv3x3(sa[i - 1], W[wn], sz[i], b, H1, H1, self.zero16, colstats=self.stat_buf[0] if t1 else None)
+            self.sbn[i].fwd(sz[i], sa[i], True, part=self.stat_buf[0], part_rows=ti)
         x = self.p0[:b * H2 * H2]
         ops.avgpool2(sa[2], x, b, H1, H1)
         for blk in self.blocks:

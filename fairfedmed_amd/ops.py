@@ -135,7 +135,8 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
-            x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None) -> Tensor:
+            x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
+            colstats: Optional[Tensor] = None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
     x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
@@ -191,7 +192,11 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
                L.ptr(ln_in.rk))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
-                      L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx)
+                      L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,
+                      L.ptr(_f32(colstats)))
+    if colstats is not None:                       # [tiles_m, 2, N] fp32 column sums of the stored output (128x128 kernel)
+        _dev(colstats)
+        assert b_packed is None and colstats.numel() >= 2 * N * ((M + 127) // 128)
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
     _call("ffm_gemm_nt", C.byref(args), L.F32_X3 if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
@@ -315,15 +320,22 @@ def col2im3x3(dcols: Tensor, dx: Tensor, B: int, H: int, W: int, stride: int) ->
 
 
 def conv3x3(x: Tensor, w: Tensor, out: Tensor, B: int, H: int, W: int, zeros: Tensor,
-            scratch: Optional[Tensor] = None) -> Tensor:
+            scratch: Optional[Tensor] = None, colstats: Optional[Tensor] = None) -> int:
     """3x3 / pad 1 / stride 1 convolution on NHWC rows as an implicit GEMM (ffm_conv3x3_nhwc): x [B*H*W, C],
-    w [N, Kp] with k = (ky*3 + kx)*C + c, out [B*H*W, N].  scratch: fp32 buffer for split-K partial tiles (optional)."""
-    _dev(x, w, out, zeros, scratch)
+    w [N, Kp] with k = (ky*3 + kx)*C + c, out [B*H*W, N].  scratch: fp32 buffer for split-K partial tiles (optional).
+    colstats: optional fp32 buffer for the column sums of the output's row tiles; returns the number of partial rows
+    written into it (0 when the launch is split over K or colstats is None: the BatchNorm forms its own sums)."""
+    _dev(x, w, out, zeros, scratch, colstats)
     assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
     assert x.shape[0] == B * H * W and tuple(out.shape) == (B * H * W, w.shape[0]) and zeros.numel() * zeros.element_size() >= 16
+    nsc = 0 if scratch is None else scratch.numel()
+    prow = 0
+    if colstats is not None:
+        prow = L.load().ffm_conv3x3_colstat_rows(B, H, W, x.shape[1], w.shape[0], w.shape[1], nsc, L.dtype_code(x.dtype))
+        assert prow >= 0 and _f32(colstats).numel() >= 2 * w.shape[0] * prow
     _call("ffm_conv3x3_nhwc", L.ptr(x), L.ptr(w), L.ptr(out), B, H, W, x.shape[1], w.shape[0], w.shape[1], L.ptr(zeros),
-          L.ptr(_f32(scratch)), 0 if scratch is None else scratch.numel(), L.dtype_code(x.dtype), L.stream_ptr())
-    return out
+          L.ptr(_f32(scratch)), nsc, L.ptr(colstats) if prow > 0 else None, L.dtype_code(x.dtype), L.stream_ptr())
+    return prow
 
 
 def bn_blocks(rows: int) -> int:
@@ -331,13 +343,16 @@ def bn_blocks(rows: int) -> int:
 
 
 def bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, run_mean: Tensor, run_var: Tensor, mean: Tensor, rstd: Tensor,
-           part: Optional[Tensor], y: Tensor, training: bool, relu: bool, res: Optional[Tensor] = None) -> None:
+           part: Optional[Tensor], y: Tensor, training: bool, relu: bool, res: Optional[Tensor] = None,
+           part_rows: int = 0) -> None:
+    """part_rows > 0: `part` already holds that many rows of column sums from the producer of x (gemm_nt / conv3x3
+    colstats): the column-sum pass over x is skipped."""
     _dev(x, gamma, beta, run_mean, run_var, mean, rstd, part, y, res)
     rows, Cc = x.shape
     assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype and (res is None or res.dtype == x.dtype)
     _call("ffm_bn_fwd", L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(_f32(run_mean)), L.ptr(_f32(run_var)),
-          L.ptr(_f32(mean)), L.ptr(_f32(rstd)), L.ptr(_f32(part)), L.ptr(res), L.ptr(y), rows, Cc, int(training), int(relu),
-          L.dtype_code(x.dtype), L.stream_ptr())
+          L.ptr(_f32(mean)), L.ptr(_f32(rstd)), L.ptr(_f32(part)), part_rows if training else 0, L.ptr(res), L.ptr(y), rows, Cc,
+          int(training), int(relu), L.dtype_code(x.dtype), L.stream_ptr())
 
 
 def bn_bwd(dy: Tensor, relu_out: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, part: Tensor,

@@ -44,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -110,6 +110,10 @@ typedef struct ffm_gemm_args {
      * {c_j = sum_k rk[j][k], d_j = sum_k beta_k lora_A[k][j]} (ffm_lora_pack_multi writes both):
      * t = rstd (x rk^T - mu c) + d = LayerNorm(x) lora_A */
     const float* ln_rk;
+    /* optional (128x128 kernel: RN50's 1x1 convolutions): [ffm_gemm_tiles_m][2][N] fp32, the column sums {sum, sum of
+     * squares} of the STORED output over each row tile - the batch statistics of the BatchNorm that follows
+     * (ffm_bn_fwd's part / part_rows), so that it does not read the tensor once more to form them */
+    float*       colstat_part;
 } ffm_gemm_args;
 
 /*
@@ -243,15 +247,21 @@ int ffm_slice_bwd(const void* dcols, const float* img, const float* conv, const 
  * w'[ci][(ky', kx', co)] = w[co][(2 - ky', 2 - kx', ci)]  (clip/model.py:20-24, 241-244 and their autograd).
  */
 int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
-                     const void* zeros, float* splitk_scratch, int64_t scratch_elems, int dtype, void* stream);
+                     const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part, int dtype,
+                     void* stream);
+/* colstat_part (optional): as ffm_gemm_args.colstat_part; written only when the launch is not split over K -
+ * ffm_conv3x3_colstat_rows returns the number of partial rows it will then hold (0: split-K, no statistics) */
+int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int Kp, int64_t scratch_elems, int dtype);
 int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
                     const float* std3, int dtype, void* stream);
 int ffm_im2col3x3(const void* x, void* cols, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);
 int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);
 int ffm_bn_blocks(int rows);
 int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
-               float* rstd, float* part, const void* res, void* y, int rows, int C, int training, int relu, int dtype,
-               void* stream);
+               float* rstd, float* part, int part_rows, const void* res, void* y, int rows, int C, int training, int relu,
+               int dtype, void* stream);
+/* part_rows > 0 (training): part already holds that many partial rows [part_rows][2][C] of column sums written by the
+ * producer of x (colstat_part): the column-sum pass over x is skipped */
 int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
                const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows, int C,
                int dtype, void* stream);

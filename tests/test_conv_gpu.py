@@ -200,3 +200,56 @@ def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, C
     dx = torch.empty(B * H * W, C, device="cuda", dtype=dt)
     ops.conv3x3(nhwc(g), _rows_bwd(w, rup(9 * Co)).to(dt), dx, B, H, W, zeros, scratch)
     assert rel(nchw(dx.float(), B, H, W), xr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (128 * 7, 64, 256), (3 * 49, 2048, 512), (5000, 192, 128)])
+def test_gemm_column_sums_feed_batchnorm(ops, dt, M, N, K):
+    """ffm_gemm_args.colstat_part: the 128x128 kernel leaves sum / sum of squares of each row tile's STORED columns
+    (ragged last tile included); ffm_bn_fwd(part_rows) on them gives the result of its own pass over the tensor."""
+    a, b = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    t = (M + 127) // 128
+    st = torch.full((t, 2, N), float("nan"), device="cuda")
+    ops.gemm_nt(a, b, out, colstats=st)
+    o = out.double()
+    for i in range(t):
+        blk = o[i * 128:(i + 1) * 128]
+        assert rel(st[i, 0], blk.sum(0)) < 1e-5 and rel(st[i, 1], (blk * blk).sum(0)) < 1e-5
+    gamma, beta = 1 + 0.1 * rnd(N, seed=8), 0.1 * rnd(N, seed=9)
+    ys, ms, rs, rms, rvs = [], [], [], [], []
+    for pr in (0, t):
+        mean, rstd = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        part = st.clone().flatten() if pr else torch.empty(ops.bn_blocks(M) * 2 * N, device="cuda")
+        y = torch.empty_like(out)
+        ops.bn_fwd(out, gamma, beta, rm, rv, mean, rstd, part, y, True, True, part_rows=pr)
+        ys.append(y); ms.append(mean); rs.append(rstd); rms.append(rm); rvs.append(rv)
+    assert rel(ms[1], ms[0]) < 1e-5 and rel(rs[1], rs[0]) < 1e-5 and rel(rms[1], rms[0]) < 1e-5 and rel(rvs[1], rvs[0]) < 1e-5
+    assert rel(ys[1], ys[0]) < (1e-5 if dt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_conv3x3_column_sums(ops, dt):
+    """ffm_conv3x3_nhwc(colstat_part): partial rows as ffm_conv3x3_colstat_rows says, none when the launch splits K."""
+    kq = 64 if dt == torch.bfloat16 else 32
+    rup = lambda v: (v + kq - 1) // kq * kq
+    zeros = torch.zeros(64, device="cuda", dtype=dt)
+    for (B, H, C, Co, sc) in [(5, 28, 64, 64, False), (4, 14, 256, 256, True), (2, 16, 32, 64, True)]:
+        x = rnd(B, C, H, H, dt=dt, seed=1)
+        w = rnd(Co, C, 3, 3, dt=dt, scale=1.0 / math.sqrt(9 * C), seed=2)
+        scratch = torch.zeros(8 * B * H * H * max(C, Co), device="cuda") if sc else None
+        M = B * H * H
+        y = torch.empty(M, Co, device="cuda", dtype=dt)
+        st = torch.full(((M + 127) // 128, 2, Co), float("nan"), device="cuda")
+        pr = ops.conv3x3(nhwc(x), _rows_fwd(w, rup(9 * C)).to(dt), y, B, H, H, zeros, scratch, colstats=st)
+        ref = F.conv2d(x.float(), w.float(), padding=1)
+        assert rel(nchw(y.float(), B, H, H), ref) < tol(dt)
+        if (B, H, C) == (4, 14, 256):
+            assert pr == 0 and bool(torch.isnan(st).all())            # 7 x 2 tiles, K = 2304: split over K
+            continue
+        assert pr == (M + 127) // 128
+        o = y.double()
+        for i in range(pr):
+            blk = o[i * 128:(i + 1) * 128]
+            assert rel(st[i, 0], blk.sum(0)) < 1e-5 and rel(st[i, 1], (blk * blk).sum(0)) < 1e-5

@@ -72,7 +72,7 @@ def test_rn_step_vs_oracle_and_golden(golden_dir, dtype, TAG):
     ref_sd = copy.deepcopy(sd)
     loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
     assert rel(out["logits"], logits) < (3e-5 if f32 else bf_tol)
-    worst, wcos = 0.0, 1.0
+    worst, wcos, small = 0.0, 1.0, []
     for k in keys:
         g, ref = eng.params.view(k, "grad"), grads[k]
         if float(ref.abs().max()) == 0.0:
@@ -88,10 +88,17 @@ def test_rn_step_vs_oracle_and_golden(golden_dir, dtype, TAG):
             # the golden vectors were taken on another host CPU, whose convolution kernels round differently: a
             # different near-zero ReLU flips there (layer3.0: 1.9e-2 of conv3.lora_B's scale)
             assert rel(g, gold[f"{TAG}.grad.{k}"]) < 5e-2 and cos(g, gold[f"{TAG}.grad.{k}"]) > 1 - 1e-3, k
+        elif g.numel() >= 64:
+            # direction only (kernels: test_rn_bf16_backward_*); the 6-block geometry drifts further (measured >= 0.71)
+            assert cos(g, ref) > (0.6 if TAG == "rn_tiny_r4g2" else 0.5), (k, cos(g, ref), e)
         else:
-            # direction only (kernels: test_rn_bf16_backward_*); the 6-block geometry drifts further: its 8-element dS
-            # tensors reach 0.40
-            assert cos(g, ref) > (0.6 if TAG == "rn_tiny_r4g2" else 0.3), (k, cos(g, ref), e)
+            small.append(k)
+    if small:
+        # the 8-element dS tensors: at 6 images a single one of them carries no direction in bf16 -- the same step with
+        # the BatchNorm sums added in another order moves layer3.1.conv3.lora_S from cosine 0.41 to 0.25 while the two
+        # runs agree with each other to 0.97 (tools/rn_bf16_diag.py) -- so they are judged together (measured 0.79)
+        cat = lambda f: torch.cat([torch.as_tensor(f(k)).double().cpu().flatten() for k in small])
+        assert cos(cat(lambda k: eng.params.view(k, "grad")), cat(lambda k: grads[k])) > 0.6
     print(TAG, dtype, "worst grad err", worst, "worst cosine", wcos)
     # BatchNorm running statistics moved exactly as nn.BatchNorm2d moves them (momentum 0.1, unbiased variance)
     bufs = eng.buffer_state()
