@@ -108,7 +108,7 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.ffm_sgd_momentum(L.ptr(f), L.ptr(f), None, 64, C_.c_float(0.1), C_.c_float(0.9), C_.c_float(0.0), 1, st) == -1
     assert lib.ffm_eval_counts(L.ptr(f), L.ptr(f), None, 0, 2, L.ptr(f), st) == -1    # N = 0
     assert lib.ffm_expand_u8(L.ptr(f), L.ptr(f), 1, 1, 6, 1, st) == -1                # HW % 4 != 0
-    assert lib.ffm_bn_fwd(L.ptr(x), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), None, None, L.ptr(x), 64, 64,
+    assert lib.ffm_bn_fwd(L.ptr(x), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), L.ptr(f), None, 0, None, L.ptr(x), 64, 64,
                           1, 0, 1, st) == -1                                           # training without scratch
     torch.cuda.synchronize()
 

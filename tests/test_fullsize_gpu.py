@@ -58,8 +58,12 @@ def test_full_rn50_step_vs_oracle(dtype):
     print("rn50", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
     assert int(out["finite"]) == 1
     assert abs(float(out["loss"]) - float(loss)) <= (1e-4 if f32 else 0.1) * abs(float(loss))
-    # 53 convolutions + train-mode BatchNorm at batch 4: logits agree to 1.5e-4 of their scale (loss to 4e-6)
-    assert rel(out["logits"], logits) < (5e-4 if f32 else 0.3)
+    # 53 convolutions + train-mode BatchNorm at batch 4: logits agree to 1.5e-4 of their scale (loss to 4e-6).  This
+    # random-weight trunk amplifies a perturbation ~1.5x per Bottleneck (tools/rn_colstat_diag.py: the fp32 step with the
+    # BatchNorm sums added in another order differs by 5e-7 after block 0 and 7e-5 after block 15; in bf16 the same two
+    # orders differ from each other by 0.30 of the logit scale), so the bf16 logits carry no tighter bound than this;
+    # the bf16 kernels themselves are held per layer in test_engine_rn_gpu.py / test_conv_gpu.py
+    assert rel(out["logits"], logits) < (5e-4 if f32 else 0.75)
     if f32:
         worst, werr = 1.0, 0.0
         for k in keys:

@@ -19,6 +19,8 @@ args = (batch["img"].cuda(), batch["attrs"].t()[0].cuda(), batch["label"].cuda()
 t0 = time.time()
 eng = create_engine(mcfg, sd, dtype=dtype, max_images=bs)
 torch.cuda.synchronize()
+if os.environ.get("FFM_SERIAL"):                       # one stream, one kernel at a time: clean per-kernel durations
+    eng.set_overlap(False)
 if not JSON:
     print(f"engine built in {time.time() - t0:.1f}s, {torch.cuda.memory_allocated() / 2**30:.2f} GiB, "
           f"{eng.params.numel} trainable elements")
@@ -51,3 +53,13 @@ if JSON:
                       "trainable_elems": eng.params.numel, "final_loss": float(eng.loss)}))
     sys.exit(0)
 print(f"RN50 r=8 G=2 bs={bs} {dtype}: {ms:.2f} ms/step, {bs / ms * 1e3:.0f} img/s, loss {float(eng.loss):.4f}")
+# host enqueue time of one step (the GPU idle): how close the step is to being launch-bound
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(5):
+    eng.forward_backward(*args); eng.sgd_step(1e-3, 0.9, 5e-4, repeats=2)
+    te = time.time()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    print(f"  enqueue {1e3 * (te - t0):.2f} ms, until done {1e3 * (t1 - t0):.2f} ms")
+    t0 = time.time()
