@@ -480,7 +480,7 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
     hipStream_t s = (hipStream_t)stream;
     if (training && part_rows > 0) {
         // the producer of x left the column sums of its row tiles behind (ffm_gemm_args.colstat_part)
-        if (part_rows > CS_MAXBLK) return FFM_EINVAL;
+        if (part_rows > 4096) return FFM_EINVAL;
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, part_rows, rows, C, mean, rstd, run_mean,
                            run_var, 0.1f, 1e-5f);
     } else if (training) {

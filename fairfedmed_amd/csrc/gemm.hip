@@ -703,6 +703,150 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 namespace {
+// ---- 3x3 convolutions with FEW output channels (N = 32 / 64: RN50's stem and layer1), where a 128-wide tile spends
+// half or three quarters of its MFMAs on padding: block tile 128 x NB, wave w owns rows [32 w, 32 w + 32) x all NB columns,
+// A through the implicit-im2col loader above, the whole weight K-tile (NB rows x 128 B) beside it, two LDS buffers,
+// three blocks per CU.  Epilogue: plain store through LDS (8-element row segments) + optional column sums of the STORED
+// values (colstat_part, as the 128x128 kernel writes them) taken straight from the accumulators.
+template <typename T, int NB>
+__global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
+    const ffm_gemm_args& p = px.g;
+    typedef typename Mma16<T>::frag_t frag_t;
+    constexpr int NF = NB / 16;
+    constexpr int WT_BYTES = NB * KT_BYTES;           // weight K-tile
+    constexpr int BUFN = TILE_BYTES + WT_BYTES;
+    constexpr int CLD = NB + 4;                       // padded f32 row of the C stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = tm * BM, n0 = blockIdx.y * NB;     // N % NB == 0 (checked by the launcher)
+    const int nk = (int)((size_t)p.K * sizeof(T) / KT_BYTES);
+    const int rsub = lane >> 3, slot = lane & 7;
+    const char* Wb = reinterpret_cast<const char*>(p.b) + (size_t)n0 * (size_t)p.ldb * sizeof(T);
+
+    auto stage_w = [&](int kbyte0, char* dst) {       // NB / 8 wave-instructions of 1 KiB, NB / 32 per wave
+#pragma unroll
+        for (int q = 0; q < NB / 32; ++q) {
+            const int inst = wave * (NB / 32) + q;
+            const int row = inst * 8 + rsub;
+            const char* src = Wb + (size_t)row * (size_t)p.ldb * sizeof(T) + kbyte0 + ((slot ^ rsub) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    ConvA<T> cva;
+    cva.init(px, m0, wave, lane, 0);
+    cva.stage(px, smem, wave);
+    stage_w(0, smem + TILE_BYTES);
+    __syncthreads();
+
+    const int frow = lane & 15, fgrp = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const char* As = smem + cur * BUFN;
+        const char* Bs = As + TILE_BYTES;
+        if (kt + 1 < nk) {
+            char* An = smem + (cur ^ 1) * BUFN;
+            cva.stage(px, An, wave);
+            stage_w((kt + 1) * KT_BYTES, An + TILE_BYTES);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + fgrp;
+            frag_t af[2], bf[NF];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wave * 32 + i * 16 + frow;
+                af[i] = *reinterpret_cast<const frag_t*>(As + ra * KT_BYTES + ((chunk ^ (ra & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int rb = j * 16 + frow;
+                bf[j] = *reinterpret_cast<const frag_t*>(Bs + rb * KT_BYTES + ((chunk ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) Mma16<T>::mma(acc[i][j], af[i], bf[j]);
+        }
+        __syncthreads();   // next tile landed (the compiler drains vmcnt before the barrier); cur is free
+    }
+
+    // ---- epilogue: accumulators -> LDS [128][CLD] f32 -> 8-element row segments
+    float* Cs = reinterpret_cast<float*>(smem);
+    float* Red = Cs + BM * CLD;                       // column sums of the four waves [2][4][NB]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Cs[(wave * 32 + i * 16 + fgrp * 4 + e) * CLD + j * 16 + frow] = acc[i][j][e];
+    if (p.colstat_part) {
+        // lane (frow, fgrp) holds column j*16 + frow of rows fgrp*4 + e: its 8 rows, then the 4 row groups of the wave
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + wave * 32 + i * 16 + fgrp * 4 + e;
+                    const float st = row < p.M ? Elem<T>::to_f(Elem<T>::from_f(acc[i][j][e])) : 0.f;
+                    s0 += st;
+                    s1 += st * st;
+                }
+            s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+            s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+            if (fgrp == 0) {
+                Red[wave * NB + j * 16 + frow] = s0;
+                Red[(4 + wave) * NB + j * 16 + frow] = s1;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int VN = 8;                         // elements per row segment (16 B of bf16, 32 B of f32)
+        constexpr int CPR = NB / VN;                  // segments per row
+        constexpr int RPP = 256 / CPR;                // rows per pass
+        T* C = reinterpret_cast<T*>(p.c);
+        const int cseg = tid % CPR, r0 = tid / CPR;
+#pragma unroll
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+            const int row = ps * RPP + r0;
+            if (m0 + row < p.M) {
+                float v[VN];
+#pragma unroll
+                for (int c = 0; c < VN; ++c) v[c] = Cs[row * CLD + cseg * VN + c];
+                Vec8<T>::store(C + (size_t)(m0 + row) * p.ldc + n0 + cseg * VN, v);
+            }
+        }
+    }
+    if (p.colstat_part && tid < NB) {
+        const float s0 = (Red[tid] + Red[NB + tid]) + (Red[2 * NB + tid] + Red[3 * NB + tid]);
+        const float s1 = (Red[4 * NB + tid] + Red[5 * NB + tid]) + (Red[6 * NB + tid] + Red[7 * NB + tid]);
+        p.colstat_part[((size_t)tm * 2) * p.N + n0 + tid] = s0;
+        p.colstat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = s1;
+    }
+}
+
+template <typename T, int NB>
+int launch_conv_narrow(const gemm_kargs& ka, hipStream_t s) {
+    constexpr int ring = 2 * (TILE_BYTES + NB * KT_BYTES), epi = BM * (NB + 4) * 4 + 8 * NB * 4;
+    const int tiles = (ka.g.M + BM - 1) / BM;
+    hipLaunchKernelGGL((conv_narrow_kernel<T, NB>), dim3(tiles, ka.g.N / NB), dim3(256), ring > epi ? ring : epi, s, ka);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
 // K slices ffm_conv3x3_nhwc will use (1: one launch with the full epilogue)
 int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_elems) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
@@ -746,6 +890,16 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
     const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems);
     if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
     a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: no epilogue, no statistics)
+    // The stem and layer1 (N = 32 / 64): 128 x N tiles, three blocks per CU (81 -> 33 / 43 us at 112 x 112, 40 -> 25 us at
+    // 56 x 56).  FFM_CONV_NARROW=off: the 128x128 kernel (A/B runs); FFM_CONV_NARROW=<t>: also N = 128 / 256 / ... as 64-wide
+    // column tiles when the launch has fewer than t 128x128 tiles (measured at t = 512 / 1000 on RN50 bs 32: no gain)
+    const int t128 = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const char* nenv = getenv("FFM_CONV_NARROW");
+    static const int narrow_max = nenv ? (nenv[0] == 'o' ? -1 : atoi(nenv)) : 0;
+    if (S == 1 && narrow_max >= 0 && (a.N == 32 || a.N == 64 || (a.N % 64 == 0 && t128 < narrow_max))) {
+        if (a.N == 32) return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 32>(ka, s) : launch_conv_narrow<float, 32>(ka, s);
+        return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 64>(ka, s) : launch_conv_narrow<float, 64>(ka, s);
+    }
     const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
     if (e || ka.ksplit <= 1) return e;
     const size_t total = (size_t)a.M * a.N, total4 = total / 4;

@@ -114,7 +114,7 @@ class _BN:
         eng.bn_scratch = max(eng.bn_scratch, ops.bn_blocks(max_rows) * 2 * C)
         eng.bn_cmax = max(eng.bn_cmax, C)
         t = (max_rows + 127) // 128                                # row tiles of the GEMM that produces this layer's input
-        if t <= 1024:
+        if t <= 4096:
             eng.stat_scratch = max(eng.stat_scratch, 2 * t * C)
         eng.bns.append(self)
 
@@ -418,9 +418,9 @@ class RN50Engine(FairLoRAEngine):
     # ---------------------------------------------------------------- forward --
     def stat_rows(self, rows: int) -> int:
         """Row tiles of the 128x128 GEMM over `rows` rows when its epilogue should leave the BatchNorm column sums behind
-        (training mode, at most 1024 partial rows: ffm_bn_fwd's limit); else 0."""
+        (training mode, at most 4096 partial rows: ffm_bn_fwd's limit); else 0."""
         t = (rows + 127) // 128
-        return t if (self.bn_training and 0 < t <= 1024 and not getattr(self, "no_colstats", False)) else 0
+        return t if (self.bn_training and 0 < t <= 4096 and not getattr(self, "no_colstats", False)) else 0
 
     def _vision_forward(self, b: int, S: int, has_attr: bool, wait=None) -> None:
         cfg, v, W = self.cfg, self.cfg.vision, self.rnw

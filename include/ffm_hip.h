@@ -260,7 +260,7 @@ int ffm_bn_blocks(int rows);
 int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* mean,
                float* rstd, float* part, int part_rows, const void* res, void* y, int rows, int C, int training, int relu,
                int dtype, void* stream);
-/* part_rows > 0 (training): part already holds that many partial rows [part_rows][2][C] of column sums written by the
+/* part_rows > 0 (training, at most 4096): part already holds that many partial rows [part_rows][2][C] of column sums written by the
  * producer of x (colstat_part): the column-sum pass over x is skipped */
 int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
                const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows, int C,

@@ -253,3 +253,14 @@ def test_conv3x3_column_sums(ops, dt):
         for i in range(pr):
             blk = o[i * 128:(i + 1) * 128]
             assert rel(st[i, 0], blk.sum(0)) < 1e-5 and rel(st[i, 1], (blk * blk).sum(0)) < 1e-5
+
+
+def test_narrow_conv_tiles_on_wide_outputs():
+    """FFM_CONV_NARROW=<t> (read once per process) sends N = 128 / 256 / 512 convolutions through the 128 x 64 tile kernel as
+    several column tiles: the implicit-GEMM and column-sum tests again in a child process with that switch."""
+    import os, subprocess, sys
+    env = dict(os.environ, FFM_CONV_NARROW="1000000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_conv_gpu.py"), "-k",
+                        "implicit_gemm or column_sums"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
