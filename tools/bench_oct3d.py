@@ -21,6 +21,8 @@ B, S = 4, 25
 batch = synth.make_batch(mcfg, B, seed=3, slices=S, signal=0.2)
 img, attr, label = batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
 eng = FairLoRAEngine(mcfg, sd, dtype=torch.bfloat16, max_images=B * S)
+if os.environ.get("FFM_SERIAL"):                       # one stream, one kernel at a time: clean per-kernel durations
+    eng.set_overlap(False)
 if not JSON:
     print("input", tuple(img.shape), "->", B * S, "ViT images")
     ref = FairLoRAEngine(mcfg, sd, dtype=torch.float32, max_images=B * S)
