@@ -114,7 +114,10 @@ struct ConvA {
 
 // FL >= 0: the epilogue flags are a compile-time constant (the combinations the engine uses are
 // instantiated below, so the epilogue is straight-line code); FL < 0: generic, flags read at run time.
-template <typename T, bool RK, int FL, bool CV = false>
+// VL: the rank-r update on the VALU (rank > 16, generic flags only).  Its 64-register LoRA tile pushes every instantiation
+// that carries it into scratch (30 spilled registers in the epilogue, +8 us per launch on RN50's short-K products), so
+// the rank <= 16 variants - the MFMA update - are compiled without it.
+template <typename T, bool RK, int FL, bool CV = false, bool VL = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     const ffm_gemm_args& p = px.g;
     typedef typename Mma16<T>::frag_t frag_t;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     // rank <= 16: the rank-r update acc += ts . lw runs on the MFMA pipe right after the main loop (operands
     // as 64-byte rows: 32 bf16 / 16 f32 rank slots, zero padded); larger ranks use the VALU update in the epilogue
     constexpr int KE = 64 / (int)sizeof(T);
-    const bool lora_mma = has_lora && r <= 16;
+    const bool lora_mma = has_lora && !VL;
     float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);     // LoRA matrix tile [r][BN] (VALU path)
     T* LwB = reinterpret_cast<T*>(smem + 2 * BUF);            // LoRA matrix tile, transposed [BN][KE] (MFMA path)
     const int ls_bytes = r * BN * 4 > BN * 64 ? r * BN * 4 : (r ? BN * 64 : 0);
@@ -194,20 +197,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
         // All global loads of a fill are issued before the first LDS store (a load -> store loop pays one
         // memory round trip per iteration).
         if (lora_mma) {
-            // thread -> column n = tid & 127 and rank slots j = (tid >> 7) + 2 it: no integer division, and all
-            // loads are in flight before the first LDS store
-            const int fn = tid & 127, fj0 = tid >> 7;
+            // thread -> column n = tid & 127 and the eight rank slots [8q, 8q + 8), q = tid >> 7: all loads in flight before
+            // the LDS store, and the tile row [KE] is written as whole 8-element segments (2-byte stores at a 64-byte
+            // lane stride were a 16-way bank conflict, and the LDS pipe is shared by the CU's eight waves)
+            const int fn = tid & 127, q = tid >> 7;
             float tmp[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int j = fj0 + 2 * it;
-                tmp[it] = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                const int j = 8 * q + e;
+                tmp[e] = 0.f;
                 if (j < r && n0 + fn < p.N)
-                    tmp[it] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+                    tmp[e] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
             }
-#pragma unroll
-            for (int it = 0; it < KE / 2; ++it)           // j < 16 carry values (or zeros), the rest is padding
-                LwB[fn * KE + fj0 + 2 * it] = Elem<T>::from_f(it < 8 ? tmp[it < 8 ? it : 0] : 0.f);
+            Vec8<T>::store(LwB + fn * KE + 8 * q, tmp);
+            if constexpr (KE > 16) {                       // slots 16 .. KE are padding
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                Vec8<T>::store(LwB + fn * KE + 16 + 8 * q, z);
+            }
         } else {
             for (int idx0 = tid; idx0 < r * BN; idx0 += 256 * 8) {
                 float tmp[8];
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
                 Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
             }
-        } else {
+        } else if (!lora_mma) {
             const int frow_ = tid & 127, fj0 = tid >> 7;
             const int gm = m0 + frow_;
             for (int jb = 0; jb < r; jb += 16) {
@@ -246,6 +252,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     if (j < r) TsAll[frow_ * r + j] = tmp[it];
                 }
             }
+        }
+    }
+    // non-RANKOP, r <= 16: row tid & 127's ts values for slots [8q, 8q + 8) stay in registers until the rank-r update
+    float tsr[8];
+    if constexpr (!RK) {
+        const int gm = m0 + (tid & 127), q = tid >> 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            tsr[e] = (lora_mma && 8 * q + e < r && gm < p.M) ? p.ts[(size_t)gm * r + 8 * q + e] : 0.f;
+    }
+
+    // dS partials (backward, first column tile): this thread's t_fwd values, element idx = tid + 256 it of the tile's
+    // [128][r] block - loaded now so that their latency hides behind the main loop
+    const bool do_ds = RK && (tn == 0) && p.t_fwd && p.ds_part;
+    float tfv[8];
+    if constexpr (RK) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + 256 * it, gm = m0 + idx / (r > 0 ? r : 1);
+            tfv[it] = (do_ds && idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
         }
     }
 
@@ -311,9 +337,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     float* Ts = Cs + CS_ROWS * CS_LD;                 // ts rows of the current half [64][rp8]
     float* Tt = Ts + CS_ROWS * rp8;                   // RANKOP: t tile [128][16]
     T* C = reinterpret_cast<T*>(p.c);
+    const float mix_u = 1.0f / (float)p.G, mix_o = (1.0f - p.lambda_group) / (float)(p.G - 1);
     auto mixw = [&](int row, int g) -> float {        // pi_b[g] of the sample that owns tile row `row`
         const int a = Ga[row];
-        return a < 0 ? 1.0f / (float)p.G : (a == g ? p.lambda_group : (1.0f - p.lambda_group) / (float)(p.G - 1));
+        return a < 0 ? mix_u : (a == g ? p.lambda_group : mix_o);
     };
     if constexpr (RK) {
 #pragma unroll
@@ -321,33 +348,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 Tt[(wm * 64 + (2 * wn + ii) * 16 + fgrp * 4 + e) * RK_ROWS + frow] = tacc[ii][e];
-        const bool do_ds = (tn == 0) && p.t_fwd && p.ds_part;
+        __syncthreads();                              // Tt complete
         if (do_ds) {
-            // Wv[row][j] = scaling * t_fwd * t, staged in the (still free) C-stage region
-            __syncthreads();                          // Tt complete
-            for (int idx0 = tid; idx0 < BM * r; idx0 += 256 * 8) {
-                float tmp[8];
+            // dS partial of this row tile: sum_rows pi_b[g] * scaling * t_fwd * t.  Element idx = tid + 256 it is
+            // (row idx / r, slot idx % r); with r a power of two a thread keeps ONE slot, so its rows add up in registers,
+            // the lanes of a slot by shuffles, the four waves through LDS (any other r: one thread per (g, slot))
+            float* Red = Cs;                          // [4][G * r]
+            if ((r & (r - 1)) == 0) {
+                float wv[8];
+                int rw[8];
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int idx = idx0 + 256 * it;
-                    const int gm = m0 + idx / r;
-                    tmp[it] = (idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
+                    const int idx = tid + 256 * it;
+                    rw[it] = idx < BM * r ? idx / r : -1;
+                    wv[it] = rw[it] >= 0 ? p.scaling * tfv[it] * Tt[rw[it] * RK_ROWS + (idx & (r - 1))] : 0.f;
                 }
+                for (int g = 0; g < p.G; ++g) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        if (rw[it] >= 0) sacc += mixw(rw[it], g) * wv[it];
+                    for (int o = r; o < 64; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+                    if (lane < r) Red[wave * (p.G * r) + g * r + lane] = sacc;
+                }
+                __syncthreads();
+                if (tid < p.G * r)
+                    p.ds_part[(size_t)tm * p.G * r + tid] = (Red[tid] + Red[p.G * r + tid]) + (Red[2 * p.G * r + tid] + Red[3 * p.G * r + tid]);
+            } else {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int idx = idx0 + 256 * it;
-                    if (idx < BM * r) Cs[idx] = p.scaling * tmp[it] * Tt[(idx / r) * RK_ROWS + idx % r];
+                    const int idx = tid + 256 * it;
+                    if (idx < BM * r) Cs[idx] = p.scaling * tfv[it] * Tt[(idx / r) * RK_ROWS + idx % r];
                 }
-            }
-        }
-        __syncthreads();                              // Tt (and Wv) visible
-        if (do_ds) {
-            if (tid < p.G * r) {
-                // dS partial of this row tile: sum_rows pi_b[g] * scaling * t_fwd * t
-                const int g = tid / r, j = tid % r;
-                float sacc = 0.f;
-                for (int row = 0; row < BM; ++row) sacc += mixw(row, g) * Cs[row * r + j];
-                p.ds_part[((size_t)tm * p.G + g) * r + j] = sacc;
+                __syncthreads();
+                if (tid < p.G * r) {
+                    const int g = tid / r, j = tid % r;
+                    float sacc = 0.f;
+                    for (int row = 0; row < BM; ++row) sacc += mixw(row, g) * Cs[row * r + j];
+                    p.ds_part[((size_t)tm * p.G + g) * r + j] = sacc;
+                }
             }
             __syncthreads();                          // Cs is reused by the halves below
         }
@@ -355,27 +394,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     if (lora_mma) {
         T* TsA = reinterpret_cast<T*>(Tt + (RK ? BM * RK_ROWS : 0));      // ts tile [BM][KE], zero padded
         {
-            const int row = tid & 127, fj0 = tid >> 7;
+            // thread -> tile row tid & 127, rank slots [8q, 8q + 8): one 8-element segment per thread (+ one of padding)
+            const int row = tid & 127, q = tid >> 7;
             const int gm = m0 + row;
+            float tsv[8];
 #pragma unroll
-            for (int it = 0; it < KE / 2; ++it) {
-                const int j = fj0 + 2 * it;
-                float tsv = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                const int j = 8 * q + e;
+                tsv[e] = 0.f;
                 if (j < r && gm < p.M) {
                     if constexpr (RK) {
                         const float tv = Tt[row * RK_ROWS + j];
                         float sb = 0.f;
                         for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
-                        tsv = p.scaling * tv * sb;
+                        tsv[e] = p.scaling * tv * sb;
                         if (tn == 0) {
                             if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
-                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv;
+                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv[e];
                         }
                     } else {
-                        tsv = TsAll[row * r + j];
+                        tsv[e] = tsr[e];
                     }
                 }
-                TsA[row * KE + j] = Elem<T>::from_f(tsv);
+            }
+            Vec8<T>::store(TsA + row * KE + 8 * q, tsv);
+            if constexpr (KE > 16) {
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                Vec8<T>::store(TsA + row * KE + 16 + 8 * q, z);
             }
         }
         __syncthreads();
@@ -466,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     for (int c = 0; c < 4; ++c) { v[i][c] = c0[c] + b0[c]; v[i][4 + c] = c1[c] + b1[c]; }
                 }
             }
-            if (has_lora && !lora_mma) {
+            if constexpr (VL) if (has_lora) {
                 // rank-r update (rank > 16): this thread's 8 columns of the LoRA matrix stay in registers
                 for (int j0 = 0; j0 < r; j0 += 8) {
                     float lreg[8][8];
@@ -547,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     }
 }
 
-template <typename T, bool RK, int FL, bool CV = false>
+template <typename T, bool RK, int FL, bool CV = false, bool VL = false>
 int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = nullptr) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int r = (a.flags & FFM_EPI_LORA) ? a.rank : 0;
@@ -557,7 +602,7 @@ int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = 
     if (lds > 65536) {
         static bool done = false;                     // one per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL, CV>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL, CV, VL>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return (int)e;
             done = true;
@@ -566,7 +611,7 @@ int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = 
     gemm_kargs ka;
     if (conv) ka = *conv;
     else { ka.g = a; ka.conv_h = ka.conv_w = ka.conv_c = 0; ka.conv_zero = nullptr; ka.ksplit = 1; ka.part = nullptr; }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV>), dim3(tiles, ka.ksplit > 1 ? ka.ksplit : 1), dim3(256), lds, s, ka);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV, VL>), dim3(tiles, ka.ksplit > 1 ? ka.ksplit : 1), dim3(256), lds, s, ka);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -658,6 +703,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);
     }
     const int fl = a.flags & ~FFM_EPI_RANKOP;
+    if ((fl & FFM_EPI_LORA) && a.rank > 16) {                             // rank-r update on the VALU: generic-flag kernels
+        if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1, false, true>(a, s) : launch_gemm<float, true, -1, false, true>(a, s);
+        return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1, false, true>(a, s) : launch_gemm<float, false, -1, false, true>(a, s);
+    }
 #define FFM_GEMM_CASE(RKB, F) \
     case F: return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
     if (rk) {
