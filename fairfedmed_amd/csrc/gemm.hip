@@ -192,29 +192,71 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
     float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
     int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
-    if (tid < BN) Bias[tid] = ((flags & FFM_EPI_BIAS) && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
-    if (has_lora) {
-        // All global loads of a fill are issued before the first LDS store (a load -> store loop pays one
-        // memory round trip per iteration).
-        if (lora_mma) {
-            // thread -> column n = tid & 127 and the eight rank slots [8q, 8q + 8), q = tid >> 7: all loads in flight before
-            // the LDS store, and the tile row [KE] is written as whole 8-element segments (2-byte stores at a 64-byte
-            // lane stride were a 16-way bank conflict, and the LDS pipe is shared by the CU's eight waves)
-            const int fn = tid & 127, q = tid >> 7;
-            float tmp[8];
+    // Every global load of these operands is ISSUED before the first LDS store of any of them: a load -> store -> load ->
+    // store sequence pays one memory round trip per operand (bias, LoRA tile, lora_S, group ids: four in a row, and a
+    // short-K product has no main loop to hide them behind).
+    float bias_v = 0.f, sg_v = 0.f, lwv[8];
+    int ga_v = -1;
+    if (tid < BN && (flags & FFM_EPI_BIAS) && n0 + tid < p.N) bias_v = p.bias[n0 + tid];
+    {
+        // LoRA tile (MFMA path): thread -> column n = tid & 127 and the eight rank slots [8q, 8q + 8), q = tid >> 7
+        const int fn = tid & 127, q = tid >> 7;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int j = 8 * q + e;
-                tmp[e] = 0.f;
-                if (j < r && n0 + fn < p.N)
-                    tmp[e] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * q + e;
+            lwv[e] = 0.f;
+            if (lora_mma && j < r && n0 + fn < p.N)
+                lwv[e] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+        }
+    }
+    if constexpr (RK) {
+        if (has_lora) {
+            if (tid < p.G * r) sg_v = p.S[tid];
+            if (tid < BM && p.attr) {
+                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+                ga_v = p.attr[gm / p.rows_per_sample];
             }
-            Vec8<T>::store(LwB + fn * KE + 8 * q, tmp);
-            if constexpr (KE > 16) {                       // slots 16 .. KE are padding
-                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                Vec8<T>::store(LwB + fn * KE + 16 + 8 * q, z);
-            }
-        } else {
+        }
+    }
+    // non-RANKOP, r <= 16: row tid & 127's ts values for slots [8q, 8q + 8) stay in registers until the rank-r update
+    float tsr[8];
+    if constexpr (!RK) {
+        const int gm = m0 + (tid & 127), q = tid >> 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            tsr[e] = (lora_mma && 8 * q + e < r && gm < p.M) ? p.ts[(size_t)gm * r + 8 * q + e] : 0.f;
+    }
+    // dS partials (backward, first column tile): this thread's t_fwd values, element idx = tid + 256 it of the tile's
+    // [128][r] block - loaded now so that their latency hides behind the main loop
+    const bool do_ds = RK && (tn == 0) && p.t_fwd && p.ds_part;
+    float tfv[8];
+    if constexpr (RK) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + 256 * it, gm = m0 + idx / (r > 0 ? r : 1);
+            tfv[it] = (do_ds && idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
+        }
+    }
+    // ---- the LDS stores
+    if (tid < BN) Bias[tid] = bias_v;
+    if (lora_mma) {
+        // the tile row [KE] is written as whole 8-element segments (2-byte stores at a 64-byte lane stride were a 16-way
+        // bank conflict, and the LDS pipe is shared by the CU's eight waves)
+        const int fn = tid & 127, q = tid >> 7;
+        Vec8<T>::store(LwB + fn * KE + 8 * q, lwv);
+        if constexpr (KE > 16) {                           // slots 16 .. KE are padding
+            const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            Vec8<T>::store(LwB + fn * KE + 16 + 8 * q, z);
+        }
+    }
+    if constexpr (RK) {
+        if (has_lora) {
+            if (tid < p.G * r) Sg[tid] = sg_v;
+            if (tid < BM) Ga[tid] = ga_v;
+        }
+    }
+    if constexpr (VL) {
+        if (has_lora) {                                    // rank > 16: fp32 LoRA tile [r][BN] and (non-RANKOP) the ts rows
             for (int idx0 = tid; idx0 < r * BN; idx0 += 256 * 8) {
                 float tmp[8];
 #pragma unroll
@@ -229,49 +271,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 for (int it = 0; it < 8; ++it)
                     if (idx0 + 256 * it < r * BN) Ls[idx0 + 256 * it] = tmp[it];
             }
-        }
-        if constexpr (RK) {
-            if (tid < p.G * r) Sg[tid] = p.S[tid];
-            if (tid < BM) {
-                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
-                Ga[tid] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
-            }
-        } else if (!lora_mma) {
-            const int frow_ = tid & 127, fj0 = tid >> 7;
-            const int gm = m0 + frow_;
-            for (int jb = 0; jb < r; jb += 16) {
-                float tmp[8];
+            if constexpr (!RK) {
+                const int frow_ = tid & 127, fj0 = tid >> 7;
+                const int gm = m0 + frow_;
+                for (int jb = 0; jb < r; jb += 16) {
+                    float tmp[8];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int j = jb + fj0 + 2 * it;
-                    tmp[it] = (j < r && gm < p.M) ? p.ts[(size_t)gm * r + j] : 0.f;
-                }
+                    for (int it = 0; it < 8; ++it) {
+                        const int j = jb + fj0 + 2 * it;
+                        tmp[it] = (j < r && gm < p.M) ? p.ts[(size_t)gm * r + j] : 0.f;
+                    }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int j = jb + fj0 + 2 * it;
-                    if (j < r) TsAll[frow_ * r + j] = tmp[it];
+                    for (int it = 0; it < 8; ++it) {
+                        const int j = jb + fj0 + 2 * it;
+                        if (j < r) TsAll[frow_ * r + j] = tmp[it];
+                    }
                 }
             }
-        }
-    }
-    // non-RANKOP, r <= 16: row tid & 127's ts values for slots [8q, 8q + 8) stay in registers until the rank-r update
-    float tsr[8];
-    if constexpr (!RK) {
-        const int gm = m0 + (tid & 127), q = tid >> 7;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            tsr[e] = (lora_mma && 8 * q + e < r && gm < p.M) ? p.ts[(size_t)gm * r + 8 * q + e] : 0.f;
-    }
-
-    // dS partials (backward, first column tile): this thread's t_fwd values, element idx = tid + 256 it of the tile's
-    // [128][r] block - loaded now so that their latency hides behind the main loop
-    const bool do_ds = RK && (tn == 0) && p.t_fwd && p.ds_part;
-    float tfv[8];
-    if constexpr (RK) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = tid + 256 * it, gm = m0 + idx / (r > 0 ? r : 1);
-            tfv[it] = (do_ds && idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
         }
     }
 
