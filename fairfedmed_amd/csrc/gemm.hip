@@ -38,7 +38,7 @@ __host__ __device__ constexpr int epi_lds_bytes(int r, bool rk) {
 }
 __host__ __device__ constexpr int persist_bytes(int r, bool rk) {
     const int ls = r * BN * 4 > BN * 64 ? r * BN * 4 : (r ? BN * 64 : 0);   // Ls [r][128] f32, or LwB [128][64 B]
-    return ls + BN * 4 + (rk ? 256 * 4 + BM * 4 : BM * r * 4);
+    return ls + BN * 4 + (rk ? 256 * 4 + BM * 4 + 272 * 4 : BM * r * 4);    // (rk: lora_S, group ids, the s_b table)
 }
 
 template <typename T>
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
     float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
     int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
+    float* SBt = reinterpret_cast<float*>(Ga + BM);           // RANKOP: s_b of every group mix [(G + 1)][r]: row 0 uniform, row 1 + a for group a
     // Every global load of these operands is ISSUED before the first LDS store of any of them: a load -> store -> load ->
     // store sequence pays one memory round trip per operand (bias, LoRA tile, lora_S, group ids: four in a row, and a
     // short-K product has no main loop to hide them behind).
@@ -207,6 +208,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             lwv[e] = 0.f;
             if (lora_mma && j < r && n0 + fn < p.N)
                 lwv[e] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+        }
+    }
+    float sbt_v = 0.f;
+    if constexpr (RK) {
+        if (has_lora && tid < (p.G + 1) * r && (p.G + 1) * r <= 272) {
+            // s_b[j] = sum_g pi_b[g] S[g][j] takes G + 1 values per rank slot (uniform mix, or the sample's group a):
+            // one table entry per thread here instead of G multiply-adds per tile element in the rank-r stage
+            const int cls = tid / r, j = tid % r;
+            const float mu = 1.0f / (float)p.G, mo = (1.0f - p.lambda_group) / (float)(p.G - 1);
+            for (int g = 0; g < p.G; ++g)
+                sbt_v += (cls == 0 ? mu : (cls - 1 == g ? p.lambda_group : mo)) * p.S[g * r + j];
         }
     }
     if constexpr (RK) {
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
         if (has_lora) {
             if (tid < p.G * r) Sg[tid] = sg_v;
             if (tid < BM) Ga[tid] = ga_v;
+            if (tid < (p.G + 1) * r && (p.G + 1) * r <= 272) SBt[tid] = sbt_v;
         }
     }
     if constexpr (VL) {
@@ -413,23 +426,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             // thread -> tile row tid & 127, rank slots [8q, 8q + 8): one 8-element segment per thread (+ one of padding)
             const int row = tid & 127, q = tid >> 7;
             const int gm = m0 + row;
-            float tsv[8];
+            const bool sb_tab = (p.G + 1) * r <= 272;
+            const bool vec_out = RK && (r & 3) == 0;          // t / ts rows leave as 16-byte stores
+            float tsv[8], tvv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int j = 8 * q + e;
-                tsv[e] = 0.f;
+                tsv[e] = tvv[e] = 0.f;
                 if (j < r && gm < p.M) {
                     if constexpr (RK) {
                         const float tv = Tt[row * RK_ROWS + j];
                         float sb = 0.f;
-                        for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
+                        if (sb_tab) sb = SBt[(Ga[row] + 1) * r + j];
+                        else for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
                         tsv[e] = p.scaling * tv * sb;
-                        if (tn == 0) {
+                        tvv[e] = tv;
+                        if (tn == 0 && !vec_out) {
                             if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
                             if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv[e];
                         }
                     } else {
                         tsv[e] = tsr[e];
+                    }
+                }
+            }
+            if constexpr (RK) {
+                if (vec_out && tn == 0 && gm < p.M) {
+#pragma unroll
+                    for (int e0 = 0; e0 < 8; e0 += 4) {
+                        if (8 * q + e0 < r) {
+                            if (p.t_out) *reinterpret_cast<f32x4*>(p.t_out + (size_t)gm * r + 8 * q + e0) = (f32x4){tvv[e0], tvv[e0 + 1], tvv[e0 + 2], tvv[e0 + 3]};
+                            if (p.ts_out) *reinterpret_cast<f32x4*>(p.ts_out + (size_t)gm * r + 8 * q + e0) = (f32x4){tsv[e0], tsv[e0 + 1], tsv[e0 + 2], tsv[e0 + 3]};
+                        }
                     }
                 }
             }
