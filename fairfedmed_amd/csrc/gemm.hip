@@ -62,6 +62,10 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int ld, int 
     }
 }
 
+// Barrier for LDS hand-offs only: __syncthreads() also drains vmcnt, i.e. waits for every global STORE issued before it
+// (the t / ts rows, the previous half's output rows); the epilogue's barriers order nothing but LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Kernel argument: the public ffm_gemm_args plus the implicit-convolution view of the A operand (CV instantiation).
 struct gemm_kargs {
     ffm_gemm_args g;
@@ -196,57 +200,85 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     // Every global load of these operands is ISSUED before the first LDS store of any of them: a load -> store -> load ->
     // store sequence pays one memory round trip per operand (bias, LoRA tile, lora_S, group ids: four in a row, and a
     // short-K product has no main loop to hide them behind).
-    float bias_v = 0.f, sg_v = 0.f, lwv[8];
+    // ... as inline-asm loads with ONE hand-placed wait: beside the LDS-DMA fills above hipcc puts s_waitcnt vmcnt(0) in
+    // front of the first use of every ordinary load, and a load under a per-lane condition ends its basic block with
+    // one (ten to twenty of them in a row made this prologue 7 300 cycles against the plain kernel's 2 200).  Indices are
+    // clamped, the loads sit in wave-uniform branches, out-of-range lanes are zeroed after the wait.
+    float bias_v = 0.f, sg_v = 0.f, lwv[8], tsr[8], tfv[8];
     int ga_v = -1;
-    if (tid < BN && (flags & FFM_EPI_BIAS) && n0 + tid < p.N) bias_v = p.bias[n0 + tid];
-    {
+    auto ldg = [](const float* q) -> float {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+        return v;
+    };
+    const int rsh = (r > 0 && (r & (r - 1)) == 0) ? __builtin_ctz(r) : -1;       // r a power of two: idx / r is a shift
+    const bool do_ds = RK && (tn == 0) && p.t_fwd && p.ds_part;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lwv[e] = tsr[e] = tfv[e] = 0.f;
+    if (flags & FFM_EPI_BIAS) {
+        const int n = n0 + (tid & (BN - 1));
+        bias_v = ldg(p.bias + (n < p.N ? n : p.N - 1));
+    }
+    if (lora_mma) {
         // LoRA tile (MFMA path): thread -> column n = tid & 127 and the eight rank slots [8q, 8q + 8), q = tid >> 7
         const int fn = tid & 127, q = tid >> 7;
+        const int n = (n0 + fn) < p.N ? (n0 + fn) : (p.N - 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int j = 8 * q + e;
-            lwv[e] = 0.f;
-            if (lora_mma && j < r && n0 + fn < p.N)
-                lwv[e] = (flags & FFM_EPI_LORA_KR) ? p.lw[(size_t)(n0 + fn) * r + j] : p.lw[(size_t)j * p.N + n0 + fn];
+            const int j = 8 * q + e, jc = j < r ? j : r - 1;
+            lwv[e] = ldg((flags & FFM_EPI_LORA_KR) ? p.lw + (size_t)n * r + jc : p.lw + (size_t)jc * p.N + n);
         }
-    }
-    float sbt_v = 0.f;
-    if constexpr (RK) {
-        if (has_lora && tid < (p.G + 1) * r && (p.G + 1) * r <= 272) {
-            // s_b[j] = sum_g pi_b[g] S[g][j] takes G + 1 values per rank slot (uniform mix, or the sample's group a):
-            // one table entry per thread here instead of G multiply-adds per tile element in the rank-r stage
-            const int cls = tid / r, j = tid % r;
-            const float mu = 1.0f / (float)p.G, mo = (1.0f - p.lambda_group) / (float)(p.G - 1);
-            for (int g = 0; g < p.G; ++g)
-                sbt_v += (cls == 0 ? mu : (cls - 1 == g ? p.lambda_group : mo)) * p.S[g * r + j];
+        if constexpr (!RK) {
+            // non-RANKOP: row tid & 127's ts values for the same slots stay in registers until the rank-r update
+            const int gm = (m0 + fn) < p.M ? (m0 + fn) : (p.M - 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 8 * q + e, jc = j < r ? j : r - 1;
+                tsr[e] = ldg(p.ts + (size_t)gm * r + jc);
+            }
         }
     }
     if constexpr (RK) {
         if (has_lora) {
-            if (tid < p.G * r) sg_v = p.S[tid];
-            if (tid < BM && p.attr) {
-                const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
-                ga_v = p.attr[gm / p.rows_per_sample];
+            const int gr = p.G * r;
+            sg_v = ldg(p.S + (tid < gr ? tid : gr - 1));
+            if (p.attr) {
+                const int gm = (m0 + (tid & 127)) < p.M ? (m0 + (tid & 127)) : (p.M - 1);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ga_v) : "v"(p.attr + gm / p.rows_per_sample) : "memory");
+            }
+        }
+        if (do_ds) {
+            // dS partials (backward, first column tile): this thread's t_fwd values, element idx = tid + 256 it of the
+            // tile's [128][r] block - loaded now so that their latency hides behind the main loop
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = tid + 256 * it, ic = idx < BM * r ? idx : BM * r - 1;
+                const int row = rsh >= 0 ? ic >> rsh : ic / r;
+                const int gm = (m0 + row) < p.M ? (m0 + row) : (p.M - 1);
+                tfv[it] = ldg(p.t_fwd + (size_t)gm * r + (ic - row * r));
             }
         }
     }
-    // non-RANKOP, r <= 16: row tid & 127's ts values for slots [8q, 8q + 8) stay in registers until the rank-r update
-    float tsr[8];
-    if constexpr (!RK) {
-        const int gm = m0 + (tid & 127), q = tid >> 7;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(bias_v), "+v"(sg_v), "+v"(ga_v));
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            tsr[e] = (lora_mma && 8 * q + e < r && gm < p.M) ? p.ts[(size_t)gm * r + 8 * q + e] : 0.f;
-    }
-    // dS partials (backward, first column tile): this thread's t_fwd values, element idx = tid + 256 it of the tile's
-    // [128][r] block - loaded now so that their latency hides behind the main loop
-    const bool do_ds = RK && (tn == 0) && p.t_fwd && p.ds_part;
-    float tfv[8];
-    if constexpr (RK) {
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(lwv[e]), "+v"(tsr[e]), "+v"(tfv[e]));
+    {
+        // zero what the clamps stood in for
+        const int fn = tid & 127, q = tid >> 7;
+        if (n0 + (tid & (BN - 1)) >= p.N) bias_v = 0.f;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = tid + 256 * it, gm = m0 + idx / (r > 0 ? r : 1);
-            tfv[it] = (do_ds && idx < BM * r && gm < p.M) ? p.t_fwd[(size_t)gm * r + idx % r] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            if (8 * q + e >= r || n0 + fn >= p.N) lwv[e] = 0.f;
+            if (8 * q + e >= r || m0 + fn >= p.M) tsr[e] = 0.f;
+        }
+        if constexpr (RK) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = tid + 256 * it;
+                const int row = rsh >= 0 ? idx >> rsh : idx / (r > 0 ? r : 1);
+                if (idx >= BM * r || m0 + row >= p.M) tfv[it] = 0.f;
+            }
         }
     }
     // ---- the LDS stores
@@ -265,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
         if (has_lora) {
             if (tid < p.G * r) Sg[tid] = sg_v;
             if (tid < BM) Ga[tid] = ga_v;
-            if (tid < (p.G + 1) * r && (p.G + 1) * r <= 272) SBt[tid] = sbt_v;
         }
     }
     if constexpr (VL) {
@@ -305,6 +336,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     }
 
     __syncthreads();
+    if constexpr (RK) {
+        // s_b[j] = sum_g pi_b[g] S[g][j] takes G + 1 values per rank slot (uniform mix, or the sample's group a): one
+        // table entry per thread here instead of G multiply-adds per tile element in the rank-r stage (read after the main
+        // loop's barriers)
+        if (has_lora && tid < (p.G + 1) * r && (p.G + 1) * r <= 272) {
+            const int cls = rsh >= 0 ? tid >> rsh : tid / r, j = tid - cls * r;
+            const float mu = 1.0f / (float)p.G, mo = (1.0f - p.lambda_group) / (float)(p.G - 1);
+            float sb = 0.f;
+            for (int g = 0; g < p.G; ++g) sb += (cls == 0 ? mu : (cls - 1 == g ? p.lambda_group : mo)) * Sg[g * r + j];
+            SBt[tid] = sb;
+        }
+    }
 
     const int frow = lane & 15, fgrp = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
@@ -377,30 +420,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 Tt[(wm * 64 + (2 * wn + ii) * 16 + fgrp * 4 + e) * RK_ROWS + frow] = tacc[ii][e];
-        __syncthreads();                              // Tt complete
+        lds_barrier();                              // Tt complete
         if (do_ds) {
             // dS partial of this row tile: sum_rows pi_b[g] * scaling * t_fwd * t.  Element idx = tid + 256 it is
             // (row idx / r, slot idx % r); with r a power of two a thread keeps ONE slot, so its rows add up in registers,
             // the lanes of a slot by shuffles, the four waves through LDS (any other r: one thread per (g, slot))
             float* Red = Cs;                          // [4][G * r]
             if ((r & (r - 1)) == 0) {
+                // (branch-free: tile row, t and group id are read with clamped indices, invalid elements weigh zero)
                 float wv[8];
-                int rw[8];
+                int gaw[8];
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int idx = tid + 256 * it;
-                    rw[it] = idx < BM * r ? idx / r : -1;
-                    wv[it] = rw[it] >= 0 ? p.scaling * tfv[it] * Tt[rw[it] * RK_ROWS + (idx & (r - 1))] : 0.f;
+                    const bool ok = idx < BM * r;
+                    const int rw = ok ? idx >> rsh : 0;
+                    const float tt = Tt[rw * RK_ROWS + (idx & (r - 1))];
+                    wv[it] = ok ? p.scaling * tfv[it] * tt : 0.f;
+                    gaw[it] = Ga[rw];
                 }
                 for (int g = 0; g < p.G; ++g) {
                     float sacc = 0.f;
 #pragma unroll
                     for (int it = 0; it < 8; ++it)
-                        if (rw[it] >= 0) sacc += mixw(rw[it], g) * wv[it];
+                        sacc += (gaw[it] < 0 ? mix_u : (gaw[it] == g ? p.lambda_group : mix_o)) * wv[it];
                     for (int o = r; o < 64; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
                     if (lane < r) Red[wave * (p.G * r) + g * r + lane] = sacc;
                 }
-                __syncthreads();
+                lds_barrier();
                 if (tid < p.G * r)
                     p.ds_part[(size_t)tm * p.G * r + tid] = (Red[tid] + Red[p.G * r + tid]) + (Red[2 * p.G * r + tid] + Red[3 * p.G * r + tid]);
             } else {
@@ -409,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     const int idx = tid + 256 * it;
                     if (idx < BM * r) Cs[idx] = p.scaling * tfv[it] * Tt[(idx / r) * RK_ROWS + idx % r];
                 }
-                __syncthreads();
+                lds_barrier();
                 if (tid < p.G * r) {
                     const int g = tid / r, j = tid % r;
                     float sacc = 0.f;
@@ -417,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     p.ds_part[((size_t)tm * p.G + g) * r + j] = sacc;
                 }
             }
-            __syncthreads();                          // Cs is reused by the halves below
+            lds_barrier();                          // Cs is reused by the halves below
         }
     }
     if (lora_mma) {
@@ -429,26 +476,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             const bool sb_tab = (p.G + 1) * r <= 272;
             const bool vec_out = RK && (r & 3) == 0;          // t / ts rows leave as 16-byte stores
             float tsv[8], tvv[8];
+            if constexpr (RK) {
+                // branch-free: the t row, the group id and the s_b table row are read unconditionally (a read under a
+                // per-lane condition is a basic block of its own that ends in s_waitcnt lgkmcnt(0): 24 LDS round trips in
+                // a row), the slots beyond r and the rows beyond M are zeroed afterwards
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(&Tt[row * RK_ROWS + 8 * q]);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(&Tt[row * RK_ROWS + 8 * q + 4]);
+                float sbv[8];
+                if (sb_tab) {
+                    const int base = (Ga[row] + 1) * r + 8 * q;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int j = 8 * q + e;
-                tsv[e] = tvv[e] = 0.f;
-                if (j < r && gm < p.M) {
-                    if constexpr (RK) {
-                        const float tv = Tt[row * RK_ROWS + j];
+                    for (int e = 0; e < 8; ++e) sbv[e] = SBt[base + e < 272 ? base + e : 271];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = 8 * q + e;
                         float sb = 0.f;
-                        if (sb_tab) sb = SBt[(Ga[row] + 1) * r + j];
-                        else for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
-                        tsv[e] = p.scaling * tv * sb;
-                        tvv[e] = tv;
-                        if (tn == 0 && !vec_out) {
-                            if (p.t_out) p.t_out[(size_t)gm * r + j] = tv;
-                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv[e];
-                        }
-                    } else {
-                        tsv[e] = tsr[e];
+                        if (j < r) for (int g = 0; g < p.G; ++g) sb += mixw(row, g) * Sg[g * r + j];
+                        sbv[e] = sb;
                     }
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = 8 * q + e < r && gm < p.M;
+                    const float tv = e < 4 ? t0[e & 3] : t1[e & 3];
+                    tvv[e] = ok ? tv : 0.f;
+                    tsv[e] = ok ? p.scaling * tv * sbv[e] : 0.f;
+                }
+                if (tn == 0 && !vec_out && gm < p.M) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = 8 * q + e;
+                        if (j < r) {
+                            if (p.t_out) p.t_out[(size_t)gm * r + j] = tvv[e];
+                            if (p.ts_out) p.ts_out[(size_t)gm * r + j] = tsv[e];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tsv[e] = tsr[e];
             }
             if constexpr (RK) {
                 if (vec_out && tn == 0 && gm < p.M) {
@@ -467,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 Vec8<T>::store(TsA + row * KE + 16 + 8 * q, z);
             }
         }
-        __syncthreads();
+        lds_barrier();
         const char* ta = reinterpret_cast<const char*>(TsA);
         const char* lb = reinterpret_cast<const char*>(LwB);
         frag_t bfr[4];
@@ -540,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (gn < p.N) {
             float v[4][8];
             {
@@ -611,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (cst) {
         // the 16 row lanes of a column chunk meet in LDS and are added in a fixed order: part[tm][0 / 1][n0 + col]
@@ -622,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             R0[erow0 * BN + ecol + c] = cs[c];
             R1[erow0 * BN + ecol + c] = cq[c];
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < BN && n0 + tid < p.N) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
