@@ -283,11 +283,37 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     float* Mu = Cv + BNp;                                     // row means [BM]
     float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
     const int r = RK ? p.rank : 0;
-    for (int i = tid; i < BNp; i += PT) Bias[i] = (flags & FFM_EPI_BIAS) ? p.bias[n0 + i] : 0.f;
-    if constexpr (LNIN) {
-        // LayerNorm statistics of this tile's A rows from the producer's partial row sums (fixed order over the
-        // partials: deterministic); E[x^2] - mu^2 in f32 is exact enough for K <= 4096 activations of O(1..100)
-        for (int i = tid; i < BNp; i += PT) Cv[i] = p.ln_c[n0 + i];
+    // bias, c (LNIN), lora_S and the rows' group ids: inline-asm loads with clamped indices, consumed behind the ONE
+    // vmcnt(0) below.  As compiler-visible loads each of them (a conditional load followed by its LDS store) was answered
+    // with its own s_waitcnt vmcnt(0) behind the ring fills: four to six memory round trips in a row in every launch.
+    constexpr int NBI = (BNp + PT - 1) / PT, NGI = (BMp + PT - 1) / PT;
+    float biasv[NBI], cvv[NBI], sgv = 0.f;
+    int gav[NGI];
+    auto ldgf = [](const float* q) -> float {
+        float v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+        return v;
+    };
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) {
+        const int i = tid + it * PT, ic = i < BNp ? i : BNp - 1;
+        biasv[it] = cvv[it] = 0.f;
+        if constexpr ((flags & FFM_EPI_BIAS) != 0) biasv[it] = ldgf(p.bias + n0 + ic);
+        if constexpr (LNIN) cvv[it] = ldgf(p.ln_c + n0 + ic);
+    }
+#pragma unroll
+    for (int it = 0; it < NGI; ++it) gav[it] = -1;
+    if constexpr (RK) {
+        const int gr = p.G * r;
+        sgv = ldgf(p.S + (tid < gr ? tid : gr - 1));
+        if (p.attr) {
+#pragma unroll
+            for (int it = 0; it < NGI; ++it) {
+                const int i = tid + it * PT, ic = i < BMp ? i : BMp - 1;
+                const int gm = (m0 + ic) < p.M ? (m0 + ic) : (p.M - 1);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(gav[it]) : "v"(p.attr + gm / p.rows_per_sample) : "memory");
+            }
+        }
     }
     if constexpr (RK) {
         if (p.lw_wide) {
@@ -326,14 +352,28 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
                 }
             }
         }
-        if (tid < p.G * r) Sg[tid] = p.S[tid];
-        for (int i = tid; i < BMp; i += PT) {
-            const int gm = (m0 + i) < p.M ? (m0 + i) : (p.M - 1);
-            Ga[i] = p.attr ? p.attr[gm / p.rows_per_sample] : -1;
-        }
     }
     FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(sgv));
+#pragma unroll
+    for (int it = 0; it < NBI; ++it) {
+        asm volatile("" : "+v"(biasv[it]), "+v"(cvv[it]));
+        const int i = tid + it * PT;
+        if (i < BNp) {
+            Bias[i] = biasv[it];
+            if constexpr (LNIN) Cv[i] = cvv[it];
+        }
+    }
+    if constexpr (RK) {
+        if (tid < p.G * r) Sg[tid] = sgv;
+#pragma unroll
+        for (int it = 0; it < NGI; ++it) {
+            asm volatile("" : "+v"(gav[it]));
+            const int i = tid + it * PT;
+            if (i < BMp) Ga[i] = gav[it];
+        }
+    }
     if constexpr (LNIN) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(lnpv[q]));
