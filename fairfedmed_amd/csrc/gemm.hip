@@ -561,17 +561,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
         constexpr int NCH = (int)(sizeof(T) * 8 / 16);               // 16-byte chunks per 8 elements (1 bf16, 2 f32)
         typename Elem<T>::chunk_t rres[4][NCH], raux[4][NCH];
         const int gn = n0 + ecol;
+        // (inline-asm loads with clamped addresses, one wait behind the barrier: as compiler-visible loads under the
+        // per-lane bounds test each of them - and then each of the four stores that use them - sat behind its own
+        // s_waitcnt vmcnt(0): eight serialised memory round trips per half tile)
+        const bool has_pre = (flags & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU)) != 0;
+        if (has_pre) {
+            const int gnc = gn < p.N ? gn : (p.N >= 8 ? p.N - 8 : 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gm = m0 + half * 64 + erow0 + 16 * i;
-            if (gn < p.N && gm < p.M) {
-                const size_t off = (size_t)gm * p.ldc + gn;
+            for (int i = 0; i < 4; ++i) {
+                const int gm0 = m0 + half * 64 + erow0 + 16 * i;
+                const size_t off = (size_t)(gm0 < p.M ? gm0 : p.M - 1) * p.ldc + gnc;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     if (flags & FFM_EPI_RESIDUAL)
-                        rres[i][c] = reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.res) + off)[c];
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.res) + off) + c) : "memory");
                     if (flags & FFM_EPI_DGELU)
-                        raux[i][c] = reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.aux) + off)[c];
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raux[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.aux) + off) + c) : "memory");
                 }
             }
         }
@@ -608,6 +613,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
             }
         }
         lds_barrier();
+        if (has_pre) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (flags & FFM_EPI_RESIDUAL) asm volatile("" : "+v"(rres[i][c]));
+                    if (flags & FFM_EPI_DGELU) asm volatile("" : "+v"(raux[i][c]));
+                }
+        }
         if (gn < p.N) {
             float v[4][8];
             {
