@@ -6,6 +6,7 @@
 //   AvgPool2d(2), residual add + ReLU, attention-pool token assembly (mean token + positional embedding)
 // All of it is HBM-bound elementwise / reduction work; 16-byte accesses along C.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -240,27 +241,60 @@ __global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restr
     rstd[c] = 1.0f / sqrtf(run_var[c] + eps);
 }
 
+// The apply kernels: threads along a row own FIXED channels (min(C/VN, 256) 16-byte chunks; blockIdx.y the chunk
+// group), the remaining threads of the block and blockIdx.x walk the rows.  The per-channel parameters are read once per
+// thread (as the flat one-chunk-per-thread loop had it, every 16 bytes of payload cost 32 scalar parameter loads and
+// an integer modulo).
+struct bn_lanes {
+    int cc, tpr, nrl, ch, rl;
+    bool on;
+    template <int VN>
+    __device__ __forceinline__ static bn_lanes make(int C) {
+        bn_lanes l;
+        l.cc = C / VN;
+        l.tpr = l.cc < 256 ? l.cc : 256;
+        l.nrl = 256 / l.tpr;
+        l.ch = blockIdx.y * 256 + threadIdx.x % l.tpr;
+        l.rl = threadIdx.x / l.tpr;
+        l.on = l.rl < l.nrl && l.ch < l.cc;
+        return l;
+    }
+};
+template <int VN>
+__device__ __forceinline__ void bn_param(const float* __restrict__ p, int c0, float (&v)[VN]) {
+#pragma unroll
+    for (int q = 0; q < VN / 4; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + c0 + 4 * q);
+        v[4 * q] = a[0]; v[4 * q + 1] = a[1]; v[4 * q + 2] = a[2]; v[4 * q + 3] = a[3];
+    }
+}
+
 // y = (x - mean) * rstd * gamma + beta  (+ residual) (ReLU)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res,
-                                                       T* __restrict__ y, size_t rows, int C, int relu) {
+                                                       T* __restrict__ y, int rows, int C, int relu) {
     constexpr int VN = VecC<T>::N;
-    const int cc = C / VN;
-    const size_t total = rows * cc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * VN;
+    const bn_lanes L = bn_lanes::make<VN>(C);
+    if (!L.on) return;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+    bn_param<VN>(mean, L.ch * VN, mu);
+    bn_param<VN>(rstd, L.ch * VN, rs);
+    bn_param<VN>(gamma, L.ch * VN, ga);
+    bn_param<VN>(beta, L.ch * VN, be);
+    for (int r = blockIdx.x * L.nrl + L.rl; r < rows; r += gridDim.x * L.nrl) {
+        const size_t o = (size_t)r * C + (size_t)L.ch * VN;
         float v[VN], rr[VN];
-        VecC<T>::load(x + i * VN, v);
-        if (res) VecC<T>::load(res + i * VN, rr);
+        VecC<T>::load(x + o, v);
+        if (res) VecC<T>::load(res + o, rr);
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
-            float o = (v[e] - mean[c + e]) * rstd[c + e] * gamma[c + e] + beta[c + e];
-            if (res) o += rr[e];
-            v[e] = relu ? fmaxf(o, 0.f) : o;
+            float t = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+            if (res) t += rr[e];
+            v[e] = relu ? fmaxf(t, 0.f) : t;
         }
-        VecC<T>::store(y + i * VN, v);
+        VecC<T>::store(y + o, v);
     }
 }
 
@@ -283,25 +317,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ mask,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ k12, T* __restrict__ dx, size_t rows,
+                                                           const float* __restrict__ k12, T* __restrict__ dx, int rows,
                                                            int C) {
     constexpr int VN = VecC<T>::N;
-    const int cc = C / VN;
-    const size_t total = rows * cc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cc) * VN;
+    const bn_lanes L = bn_lanes::make<VN>(C);
+    if (!L.on) return;
+    float mu[VN], rs[VN], ga[VN], k1[VN], k2[VN];
+    bn_param<VN>(mean, L.ch * VN, mu);
+    bn_param<VN>(rstd, L.ch * VN, rs);
+    bn_param<VN>(gamma, L.ch * VN, ga);
+    bn_param<VN>(k12, L.ch * VN, k1);
+    bn_param<VN>(k12 + C, L.ch * VN, k2);
+    for (int r = blockIdx.x * L.nrl + L.rl; r < rows; r += gridDim.x * L.nrl) {
+        const size_t o = (size_t)r * C + (size_t)L.ch * VN;
         float g[VN], xv[VN], m[VN];
-        VecC<T>::load(dy + i * VN, g);
-        VecC<T>::load(x + i * VN, xv);
-        if (mask) VecC<T>::load(mask + i * VN, m);
+        VecC<T>::load(dy + o, g);
+        VecC<T>::load(x + o, xv);
+        if (mask) VecC<T>::load(mask + o, m);
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             float gg = g[e];
             if (mask && !(m[e] > 0.f)) gg = 0.f;
-            const float xh = (xv[e] - mean[c + e]) * rstd[c + e];
-            g[e] = gamma[c + e] * rstd[c + e] * (gg - k12[c + e] - xh * k12[C + c + e]);
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            g[e] = ga[e] * rs[e] * (gg - k1[e] - xh * k2[e]);
         }
-        VecC<T>::store(dx + i * VN, g);
+        VecC<T>::store(dx + o, g);
     }
 }
 
@@ -473,6 +513,18 @@ extern "C" int ffm_col2im3x3(const void* dcols, void* dx, int B, int H, int W, i
     return FFM_OK;
 }
 
+namespace {
+// grid of the apply kernels: blockIdx.y = group of 256 channel chunks, blockIdx.x walks the rows; FFM_BN_RPT rows per
+// thread (default 2; 1 / 2 / 4 / 8 measured 7.09 / 7.04 / 7.05 / 7.24 ms on the RN50 step)
+inline dim3 bn_apply_grid(int rows, int C, int vn) {
+    static const int rpt = getenv("FFM_BN_RPT") ? atoi(getenv("FFM_BN_RPT")) : 2;
+    const int cc = C / vn, tpr = cc < 256 ? cc : 256, nrl = 256 / tpr, gy = (cc + 255) / 256;
+    int gx = (rows + nrl * rpt - 1) / (nrl * rpt);
+    const int cap = 65535;
+    return dim3(gx < 1 ? 1 : (gx > cap ? cap : gx), gy);
+}
+}  // namespace
+
 extern "C" int ffm_bn_blocks(int rows) { return cs_blocks(rows); }
 
 extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
@@ -499,10 +551,10 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, run_var, mean, rstd, C, 1e-5f);
     }
     FFM_CHECK_LAUNCH();
-    const int g2 = grid1d((size_t)rows * C / 4);
+    const dim3 g2 = bn_apply_grid(rows, C, dtype == FFM_BF16 ? 8 : 4);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(g2), dim3(256), 0, s, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)y, (size_t)rows, C, relu),
-               hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, (const float*)res, (float*)y, (size_t)rows, C, relu))
+               hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)res, (bf16_t*)y, rows, C, relu),
+               hipLaunchKernelGGL((bn_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)x, mean, rstd, gamma, beta, (const float*)res, (float*)y, rows, C, relu))
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -522,10 +574,10 @@ extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, c
     FFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();
-    const int g2 = grid1d((size_t)rows * C / 4);
+    const dim3 g2 = bn_apply_grid(rows, C, dtype == FFM_BF16 ? 8 : 4);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(g2), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)relu_out, (const bf16_t*)x, mean, rstd, gamma, k12, (bf16_t*)dx, (size_t)rows, C),
-               hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(g2), dim3(256), 0, s, (const float*)dy, (const float*)relu_out, (const float*)x, mean, rstd, gamma, k12, (float*)dx, (size_t)rows, C))
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)relu_out, (const bf16_t*)x, mean, rstd, gamma, k12, (bf16_t*)dx, rows, C),
+               hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)dy, (const float*)relu_out, (const float*)x, mean, rstd, gamma, k12, (float*)dx, rows, C))
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
