@@ -324,6 +324,7 @@ class FairLoRAEngine:
         self.ev_layer = [torch.cuda.Event() for _ in range(self._n_layer_events())]
         self.ev_grads = torch.cuda.Event()
         self.ev_tail = torch.cuda.Event()
+        self.ev_tail0 = torch.cuda.Event()
         self.ev_text_fwd = torch.cuda.Event()
         self.ev_head_bwd = torch.cuda.Event()
         self.ev_text_bwd = torch.cuda.Event()
@@ -602,6 +603,14 @@ class FairLoRAEngine:
                 pt = st.part[i]
                 # ---- critical path: u = g B^T and dX (+ LoRA dx term), dS partials
                 fused = self.fused_rank
+                early = last and getattr(self, "tail_early", True)
+                if early:
+                    # the step's tail: dB(c_proj) needs only gi and the forward's ts2 - it starts beside this block's dX
+                    # product instead of behind it
+                    self._ev_record(self.ev_tail0, main)
+                    self._ev_wait(self.grad_stream, self.ev_tail0)
+                    with self._on(self.grad_stream):
+                        ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
                 if fused:
                     ro = ops.RankOp(self.rk[i]["proj_B"], self._S(i, "proj"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"],
@@ -627,7 +636,8 @@ class FairLoRAEngine:
                         self._ev_record(self.ev_tail, main)
                         self._ev_wait(self.grad_stream, self.ev_tail)
                         with self._on(self.grad_stream):
-                            ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
+                            if not early:
+                                ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
                             ops.lora_grad_partial(act, us2, r, pt["proj_A"])
                             ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
                     ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._S(i, "fc"), attr, r, G,
