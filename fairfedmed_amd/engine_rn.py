@@ -76,8 +76,10 @@ class _Lora:
                       lo.lambda_group, self.t[:rows], self.ts[:rows])
         ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res, colstats=colstats)
 
-    def bwd(self, g: Tensor, Wt: Tensor, dx: Tensor, x: Tensor, attr: Optional[Tensor], rps: int, res=None) -> None:
-        """g = dL/dy; writes dx = g W (+ LoRA term) (+ res) and the partial sums of dA, dB, dS."""
+    def bwd(self, g: Tensor, Wt: Tensor, dx: Tensor, x: Tensor, attr: Optional[Tensor], rps: int, res=None,
+            defer: bool = False) -> None:
+        """g = dL/dy; writes dx = g W (+ LoRA term) (+ res) and the partial sums of dA, dB, dS (defer: the caller runs
+        grads() itself, on the gradient stream)."""
         e, lo = self.eng, self.eng.cfg.lora
         rows = g.shape[0]
         S, G = self._s()
@@ -90,8 +92,14 @@ class _Lora:
             ops.lora_down(g, e.params.view(self.kB), True, S, attr, lo.rank, G, rps, lo.scaling,
                           lo.lambda_group, self.u[:rows], self.us[:rows], self.t[:rows] if self.fair else None, self.pS)
             ops.gemm_nt(g, Wt, dx, ts=self.us[:rows], lw=e.params.view(self.kA), lw_is_kr=True, res=res)
-        ops.lora_grad_partial(g, self.ts[:rows], lo.rank, self.pB)
-        ops.lora_grad_partial(x, self.us[:rows], lo.rank, self.pA)
+        if not defer:
+            self.grads(g, x)
+
+    def grads(self, g: Tensor, x: Tensor) -> None:
+        """The rank-r reductions dB = g^T ts, dA = x^T us (partials); nothing downstream of them in the dX chain."""
+        rows, r = g.shape[0], self.eng.cfg.lora.rank
+        ops.lora_grad_partial(g, self.ts[:rows], r, self.pB)
+        ops.lora_grad_partial(x, self.us[:rows], r, self.pA)
 
     def reduce_entries(self, rows: int) -> list:
         e, lo = self.eng, self.eng.cfg.lora
@@ -162,6 +170,7 @@ class _Bneck:
             self.dxid = e(Ri, inpl) if stride > 1 else None
         else:
             self.gid = e(Ro, out)
+        self.ev = torch.cuda.Event()
 
     def load(self, sd, putw) -> None:
         e, p = self.eng, self.p
@@ -223,7 +232,8 @@ class _Bneck:
             gid = self.gid[:ro]
             ops.relu_bwd(g, out, gid)
         a = self.a2p[:ro] if self.stride > 1 else self.a2[:ri]
-        self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho)
+        side = getattr(e, "grads_on_side", True)
+        self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho, defer=side)
         da2 = self.da2p[:ro]
         if self.stride > 1:
             da2 = self.da2[:ri]
@@ -231,7 +241,16 @@ class _Bneck:
         self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
         ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk)   # dX = conv3x3(dY; w')
         self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
-        self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid)
+        self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid, defer=side)
+        if side:
+            # off the dX chain: this block's four rank-r reductions (every operand is a per-block buffer that stays put
+            # until the next step's forward)
+            main = torch.cuda.current_stream(e.device)
+            e._ev_record(self.ev, main)
+            e._ev_wait(e.grad_stream, self.ev)
+            with e._on(e.grad_stream):
+                self.c3.grads(self.dz3[:ro], a)
+                self.c1.grads(self.dz1[:ri], x)
         return self.dx[:ri]
 
     def loras(self):
@@ -485,9 +504,21 @@ class RN50Engine(FairLoRAEngine):
         self.sbn[1].bwd(dsa[1], sa[1], sz[1], dsz[1])
         ops.conv3x3(dsz[1], W["s2b"], dsa[0], b, H1, H1, self.zero16)
         self.sbn[0].bwd(dsa[0], sa[0], sz[0], dsz[0])
-        self._reduce(b).run()
-        if self.sops.glob:
-            self._glue(self.sops.finish)
+        if getattr(self, "grads_on_side", True):
+            # the partial sums of every site -> params.grad, behind the reductions on the gradient stream
+            main = torch.cuda.current_stream(self.device)
+            self._ev_record(self.ev_layer[0], main)               # (the attention pool's reductions ran on main)
+            self._ev_wait(self.grad_stream, self.ev_layer[0])
+            with self._on(self.grad_stream):
+                self._reduce(b).run()
+            if self.sops.glob:
+                self._glue(self.sops.finish, self.grad_stream)
+            self._ev_record(self.ev_grads, self.grad_stream)
+            self._ev_wait(main, self.ev_grads)
+        else:
+            self._reduce(b).run()
+            if self.sops.glob:
+                self._glue(self.sops.finish)
 
     def _reduce(self, b: int) -> "ops.ReducePlan":
         if b not in self.rn_plans:
