@@ -313,6 +313,7 @@ class RN50Engine(FairLoRAEngine):
         self.delta = torch.zeros_like(self.lse)
         self.d_o, self.dqkv, self.dtok = e(T, E), e(T, 3 * E), [e(T, E), e(T, E)]
         self.dx4 = e(max_images * v.spacial * v.spacial, E)
+        self.ev_ap = torch.cuda.Event()
         self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
         # column sums left behind by the GEMMs that produce a BatchNorm's input ([1]: the downsample branch, whose
         # product sits between conv3 and bn3)
@@ -481,13 +482,24 @@ class RN50Engine(FairLoRAEngine):
         rows = b * L
         a32 = self.attr_i32[:b] if has_attr else None
         tok, qkv, dqkv = self.tok[:rows], self.qkv[:rows], self.dqkv[:rows]
-        self.ap["c"].bwd(self.dfeat[:rows], W["ap_ct"], self.d_o[:rows], self.att_o[:rows], None, L)
+        side = getattr(self, "grads_on_side", True)
+        self.ap["c"].bwd(self.dfeat[:rows], W["ap_ct"], self.d_o[:rows], self.att_o[:rows], None, L, defer=side)
         ops.attention_bwd(qkv, self.att_o[:rows], self.d_o[:rows], self.lse, self.delta, dqkv, b, L, v.heads, False)
         acc = None
         for i, n in enumerate("qkv"):
             dst = self.dtok[i & 1][:rows]
-            self.ap[n].bwd(dqkv[:, i * E:(i + 1) * E], W[f"ap_{n}t"], dst, tok, None, L, res=acc)
+            self.ap[n].bwd(dqkv[:, i * E:(i + 1) * E], W[f"ap_{n}t"], dst, tok, None, L, res=acc, defer=side)
             acc = dst
+        if side:
+            # the attention pool's eight rank-r reductions beside the trunk's dX chain (dfeat, att_o, dqkv and tok stay
+            # put until the next step)
+            main = torch.cuda.current_stream(self.device)
+            self._ev_record(self.ev_ap, main)
+            self._ev_wait(self.grad_stream, self.ev_ap)
+            with self._on(self.grad_stream):
+                self.ap["c"].grads(self.dfeat[:rows], self.att_o[:rows])
+                for i, n in enumerate("qkv"):
+                    self.ap[n].grads(dqkv[:, i * E:(i + 1) * E], tok)
         g = self.dx4[:b * HW]
         ops.attnpool_tokens(acc, None, g, b, HW, backward=True)
         for i in range(len(self.blocks) - 1, -1, -1):
@@ -507,7 +519,7 @@ class RN50Engine(FairLoRAEngine):
         if getattr(self, "grads_on_side", True):
             # the partial sums of every site -> params.grad, behind the reductions on the gradient stream
             main = torch.cuda.current_stream(self.device)
-            self._ev_record(self.ev_layer[0], main)               # (the attention pool's reductions ran on main)
+            self._ev_record(self.ev_layer[0], main)
             self._ev_wait(self.grad_stream, self.ev_layer[0])
             with self._on(self.grad_stream):
                 self._reduce(b).run()
