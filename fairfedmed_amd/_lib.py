@@ -73,7 +73,7 @@ SIGNATURES = {
     "ffm_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_bn_blocks": [_i32],
     "ffm_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_avgpool2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],

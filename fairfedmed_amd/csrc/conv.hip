@@ -142,7 +142,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, const T* __restrict__ p1,
                                                      const T* __restrict__ mask, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ part, int rows,
-                                                     int C, int rpb) {
+                                                     int C, int rpb, T* __restrict__ gout = nullptr) {
     constexpr int VN = VecC<T>::N;
     __shared__ float red[2][256][VN + 1];
     const int cc = C / VN;
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, c
                     const float g = (mask && !(m[e] > 0.f)) ? 0.f : a[e];
                     s0[e] += g;
                     s1[e] += g * (xv[e] - mu[e]) * rs[e];
+                    a[e] = g;
                 }
+                if (gout) VecC<T>::store(gout + o, a);       // g = dy * (y > 0): the identity path's gradient (relu_bwd)
             }
         }
     }
@@ -560,8 +562,8 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
 }
 
 extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
-                          const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows,
-                          int C, int dtype, void* stream) {
+                          const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, void* g_out,
+                          int rows, int C, int dtype, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !part || !k12 || !dgamma || !dbeta || !dx || rows <= 0 || C <= 0)
         return FFM_EINVAL;
     if (C % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
@@ -569,8 +571,8 @@ extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, c
     const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
     dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb),
-               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb))
+               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out),
+               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out))
     FFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();

@@ -134,10 +134,10 @@ class _BN:
                    self.run_var, self.mean, self.rstd, part if part_rows else e.bn_part, y, e.bn_training, relu, res,
                    part_rows=part_rows)
 
-    def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor) -> None:
+    def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor, g_out: Optional[Tensor] = None) -> None:
         e = self.eng
         ops.bn_bwd(dy, relu_out, x, e.params.view(self.prefix + "weight"), self.mean, self.rstd, e.bn_part, e.bn_k12,
-                   e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx)
+                   e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx, g_out)
 
 
 class _Bneck:
@@ -220,7 +220,8 @@ class _Bneck:
         Hi, Ho = self.Hin, self.Hout
         ri, ro = images * Hi * Hi, images * Ho * Ho
         out = self.out[:ro]
-        self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro])
+        # (identity-skip blocks: the ReLU-masked gradient that goes on beside bn3 leaves the same pass)
+        self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro], g_out=None if self.has_down else self.gid[:ro])
         if self.has_down:
             self.bnd.bwd(g, out, self.zd[:ro], self.dzd[:ro])
             gid = self.dxp[:ro]
@@ -230,7 +231,6 @@ class _Bneck:
                 gid = self.dxid[:ri]
         else:
             gid = self.gid[:ro]
-            ops.relu_bwd(g, out, gid)
         a = self.a2p[:ro] if self.stride > 1 else self.a2[:ri]
         side = getattr(e, "grads_on_side", True)
         self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho, defer=side)

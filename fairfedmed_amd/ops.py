@@ -356,12 +356,14 @@ def bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, run_mean: Tensor, run_var: Te
 
 
 def bn_bwd(dy: Tensor, relu_out: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, part: Tensor,
-           k12: Tensor, dgamma: Tensor, dbeta: Tensor, dx: Tensor) -> None:
-    _dev(dy, relu_out, x, gamma, mean, rstd, part, k12, dgamma, dbeta, dx)
+           k12: Tensor, dgamma: Tensor, dbeta: Tensor, dx: Tensor, g_out: Optional[Tensor] = None) -> None:
+    """g_out (optional, like dy): also receives g = dy * (relu_out > 0), the identity path's gradient."""
+    _dev(dy, relu_out, x, gamma, mean, rstd, part, k12, dgamma, dbeta, dx, g_out)
     rows, Cc = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dy.dtype == x.dtype == dx.dtype
+    assert g_out is None or (g_out.is_contiguous() and g_out.dtype == dy.dtype and g_out.shape == dy.shape)
     _call("ffm_bn_bwd", L.ptr(dy), L.ptr(relu_out), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
-          L.ptr(_f32(part)), L.ptr(_f32(k12)), L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), L.ptr(dx), rows, Cc,
+          L.ptr(_f32(part)), L.ptr(_f32(k12)), L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), L.ptr(dx), L.ptr(g_out), rows, Cc,
           L.dtype_code(x.dtype), L.stream_ptr())
 
 

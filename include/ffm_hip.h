@@ -263,8 +263,10 @@ int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_
 /* part_rows > 0 (training, at most 4096): part already holds that many partial rows [part_rows][2][C] of column sums written by the
  * producer of x (colstat_part): the column-sum pass over x is skipped */
 int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
-               const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, int rows, int C,
-               int dtype, void* stream);
+               const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, void* g_out, int rows,
+               int C, int dtype, void* stream);
+/* g_out (optional, [rows, C] dtype): also receives g = dy * (relu_out > 0) - the gradient that an identity-skip
+ * Bottleneck passes on beside bn3 (clip/model.py:57-59), which is otherwise one more pass (ffm_relu_bwd) */
 int ffm_avgpool2(const void* in, void* out, int B, int H, int W, int C, int backward, int dtype, void* stream);
 int ffm_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 int ffm_relu_bwd(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);

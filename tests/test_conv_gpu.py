@@ -113,9 +113,11 @@ def test_batchnorm_train_forward_backward_and_eval(ops, dt, rows, C, relu, with_
     ref.backward(dy.double())
     k12, dg, db = torch.empty(2 * C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     dx = torch.empty_like(x)
-    ops.bn_bwd(dy, y if relu else None, x, gamma, mean, rstd, part, k12, dg, db, dx)
+    gout = torch.full_like(x, float("nan"))
+    ops.bn_bwd(dy, y if relu else None, x, gamma, mean, rstd, part, k12, dg, db, dx, g_out=gout)
     t = tol(dt) * (3 if dt == torch.float32 else 1)
     assert rel(dx, xr.grad) < t and rel(dg, gr.grad) < t and rel(db, br.grad) < t
+    assert torch.equal(gout, dy * (y > 0) if relu else dy)        # g_out: the ReLU-masked gradient (ffm_relu_bwd's result)
     # eval mode: running statistics, nothing updated
     rm2, rv2 = rm.clone(), rv.clone()
     ops.bn_fwd(x, gamma, beta, rm2, rv2, mean, rstd, None, y, False, False)
