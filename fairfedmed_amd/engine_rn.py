@@ -115,8 +115,8 @@ class _Lora:
 class _BN:
     """nn.BatchNorm2d over NHWC rows; weight / bias live in the flat trainable buffer."""
 
-    def __init__(self, eng: "RN50Engine", prefix: str, C: int, max_rows: int):
-        self.eng, self.prefix, self.C = eng, prefix, C
+    def __init__(self, eng: "RN50Engine", prefix: str, C: int, max_rows: int, aux: bool = False):
+        self.eng, self.prefix, self.C, self.aux = eng, prefix, C, aux    # aux: the downsample branch's own scratch
         f = lambda: torch.zeros(C, device=eng.device, dtype=torch.float32)
         self.run_mean, self.run_var, self.mean, self.rstd = f(), f(), f(), f()
         eng.bn_scratch = max(eng.bn_scratch, ops.bn_blocks(max_rows) * 2 * C)
@@ -131,12 +131,13 @@ class _BN:
         """part / part_rows: the column sums the producing GEMM left behind (RN50Engine.stat_buf); else own pass over x."""
         e = self.eng
         ops.bn_fwd(x, e.params.view(self.prefix + "weight"), e.params.view(self.prefix + "bias"), self.run_mean,
-                   self.run_var, self.mean, self.rstd, part if part_rows else e.bn_part, y, e.bn_training, relu, res,
-                   part_rows=part_rows)
+                   self.run_var, self.mean, self.rstd, part if part_rows else (e.bn_part_d if self.aux else e.bn_part), y,
+                   e.bn_training, relu, res, part_rows=part_rows)
 
     def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor, g_out: Optional[Tensor] = None) -> None:
         e = self.eng
-        ops.bn_bwd(dy, relu_out, x, e.params.view(self.prefix + "weight"), self.mean, self.rstd, e.bn_part, e.bn_k12,
+        ops.bn_bwd(dy, relu_out, x, e.params.view(self.prefix + "weight"), self.mean, self.rstd,
+                   e.bn_part_d if self.aux else e.bn_part, e.bn_k12_d if self.aux else e.bn_k12,
                    e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx, g_out)
 
 
@@ -164,13 +165,14 @@ class _Bneck:
         self.da2 = e(Ri, planes) if stride > 1 else None
         self.dx = e(Ri, inpl)
         if self.has_down:
-            self.bnd = _BN(eng, p + "downsample.1.", out, Ro)
+            self.bnd = _BN(eng, p + "downsample.1.", out, Ro, aux=True)
             self.xp = e(Ro, inpl) if stride > 1 else None
             self.zd, self.idn, self.dzd, self.dxp = e(Ro, out), e(Ro, out), e(Ro, out), e(Ro, inpl)
             self.dxid = e(Ri, inpl) if stride > 1 else None
         else:
             self.gid = e(Ro, out)
         self.ev = torch.cuda.Event()
+        self.ev_d = [torch.cuda.Event() for _ in range(4)]        # downsample branch: fork / join, forward and backward
 
     def load(self, sd, putw) -> None:
         e, p = self.eng, self.p
@@ -193,6 +195,16 @@ class _Bneck:
         # stat_buf[k], and the BatchNorm skips its own pass over the tensor (split-K convolutions excepted)
         sb, nt = e.stat_buf, e.stat_rows
         t_i, t_o = nt(ri), nt(ro)
+        # The downsample branch (4 of the 16 blocks) shares nothing with conv1 .. conv3 until bn3 adds it: it runs on
+        # the auxiliary stream beside them (its BatchNorm has scratch of its own), fork here, join in front of bn3.
+        main = torch.cuda.current_stream(e.device)
+        fork = self.has_down and getattr(e, "down_on_side", True) and e.aux_stream != main
+        if fork:
+            e._ev_record(self.ev_d[0], main)
+            e._ev_wait(e.aux_stream, self.ev_d[0])
+            with e._on(e.aux_stream):
+                self._down_fwd(x, images, t_o)
+            e._ev_record(self.ev_d[1], e.aux_stream)
         self.c1.fwd(x, W[p + "w1"], z1, attr, Hi * Hi, colstats=sb[0] if t_i else None)
         self.bn1.fwd(z1, a1, True, part=sb[0], part_rows=t_i)
         t2 = ops.conv3x3(a1, W[p + "w2"], z2, images, Hi, Hi, e.zero16, e.splitk, colstats=sb[0] if t_i else None)
@@ -204,15 +216,24 @@ class _Bneck:
         self.c3.fwd(a, W[p + "w3"], z3, attr, Ho * Ho, colstats=sb[0] if t_o else None)
         idn = x
         if self.has_down:
-            xi = x
-            if self.stride > 1:
-                xi = self.xp[:ro]
-                ops.avgpool2(x, xi, images, Hi, Hi)
-            ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro], colstats=sb[1] if t_o else None)
             idn = self.idn[:ro]
-            self.bnd.fwd(self.zd[:ro], idn, False, part=sb[1], part_rows=t_o)
+            if fork:
+                e._ev_wait(main, self.ev_d[1])                    # join: the downsample branch's bn output
+            else:
+                self._down_fwd(x, images, t_o)
         self.bn3.fwd(z3, out, True, res=idn, part=sb[0], part_rows=t_o)   # relu(bn3(conv3) + identity)
         return out
+
+    def _down_fwd(self, x: Tensor, images: int, t_o: int) -> None:
+        """downsample: AvgPool2d(stride) -> 1x1 convolution -> BatchNorm (clip/model.py:29-36), into self.idn"""
+        e, p, W = self.eng, self.p, self.eng.rnw
+        ro = images * self.Hout * self.Hout
+        xi = x
+        if self.stride > 1:
+            xi = self.xp[:ro]
+            ops.avgpool2(x, xi, images, self.Hin, self.Hin)
+        ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro], colstats=e.stat_buf[1] if t_o else None)
+        self.bnd.fwd(self.zd[:ro], self.idn[:ro], False, part=e.stat_buf[1], part_rows=t_o)
 
     def backward(self, g: Tensor, x: Tensor, images: int, attr: Optional[Tensor]) -> Tensor:
         """g = dL/d(block output) -> dL/d(block input)."""
@@ -222,13 +243,18 @@ class _Bneck:
         out = self.out[:ro]
         # (identity-skip blocks: the ReLU-masked gradient that goes on beside bn3 leaves the same pass)
         self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro], g_out=None if self.has_down else self.gid[:ro])
+        main = torch.cuda.current_stream(e.device)
+        fork = self.has_down and getattr(e, "down_on_side", True) and e.aux_stream != main
         if self.has_down:
-            self.bnd.bwd(g, out, self.zd[:ro], self.dzd[:ro])
-            gid = self.dxp[:ro]
-            ops.gemm_nt(self.dzd[:ro], W[p + "wdt"], gid)
-            if self.stride > 1:
-                ops.avgpool2(gid, self.dxid[:ri], images, Hi, Hi, backward=True)
-                gid = self.dxid[:ri]
+            gid = self.dxid[:ri] if self.stride > 1 else self.dxp[:ro]
+            if fork:                                              # beside conv3 .. conv1's dX chain, joined at conv1's dX
+                e._ev_record(self.ev_d[2], main)
+                e._ev_wait(e.aux_stream, self.ev_d[2])
+                with e._on(e.aux_stream):
+                    self._down_bwd(g, images)
+                e._ev_record(self.ev_d[3], e.aux_stream)
+            else:
+                self._down_bwd(g, images)
         else:
             gid = self.gid[:ro]
         a = self.a2p[:ro] if self.stride > 1 else self.a2[:ri]
@@ -241,6 +267,8 @@ class _Bneck:
         self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
         ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk)   # dX = conv3x3(dY; w')
         self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
+        if fork:
+            e._ev_wait(main, self.ev_d[3])                        # join: the downsample branch's input gradient
         self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid, defer=side)
         if side:
             # off the dX chain: this block's four rank-r reductions (every operand is a per-block buffer that stays put
@@ -252,6 +280,14 @@ class _Bneck:
                 self.c3.grads(self.dz3[:ro], a)
                 self.c1.grads(self.dz1[:ri], x)
         return self.dx[:ri]
+
+    def _down_bwd(self, g: Tensor, images: int) -> None:
+        e, p, W = self.eng, self.p, self.eng.rnw
+        ri, ro = images * self.Hin * self.Hin, images * self.Hout * self.Hout
+        self.bnd.bwd(g, self.out[:ro], self.zd[:ro], self.dzd[:ro])
+        ops.gemm_nt(self.dzd[:ro], W[p + "wdt"], self.dxp[:ro])
+        if self.stride > 1:
+            ops.avgpool2(self.dxp[:ro], self.dxid[:ri], images, self.Hin, self.Hin, backward=True)
 
     def loras(self):
         return [(self.c1, self.Hin), (self.c3, self.Hout)]
@@ -314,6 +350,9 @@ class RN50Engine(FairLoRAEngine):
         self.d_o, self.dqkv, self.dtok = e(T, E), e(T, 3 * E), [e(T, E), e(T, E)]
         self.dx4 = e(max_images * v.spacial * v.spacial, E)
         self.ev_ap = torch.cuda.Event()
+        self.aux_stream = self._aux0 = torch.cuda.Stream(device=dev)      # the downsample branches (_Bneck.forward / backward)
+        self.bn_part_d = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
+        self.bn_k12_d = torch.zeros(2 * self.bn_cmax, device=dev, dtype=torch.float32)
         self.bn_part = torch.zeros(self.bn_scratch, device=dev, dtype=torch.float32)
         # column sums left behind by the GEMMs that produce a BatchNorm's input ([1]: the downsample branch, whose
         # product sits between conv3 and bn3)
@@ -334,6 +373,10 @@ class RN50Engine(FairLoRAEngine):
 
     def _n_layer_events(self) -> int:
         return 1
+
+    def set_overlap(self, on: bool) -> None:
+        super().set_overlap(on)
+        self.aux_stream = self._aux0 if on else torch.cuda.current_stream(self.device)
 
     def conv3x3_rows(self, w: Tensor, Kp: int) -> Tensor:
         """[Cout, Cin, 3, 3] -> [Cout, Kp] with k = (ky*3 + kx)*Cin + c, zero padded (the order ffm_im2col3x3 writes)."""
