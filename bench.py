@@ -373,8 +373,14 @@ def main():
         eng.use_replay = False                         # per-launch events need eager launches ...
         eng.set_overlap(False)                         # ... and one kernel at a time (no side streams)
         eager_step()
+        # The event pairs must measure the GPU, not the host: with an idle queue the first event of a pair executes the
+        # moment it arrives and the pair's interval then includes the Python time between its enqueue and the launch's
+        # (on a slow host the figure dropped from 0.23 to 0.19 of peak with identical kernels).  A spin kernel in front of
+        # every timed step keeps the queue backed up while the host enqueues the step, so the pairs run back to back.
+        spin = int(2.0e9 * 0.015)                      # ~15 ms of device cycles: longer than one eager step's enqueue
         with GemmTimer(ops) as gt:
             for _ in range(args.steps):
+                torch.cuda._sleep(spin)
                 eager_step()
             n, ms, fl = gt.summary(min_rows=1024)      # the vision tower's GEMMs (6304 token rows)
             n_all, ms_all, fl_all = gt.summary()
