@@ -11,8 +11,18 @@ accumulation and fp32 trainable tensors, batch 32 of 224x224x3
 (BASELINE.json configs[1]).  With N > 1 every rank is one federated client
 (one process per GPU, weak scaling) and the K steps end with the round-boundary
 FedAvg all-reduce of the LoRA/ctx parameters over RCCL.  `python bench.py --gpus N`
-starts the N ranks itself (torch.distributed.run children, before this process
-touches the GPU); started under torch.distributed.run it is one of the ranks.
+starts the N ranks itself (torch.distributed.run children); started under
+torch.distributed.run it is one of the ranks and takes the world size from the
+launcher (an explicit --gpus that disagrees is an error).
+
+    --config c2   (default) BASELINE.json configs[1]: the headline workload above
+    --config c4   configs[3]: 3D OCT, 4 volumes of 200x224x224 per step (D=8 -> 100
+                  ViT-B/16 images), FairLoRA r=16, dX through the trainable slice conv
+    --config c5   configs[4]: RN50 FairLoRA r=8, gender (2 groups), bs 32; the round
+                  boundary also averages the BatchNorm buffers (second all-reduce)
+`value` of c4 / c5 is in that workload's own unit (volumes/sec, images/sec); the
+driver's line is c2.  The default c2 run reports c4 and c5 under `secondary`
+(child processes, each with its own `roofline`).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      achieved TFLOP/s of the dominant kernel (the MFMA GEMM), timed
@@ -49,7 +59,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU); default: the launcher's WORLD_SIZE, else 1")
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="BASELINE.json workload: c2 = configs[1] ViT-B/16 r=8 bs32 (the metric), c4 = configs[3] 3D OCT "
+                         "r=16, c5 = configs[4] RN50 r=8 G=2")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -69,15 +83,18 @@ def parse():
 
 
 class GemmTimer:
-    """Wraps ops.gemm_nt: one HIP event pair per launch on the launching stream."""
+    """Wraps ops.gemm_nt (and ops.conv3x3, RN50's implicit-GEMM convolutions): one HIP event pair per launch on the
+    launching stream."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.rec = ops, ops.gemm_nt, []
+        self.ops, self.orig, self.orig_conv, self.rec = ops, ops.gemm_nt, ops.conv3x3, []
+
+    def _pair(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def __enter__(self):
         def timed(a, b, out, **kw):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+            e0, e1 = self._pair()
             e0.record()
             r = self.orig(a, b, out, **kw)
             e1.record()
@@ -91,11 +108,19 @@ class GemmTimer:
                 fl += 2.0 * M * K * 16 + 2.0 * M * N * rk.S.shape[1]
             self.rec.append((e0, e1, fl, M))
             return r
-        self.ops.gemm_nt = timed
+
+        def timed_conv(x, w, out, *a, **kw):
+            e0, e1 = self._pair()
+            e0.record()
+            r = self.orig_conv(x, w, out, *a, **kw)
+            e1.record()
+            self.rec.append((e0, e1, 2.0 * x.shape[0] * w.shape[0] * 9 * x.shape[1], x.shape[0]))
+            return r
+        self.ops.gemm_nt, self.ops.conv3x3 = timed, timed_conv
         return self
 
     def __exit__(self, *a):
-        self.ops.gemm_nt = self.orig
+        self.ops.gemm_nt, self.ops.conv3x3 = self.orig, self.orig_conv
 
     def summary(self, min_rows=0):
         torch.cuda.synchronize()
@@ -162,8 +187,9 @@ def _free_port() -> int:
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run and
     relay their output and exit code.  Nothing in THIS process has touched the GPU (importing torch does not
-    initialise HIP), so the children are ordinary subprocesses, not an exec of a GPU process."""
-    have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    initialise HIP; counting the devices may, on builds that fall back to hipGetDeviceCount), and whatever it has
+    touched the ranks are always FRESH subprocess children, never an exec of this process."""
+    have = torch.cuda.device_count()
     if have < n and not os.environ.get("FFM_BENCH_ONE_DEVICE"):
         raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
@@ -240,33 +266,102 @@ def trainer_throughput(tr, use_dist):
 
 
 def secondary_configs():
-    """Step times of BASELINE.json configs[3] (3D OCT, ViT-B/16 r=16, 4 volumes of 200x224x224 -> 100 ViT images) and
-    configs[4] (RN50 r=8 G=2, bs 32), each in a child process of its own (fresh HIP queues; this process is done
-    timing).  Never part of `value`."""
+    """BASELINE.json configs[3] (3D OCT r=16) and configs[4] (RN50 r=8 G=2) through `bench.py --config c4 / c5`, each in a
+    child process of its own (fresh HIP queues; this process is done timing), each with its own `roofline`.  Never part
+    of `value`."""
     out = {}
-    for key, tool in (("configs[3]_oct3d_vitb16_r16_bf16", "bench_oct3d.py"), ("configs[4]_rn50_r8_g2_bf16", "bench_rn50.py")):
+    for key, cfg in (("configs[3]_oct3d_vitb16_r16_bf16", "c4"), ("configs[4]_rn50_r8_g2_bf16", "c5")):
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--json"], capture_output=True,
-                               text=True, timeout=600, cwd=ROOT)
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--gpus", "1", "--steps", "10",
+                                "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--no-trainer"],
+                               capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            out[key] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+            if line:
+                j = json.loads(line[-1])
+                out[key] = {"workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "value": j["value"],
+                            "unit": j["unit"], "steps": j["steps"], "dtype": j["dtype"],
+                            "trainable_elems": j["config"]["trainable_elems"], "final_loss": j["config"]["final_loss"],
+                            "roofline": j.get("roofline")}
+                for extra in ("vit_images_per_sec",):
+                    if extra in j["config"]:
+                        out[key][extra] = j["config"][extra]
+            else:
+                out[key] = {"error": (r.stderr or r.stdout)[-300:]}
         except Exception as e:                                        # a failed side measurement never fails the bench
             out[key] = {"error": repr(e)[:300]}
     return out
 
 
+class Workload:
+    """One BASELINE.json configuration: engine, resident batch, and how a step's work is counted."""
+
+    def __init__(self, args, dev, rank):
+        import dataclasses
+        from fairfedmed_amd import config as C
+        from fairfedmed_amd import synth
+        from fairfedmed_amd.engine import FairLoRAEngine
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        self.key, self.tr, self.vit_images = args.config, None, None
+        if args.config == "c2":
+            self.mcfg = C.vit_b16(rank=args.rank)
+            sd = synth.make_state_dict(self.mcfg, seed=1, lora_init="reference")
+            # The engine is the one the registry-built trainer owns (build_trainer(cfg) -> GLP_OT_SVLoRA.build_model), so
+            # the headline steps and the trainer-level entries run on the SAME engine, streams and hardware queues.
+            self.tr = build_bench_trainer(self.mcfg, sd, args, dev, rank)
+            self.eng = self.tr.engine
+            assert isinstance(self.eng, FairLoRAEngine)
+            batch = synth.make_batch(self.mcfg, BATCH, seed=1234 + rank)
+            self.units, self.unit = BATCH, "images/sec"
+            self.metric = "images/sec per client-round, ViT-B/16 FairLoRA r=8, bs=32 224^2"
+            self.desc = ("configs[1]: 1-client ViT-B/16 FairLoRA rank=%d G=3, bs=32 synthetic 224x224x3, fwd+bwd+SGD per step"
+                         % args.rank)
+            self.min_rows, self.rows = 1024, BATCH * 197
+            self.by_attr = [400, 300, 324]
+        elif args.config == "c4":
+            B, S = 4, 25
+            self.mcfg = dataclasses.replace(C.vit_b16(rank=16), dim_per_3d_slice=8)
+            sd = synth.make_state_dict(self.mcfg, seed=1, lora_init="reference")
+            self.eng = FairLoRAEngine(self.mcfg, sd, dtype=dtype, max_images=B * S, device=dev)
+            batch = synth.make_batch(self.mcfg, B, seed=3 + rank, slices=S, signal=0.2)
+            self.units, self.unit, self.vit_images = B, "volumes/sec", B * S
+            self.metric = "volumes/sec per client-round, 3D OCT 200x224x224, ViT-B/16 FairLoRA r=16"
+            self.desc = ("configs[3]: 3D OCT, 4 volumes of 200x224x224 per step, D=8 -> 100 ViT-B/16 images, FairLoRA r=16 G=3, "
+                         "fwd+bwd (through the trainable slice conv)+SGD per step")
+            self.min_rows, self.rows = 1024, B * S * 197
+            self.by_attr = [400, 300, 324]
+        else:
+            from fairfedmed_amd.engine_rn import create_engine
+            self.mcfg = C.rn50(rank=8, num_groups=2)
+            sd = synth.make_state_dict(self.mcfg, seed=1, lora_init="random")
+            self.eng = create_engine(self.mcfg, sd, dtype=dtype, max_images=BATCH, device=dev)
+            batch = synth.make_batch(self.mcfg, BATCH, seed=1234 + rank)
+            self.units, self.unit = BATCH, "images/sec"
+            self.metric = "images/sec per client-round, RN50 FairLoRA r=8 G=2, bs=32 224^2"
+            self.desc = "configs[4]: RN50 (3,4,6,3) FairLoRA r=8, gender (2 groups), bs=32 synthetic 224x224x3, fwd+bwd+SGD per step"
+            self.min_rows, self.rows = 1024, None
+            self.by_attr = [600, 424]
+        self.dtype = dtype
+        self.img = batch["img"].to(dev)
+        self.attr = batch["attrs"].t()[0].contiguous().to(dev)
+        self.label = batch["label"].to(dev)
+        self.has_buf = hasattr(self.eng, "buffers_flat")       # RN50: BatchNorm running statistics
+
+
 def main():
     args = parse()
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if args.gpus is None:
+        args.gpus = world                                # under a launcher: its world size; else one GPU
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "RANK" not in os.environ and args.gpus > 1:
+    if not launched and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # started by torch.distributed.run
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     use_dist = (world > 1 or launched) and not os.environ.get("FFM_BENCH_NO_DIST")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -286,27 +381,19 @@ def main():
     torch.cuda.set_device(local)
 
     from fairfedmed_amd import config as C
-    from fairfedmed_amd import ops, synth
-    from fairfedmed_amd.engine import FairLoRAEngine
+    from fairfedmed_amd import ops
     from fairfedmed_amd.fedavg import FedAvgAggregator
 
-    mcfg = C.vit_b16(rank=args.rank)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
-    # The engine is the one the registry-built trainer owns (build_trainer(cfg) -> GLP_OT_SVLoRA.build_model), so the
-    # headline steps and the trainer-level entries below run on the SAME engine, streams and hardware queues.
-    tr = build_bench_trainer(mcfg, sd, args, dev, rank)
-    eng = tr.engine
-    assert isinstance(eng, FairLoRAEngine)
-    del sd
-    batch = synth.make_batch(mcfg, BATCH, seed=1234 + rank)
-    img, attr, label = batch["img"].to(dev), batch["attrs"].t()[0].contiguous().to(dev), batch["label"].to(dev)
+    wl = Workload(args, dev, rank)
+    mcfg, eng, tr, dtype = wl.mcfg, wl.eng, wl.tr, wl.dtype
+    img, attr, label = wl.img, wl.attr, wl.label
     opt = C.OptimCfg()
     agg = None
     if use_dist:
         agg = FedAvgAggregator(eng.params.flat, eng.params.offsets, mcfg.lora.num_groups, mcfg.lora.rank)
     n_client = [1024] * world
-    by_attr = [[400, 300, 324]] * world
+    by_attr = [wl.by_attr] * world
+    buf_bytes = 0
 
     def eager_step():
         eng.forward_backward(img, attr, label)
@@ -317,6 +404,8 @@ def main():
     eng.use_replay = args.launch == "replay"
     if args.serial:
         eng.set_overlap(False)
+    if args.launch == "graph" and args.config != "c2":
+        raise SystemExit("--launch graph: the captured step exists for --config c2 only")
     graphed = eng.capture_train_step(BATCH, opt.lr, opt.momentum, opt.weight_decay) if args.launch == "graph" else None
 
     def step():
@@ -326,8 +415,17 @@ def main():
             graphed.run(img, attr, label)          # copies the (resident) batch into the graph's inputs, replays
 
     def round_boundary():
-        if agg is not None:
-            agg.aggregate(rank, list(range(world)), n_client, by_attr, 1, 50)
+        nonlocal buf_bytes
+        if agg is None:
+            return
+        agg.aggregate(rank, list(range(world)), n_client, by_attr, 1, 50)
+        if wl.has_buf:
+            # RN50: the BatchNorm running statistics / counters are state_dict entries too and are averaged with the plain
+            # n_k / sum n weights (utils/fed_utils.py:76-86): a second, small all-reduce
+            buf = eng.buffers_flat() * (n_client[rank] / float(sum(n_client)))
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            eng.load_buffers_flat(buf)
+            buf_bytes = buf.numel() * 4
 
     for _ in range(args.warmup):
         step()
@@ -353,7 +451,7 @@ def main():
     finite = int(eng.finite)
     loss = float(eng.loss)
     # round-boundary exchange on its own: pre-scale, ONE all-reduce of the flat trainable buffer,
-    # shared_half_s + EMA; median of 5 after the timed region, max over ranks
+    # shared_half_s + EMA (RN50: + the BatchNorm-buffer all-reduce); median of 5 after the timed region, max over ranks
     fedavg_us = None
     if agg is not None:
         samples = []
@@ -377,12 +475,12 @@ def main():
         # moment it arrives and the pair's interval then includes the Python time between its enqueue and the launch's
         # (on a slow host the figure dropped from 0.23 to 0.19 of peak with identical kernels).  A spin kernel in front of
         # every timed step keeps the queue backed up while the host enqueues the step, so the pairs run back to back.
-        spin = int(2.0e9 * 0.015)                      # ~15 ms of device cycles: longer than one eager step's enqueue
+        spin = int(2.0e9 * (0.015 if args.config == "c2" else 0.030))   # longer than one eager step's enqueue
         with GemmTimer(ops) as gt:
             for _ in range(args.steps):
                 torch.cuda._sleep(spin)
                 eager_step()
-            n, ms, fl = gt.summary(min_rows=1024)      # the vision tower's GEMMs (6304 token rows)
+            n, ms, fl = gt.summary(min_rows=wl.min_rows)   # the vision tower's GEMMs (not the text tower's 40 rows)
             n_all, ms_all, fl_all = gt.summary()
         eng.set_overlap(True)
         peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
@@ -393,15 +491,19 @@ def main():
         try:
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
             cand = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json"))
-            if cand and dtype == torch.bfloat16 and args.rank == 8:
+            if cand and dtype == torch.bfloat16 and args.rank == 8 and args.config == "c2":
                 traffic = json.load(open(os.path.join(pdir, cand[-1])))["traffic_bytes_per_launch"]
                 tsrc = "profiles/" + cand[-1]
         except (OSError, KeyError, ValueError):
             pass
-        roof = {"bound": "mfma",
-                "kernel": "ffm_gemm_nt on the vision tower (M=%d): gemm_panel_kernel<%s> on fragment-packed frozen "
-                          "weights (bf16; the qkv / c_fc launches also carry ln_1 / ln_2, FFM_EPI_LNIN, whose flops are "
-                          "not counted), gemm_nt_kernel otherwise" % (BATCH * 197, args.dtype),
+        if args.config == "c5":
+            kernel = ("ffm_gemm_nt (1x1 convolutions with the FairLoRA epilogues, attention pool) and ffm_conv3x3_nhwc "
+                      "(implicit-GEMM 3x3 convolutions) of the RN50 tower: gemm_nt_kernel / conv_narrow_kernel (%s)" % args.dtype)
+        else:
+            kernel = ("ffm_gemm_nt on the vision tower (M=%d): gemm_panel_kernel<%s> on fragment-packed frozen "
+                      "weights (bf16; the qkv / c_fc launches also carry ln_1 / ln_2, FFM_EPI_LNIN, whose flops are "
+                      "not counted), gemm_nt_kernel otherwise" % (wl.rows, args.dtype))
+        roof = {"bound": "mfma", "kernel": kernel,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), algorithmic mean 54.4e6",
                 "traffic_source": tsrc,
@@ -414,7 +516,7 @@ def main():
                             "side streams folded into the main stream (one kernel at a time); value comes from the "
                             "un-instrumented overlapped pass"}
     trainer_res = None
-    if not args.no_trainer:
+    if not args.no_trainer and tr is not None:
         eng.set_overlap(True)
         eng.use_replay = True
         trainer_res = trainer_throughput(tr, use_dist)
@@ -423,33 +525,35 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "images/sec per client-round, ViT-B/16 FairLoRA r=8, bs=32 224^2",
-            "value": BATCH * args.steps * world / dt,
-            "unit": "images/sec",
+            "metric": wl.metric,
+            "value": wl.units * args.steps * world / dt,
+            "unit": wl.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: 1-client ViT-B/16 FairLoRA rank=%d G=3, bs=32 synthetic 224x224x3, "
-                                   "fwd+bwd+SGD per step%s" % (args.rank, "" if world == 1 else
-                                                               "; one client per GPU, FedAvg all-reduce at the round end"),
-                       "global_batch": BATCH * world, "clients": world,
+            "config": {"workload": wl.desc + ("" if world == 1 else "; one client per GPU, FedAvg all-reduce at the round end"),
+                       "global_batch": wl.units * world, "clients": world,
                        "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite,
                        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
                        "launch": args.launch,
                        "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None},
         }
+        if wl.vit_images:
+            res["config"]["vit_images_per_sec"] = wl.vit_images * args.steps * world / dt
         if fedavg_us is not None:
             res["config"]["fedavg_round_boundary_us"] = fedavg_us
             res["config"]["fedavg_payload_bytes"] = eng.params.numel * 4
+            if wl.has_buf:
+                res["config"]["fedavg_buffer_payload_bytes"] = buf_bytes
         if roof:
             res["roofline"] = roof
         if trainer_res:
             res["trainer"] = trainer_res
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and args.config == "c2":
             res["secondary"] = secondary_configs()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             res["cpu_baseline"] = cpu_baseline(mcfg)
         print(json.dumps(res), flush=True)
     if use_dist:

@@ -821,10 +821,13 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     }
     if (dtype == FFM_F32_X3) return FFM_EUNSUP;                           // split-operand products: skinny shapes only
     if (a.flags & (FFM_EPI_ROWSTATS | FFM_EPI_LNIN)) {                    // LayerNorm folding: the panel kernel only
+        if (a.colstat_part) return FFM_EUNSUP;                            // ... which has no column-sum epilogue
         const int cfgl = a.b_packed ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
         return cfgl >= 0 ? ffm_panel_launch(a, cfgl, s) : FFM_EUNSUP;
     }
-    if (a.b_packed) {
+    // column sums (colstat_part) are an epilogue of the 128x128 / 128xN kernels only: a packed weight does not send
+    // such a launch to the panel kernel, which would return without writing them
+    if (a.b_packed && !a.colstat_part) {
         const int cfg = ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true);
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);
     }

@@ -53,9 +53,12 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
     if (!packed || dtype != FFM_BF16 || K % 128 != 0 || K < 512) return -1;
     const bool rk = (flags & FFM_EPI_RANKOP) != 0;
     if (rk ? !rk_flags_ok(flags, rank) : !plain_flags_ok(flags)) return -1;
-    if (const char* f = getenv("FFM_PANEL")) {               // FFM_PANEL=off: always the 128x128 kernel (A/B runs)
-        if (f[0] == 'o' || f[0] == '0') return -1;
-    }
+    // FFM_PANEL=off: always the 128x128 kernel (A/B runs); read once per process, not per launch
+    static const bool panel_off = [] {
+        const char* f = getenv("FFM_PANEL");
+        return f && (f[0] == 'o' || f[0] == '0');
+    }();
+    if (panel_off) return -1;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     long best = ((t128 + 255) / 256) * 256;
     int pick = -1;

@@ -34,7 +34,10 @@ _FILTERED = {"gender", "maritalstatus", "hispanic", "language", "ethnicity", "ra
 
 
 def resize_image(img: np.ndarray, shape) -> np.ndarray:
-    """skimage.transform.resize(img, shape) for a 2-D float image (defaults: order 1, mode='reflect', clip=True)."""
+    """skimage.transform.resize(img, shape) for a 2-D float image (defaults: order 1, mode='reflect', clip=True,
+    anti-aliasing Gaussian with sigma = (in/out - 1) / 2 when an axis shrinks), restated on scipy.ndimage because
+    scikit-image is not installable here; pinned by tests/test_data_cpu.py against values worked out by hand from the
+    published algorithm and against a loop-level implementation of it that shares no code with this one."""
     from scipy import ndimage as ndi
     img = np.asarray(img)
     out_dtype = img.dtype if img.dtype.kind == "f" else np.float64

@@ -27,6 +27,15 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
+def is_group_s_block(key: str, shape: Sequence[int], num_groups: int) -> bool:
+    """The per-group singular-value blocks that get the per-attribute weights and shared_half_s
+    (utils/fed_utils.py:76,90: 'lora_S' in key and shape[0] == number of groups).  Only the real 2-D [G, r]
+    tensors count: the 1-D lora_S_global [r] (GLOBAL_S) and SVLoRA's lora_S [r] also carry 'lora_S' in their
+    keys and have shape[0] == G whenever rank == num_groups; taken for a block they would be read G*r wide,
+    over the neighbouring tensors of the flat buffer."""
+    return "lora_S" in key and len(shape) == 2 and shape[0] == num_groups
+
+
 def element_weights(offsets: Dict[str, Tuple[int, Tuple[int, ...]]], numel: int, client: int,
                     participants: Sequence[int], n_client: Sequence[int],
                     n_client_by_attr: Optional[Sequence[Sequence[int]]]) -> Tensor:
@@ -43,7 +52,7 @@ def element_weights(offsets: Dict[str, Tuple[int, Tuple[int, ...]]], numel: int,
         fg = (by[client] / tot).to(torch.float32)           # same fp32 division as the reference
         G = by.shape[1]
         for key, (off, shp) in offsets.items():
-            if "lora_S" in key and shp[0] == G:
+            if is_group_s_block(key, shp, G):
                 r = shp[1]
                 w[off:off + G * r] = fg[:, None].expand(G, r).reshape(-1)
     return w
@@ -59,7 +68,7 @@ class FedAvgAggregator:
         self.buf = torch.empty_like(flat)
         self._wcache = {}
         self.s_offsets = torch.tensor(
-            [off for k, (off, shp) in offsets.items() if "lora_S" in k and shp[0] == num_groups],
+            [off for k, (off, shp) in offsets.items() if is_group_s_block(k, shp, num_groups)],
             dtype=torch.int64, device=flat.device)
 
     @torch.no_grad()

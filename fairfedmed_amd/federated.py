@@ -23,6 +23,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .fedavg import is_group_s_block
+
 Tensor = torch.Tensor
 
 
@@ -63,7 +65,9 @@ def average_weights_ema(w_g: Dict[str, Tensor], w: Dict[int, Dict[str, Tensor]],
     beta_decay = beta * (epoch / max(max_epoch, 1))
     out: Dict[str, Tensor] = {}
     for key, first in w[idxs_users[0]].items():
-        grouped = by_attr is not None and "lora_S" in key and first.shape[0] == G
+        # (2-D blocks only: a 1-D lora_S_global / SVLoRA lora_S [r] with r == G would be broadcast to [G, r] by the
+        # reference's shape[0] test - a latent shape bug there, not a behaviour to reproduce)
+        grouped = by_attr is not None and is_group_s_block(key, first.shape, G)
         acc = None
         for u in idxs_users:
             x = w[u][key]
@@ -241,10 +245,10 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         if has_buf:
             dist.all_reduce(acc_buf, op=dist.ReduceOp.SUM)
-        if args.shared_half_s:
+        if args.shared_half_s and by_attr is not None:               # utils/fed_utils.py:90 (same guard as the weights)
             G, r = lo.num_groups, lo.rank
             for k, (off, shp) in offsets.items():
-                if "lora_S" in k and shp[0] == G:
+                if is_group_s_block(k, shp, G):
                     blk = acc[off:off + G * r].view(G, r)
                     blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
         beta_decay = 0.999 * (epoch / max(args.round, 1))

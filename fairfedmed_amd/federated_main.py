@@ -89,7 +89,8 @@ def build_parser() -> argparse.ArgumentParser:
                      ("--mu", dict(type=float, default=0.5)), ("--logdir", dict(type=str, default="./logs/"))):
         a(flag, **kw)
     # build-specific
-    a("--prec", type=str, default="bf16", choices=["bf16", "fp32"], help="compute dtype (the reference's fp16 -> bf16)")
+    a("--prec", type=str, default="bf16", choices=["bf16", "fp32", "amp", "fp16"],
+      help="TRAINER.GLP_OT.PREC; the reference's 'fp16' runs as bf16 here, with a warning (trainer.resolve_precision)")
     a("--state-dict", type=str, default="", help="CustomCLIP state_dict (.pt) with the pretrained CLIP weights")
     a("--synthetic", action="store_true", help="synthetic batches instead of the dataset under --root")
     a("--synthetic-batches", type=int, default=4)

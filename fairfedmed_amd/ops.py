@@ -444,6 +444,10 @@ def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups:
     assert method in ("auto", "pairs", "sort")
     out = torch.empty(num_groups + 2, EVAL_SLOTS, device=prob.device, dtype=torch.int64)
     if method == "sort" or (method == "auto" and N >= EVAL_SORT_FROM):
+        if recording():
+            # refused BEFORE anything is allocated or launched: a recorded launch would keep the raw pointer of the
+            # temporary workspace and replay into freed memory
+            raise RuntimeError("eval_counts(method='sort') holds a temporary workspace and cannot be recorded")
         nbytes = int(L.load().ffm_eval_counts_ws_bytes(N))
         if nbytes <= 0:
             raise RuntimeError("ffm_eval_counts_ws_bytes failed")
@@ -451,8 +455,6 @@ def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups:
         off = (-ws.data_ptr()) % 256
         _call("ffm_eval_counts_sorted", L.ptr(prob), L.ptr(label), L.ptr(attr), N, num_groups, L.ptr(out),
               ws.data_ptr() + off, nbytes, L.stream_ptr())
-        if recording():
-            raise RuntimeError("eval_counts(method='sort') holds a temporary workspace and cannot be recorded")
         return out
     _call("ffm_eval_counts", L.ptr(prob), L.ptr(label), L.ptr(attr), N, num_groups, L.ptr(out), L.stream_ptr())
     return out

@@ -112,7 +112,10 @@ typedef struct ffm_gemm_args {
     const float* ln_rk;
     /* optional (128x128 kernel: RN50's 1x1 convolutions): [ffm_gemm_tiles_m][2][N] fp32, the column sums {sum, sum of
      * squares} of the STORED output over each row tile - the batch statistics of the BatchNorm that follows
-     * (ffm_bn_fwd's part / part_rows), so that it does not read the tensor once more to form them */
+     * (ffm_bn_fwd's part / part_rows), so that it does not read the tensor once more to form them.  A launch that
+     * asks for them always runs on the 128x128 / 128xN kernels (b_packed is then ignored: the panel kernel has no
+     * column-sum epilogue; ask ffm_gemm_tiles_m with packed = 0 for the row tiles); together with
+     * FFM_EPI_ROWSTATS / FFM_EPI_LNIN: FFM_EUNSUP */
     float*       colstat_part;
 } ffm_gemm_args;
 

@@ -63,3 +63,53 @@ def test_gpus_flag_launches_the_ranks_itself():
     j = last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["rccl_ranks"] == 2 and j["config"]["backend"] == "gloo"
     assert j["config"]["fedavg_round_boundary_us"] > 0 and j["config"]["clients"] == 2
+
+
+def _run_bench(extra, env=None, launcher=None, timeout=900):
+    base = [sys.executable, "bench.py"] if launcher is None else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher), "--master-addr",
+         "127.0.0.1", "--master-port", str(29520 + (launcher or 0) + len(extra)), "bench.py"]
+    r = subprocess.run(base + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return last_json(r.stdout)
+
+
+def test_rccl_executes_at_world_one_and_does_not_slow_the_step():
+    """torch.distributed.run with ONE rank and the nccl backend (= RCCL on ROCm): the round-boundary all-reduce really runs
+    through an RCCL communicator on this box's GPU, and with a communicator alive the three-stream step keeps its time
+    (GPU_MAX_HW_QUEUES=8, DESIGN section 5: RCCL's stream must not push a side stream onto the vision chain's queue).
+    No --gpus on the launched command: the world size comes from the launcher."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FFM_BENCH_ONE_DEVICE")}
+    common = ["--steps", "30", "--warmup", "5", "--no-roofline", "--no-trainer", "--no-cpu-baseline", "--no-secondary"]
+    plain = _run_bench(common, env=env)
+    assert plain["config"]["rccl_ranks"] == 1 and plain["config"]["backend"] is None
+    j = _run_bench(common, env=env, launcher=1)
+    assert j["n_gpus"] == 1 and j["config"]["backend"] == "nccl" and j["config"]["rccl_ranks"] == 1
+    assert j["config"]["fedavg_round_boundary_us"] > 0 and j["config"]["fedavg_payload_bytes"] == 741952 * 4
+    assert j["config"]["loss_finite"] == 1
+    # the un-launched line's 30 steps against the launched line's 30 steps + one round boundary (fractions of a ms)
+    assert j["ms_per_step"] < 1.05 * plain["ms_per_step"] + 0.05, (j["ms_per_step"], plain["ms_per_step"])
+
+
+@pytest.mark.parametrize("cfg,unit,buf", [("c4", "volumes/sec", False), ("c5", "images/sec", True)])
+def test_other_baseline_configs_launch_at_two_ranks(cfg, unit, buf):
+    """`bench.py --config c4 / c5 --gpus 2` (configs[3] 3D OCT r=16, configs[4] RN50 r=8 G=2): the N > 1 lines exist, end
+    with the FedAvg exchange of that workload's trainable buffer and, for RN50, the BatchNorm-buffer all-reduce."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["FFM_BENCH_ONE_DEVICE"] = "1"
+    j = _run_bench(["--config", cfg, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"], env=env)
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["unit"] == unit and j["config"]["clients"] == 2
+    assert j["config"]["backend"] == "gloo" and j["config"]["loss_finite"] == 1
+    assert j["config"]["fedavg_payload_bytes"] == 4 * j["config"]["trainable_elems"] > 0
+    assert ("fedavg_buffer_payload_bytes" in j["config"]) == buf
+    if buf:
+        assert j["config"]["fedavg_buffer_payload_bytes"] > 4 * 2 * 1000         # running mean + variance of 53 BatchNorms
+    assert ("configs[3]" if cfg == "c4" else "configs[4]") in j["config"]["workload"]
+
+
+def test_rn50_config_at_world_one_over_rccl_has_a_roofline():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FFM_BENCH_ONE_DEVICE")}
+    j = _run_bench(["--config", "c5", "--steps", "5", "--warmup", "2"], env=env, launcher=1)
+    assert j["config"]["backend"] == "nccl" and j["config"]["fedavg_buffer_payload_bytes"] > 0
+    ro = j["roofline"]
+    assert ro["bound"] == "mfma" and 0.01 < ro["frac"] < 1.0 and ro["launches_per_step"] > 100

@@ -116,3 +116,106 @@ def test_resize_image_properties():
     r = D.resize_image(ramp, (40, 40))
     d = np.diff(r[20, 4:-4])
     assert np.allclose(d, 0.5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# resize_image: skimage.transform.resize (utils/data_utils.py:667-679) cannot be imported here, so the restatement on
+# scipy is held to (i) numbers worked out by hand from skimage's published algorithm and (ii) a loop-level
+# implementation of that algorithm that shares no code (and no scipy call) with fairfedmed_amd.data.resize_image:
+#   1. shrinking along any axis -> Gaussian pre-filter, sigma = max(0, (in/out - 1) / 2) per axis, truncated at 4 sigma,
+#      borders mirrored about the edge pixel centres (numpy.pad 'reflect' = ndimage 'mirror');
+#   2. order-1 (linear) interpolation at x_in = (i + 0.5) * in / out - 0.5 (pixel-grid zoom), same mirroring;
+#   3. clip to the input's [min, max].
+# ----------------------------------------------------------------------------------------------------------------
+def _mirror(x, n):
+    if n == 1:
+        return 0.0
+    p = 2 * (n - 1)
+    x = abs(x) % p
+    return p - x if x > n - 1 else x
+
+
+def _gauss1d(v, sigma):
+    import math
+    if sigma <= 0:
+        return list(v)
+    rad = int(4.0 * sigma + 0.5)
+    w = [math.exp(-0.5 * (k / sigma) ** 2) for k in range(-rad, rad + 1)]
+    s = sum(w)
+    return [sum(w[k + rad] / s * v[int(round(_mirror(i + k, len(v))))] for k in range(-rad, rad + 1)) for i in range(len(v))]
+
+
+def _lerp1d(v, m):
+    import math
+    n, out = len(v), []
+    for i in range(m):
+        x = _mirror((i + 0.5) * n / m - 0.5, n)
+        i0 = min(int(math.floor(x)), n - 1)
+        i1, t = min(i0 + 1, n - 1), x - i0
+        out.append(v[i0] * (1 - t) + v[i1] * t)
+    return out
+
+
+def _resize_by_definition(img, shape):
+    img = np.asarray(img, dtype=np.float64)
+    H, W = img.shape
+    shrink = shape[0] < H or shape[1] < W
+    sy, sx = (max(0.0, (H / shape[0] - 1) / 2), max(0.0, (W / shape[1] - 1) / 2)) if shrink else (0.0, 0.0)
+    a = np.array([_gauss1d(list(img[:, c]), sy) for c in range(W)]).T
+    a = np.array([_gauss1d(list(a[r]), sx) for r in range(H)])
+    b = np.array([_lerp1d(list(a[:, c]), shape[0]) for c in range(W)]).T
+    b = np.array([_lerp1d(list(b[r]), shape[1]) for r in range(shape[0])])
+    return np.clip(b, img.min(), img.max())
+
+
+def test_resize_image_against_hand_derived_values():
+    from fairfedmed_amd.data import resize_image
+    # (a) 3 x 5 ramp f(r, c) = 10 r + c enlarged 2 x: no pre-filter; output row i reads r' = (i + 0.5) / 2 - 0.5 =
+    # -0.25, 0.25, 0.75, 1.25, 1.75, 2.25 -> mirrored to 0.25, 0.25, 0.75, 1.25, 1.75, 1.75; columns likewise
+    # (0.25, 0.25, 0.75, ..., 3.75, 3.75); linear interpolation is exact on a ramp: out = 10 r' + c'
+    ramp = np.array([[10 * r + c for c in range(5)] for r in range(3)], dtype=np.float32)
+    rows = [0.25, 0.25, 0.75, 1.25, 1.75, 1.75]
+    cols = [0.25, 0.25, 0.75, 1.25, 1.75, 2.25, 2.75, 3.25, 3.75, 3.75]
+    want = np.array([[10 * r + c for c in cols] for r in rows])
+    got = resize_image(ramp, (6, 10))
+    assert got.dtype == np.float32 and got.shape == (6, 10)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    # (b) an impulse of 8 at (2, 2) of a 6 x 4 image halved to 3 x 2: sigma = (2 - 1) / 2 = 0.5 on both axes, taps
+    # k = -2..2 with weights exp(-2 k^2) / 1.2713412 = 0.7865707, 0.1064507 (x2), 0.0002639 (x2).  Filtered column
+    # profile around row 2: w2 w1 w0 w1 w2 at rows 0..4; row profile in a 4-wide image: column 3 receives w1 twice (its
+    # right neighbour mirrors back onto column 2), column 0 receives w2, column 1 w1, column 2 w0 + w2 (column 4
+    # mirrors to 2).  Output (1, 1) averages rows 2, 3 and columns 2, 3:
+    #   8 * (w0 + w1) / 2 * ((w0 + w2) + 2 w1) / 2 = 8 * 0.4465107 * 0.4998680 = 1.7855717
+    w0, w1, w2 = 0.7865707, 0.1064507, 0.0002639
+    imp = np.zeros((6, 4), np.float32)
+    imp[2, 2] = 8.0
+    got = resize_image(imp, (3, 2))
+    assert abs(got[1, 1] - 8 * (w0 + w1) / 2 * ((w0 + w2) + 2 * w1) / 2) < 2e-6
+    assert abs(got[1, 1] - 1.7855717) < 2e-6
+    # output (0, 0) averages rows 0, 1 and columns 0, 1.  Row 0 sees the impulse row through k = +2 AND through k = -2
+    # (row -2 mirrors onto row 2): 2 w2; row 1 through k = +1 only: w1; the columns likewise:
+    #   8 * ((2 w2 + w1) / 2)^2 = 0.0228888
+    assert abs(got[0, 0] - 8 * ((2 * w2 + w1) / 2) ** 2) < 2e-6
+    np.testing.assert_allclose(got, _resize_by_definition(imp, (3, 2)), rtol=0, atol=2e-6)
+    # (c) general shapes (shrink, mixed, enlarge, identity) against the by-definition loops; the clip keeps the range
+    rng = np.random.default_rng(0)
+    x = (rng.random((7, 9)) * 255).astype(np.float32)
+    for shp in ((4, 4), (14, 5), (3, 18), (7, 9), (2, 2)):
+        out = resize_image(x, shp)
+        np.testing.assert_allclose(out, _resize_by_definition(x, shp), rtol=0, atol=3e-5)
+        assert out.min() >= x.min() and out.max() <= x.max()
+
+
+def test_fp16_precision_flag_is_mapped_to_bf16_with_a_warning():
+    """The reference's GPU default PREC='fp16' (federated_main.py:85) has no fp16 engine here: it runs as bf16 and says so."""
+    import warnings
+    import torch
+    from fairfedmed_amd.trainer import resolve_precision
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                  # the documented values are silent
+        assert resolve_precision("bf16") is torch.bfloat16
+        assert resolve_precision("fp32") is torch.float32 and resolve_precision("amp") is torch.float32
+    with pytest.warns(UserWarning, match="fp16.*bf16"):
+        assert resolve_precision("fp16") is torch.bfloat16
+    with pytest.raises(ValueError):
+        resolve_precision("int8")

@@ -336,3 +336,51 @@ def test_ranks_share_one_client_draw_and_one_lr_schedule():
         assert torch.allclose(se[0]["flat"][o:o + v.numel()], v.reshape(-1), rtol=1e-5, atol=1e-7), k
     # the per-client weights the CLI saves exist on every rank, for every client, under the trainable keys
     assert sorted(se[0]["keys"]) == [0, 1, 2, 3] and se[0]["keys"][0] == sorted(p.offsets)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GLOBAL_S with rank == num_groups: the 1-D lora_S_global [r] has shape[0] == G.  Neither driver may treat it as a
+# [G, r] block (the flat-buffer view would average over the neighbouring lora_B entries).
+# ----------------------------------------------------------------------------------------------------------------
+class _GlobalSTrainer(_FlatTrainer):
+    def __init__(self, users):
+        import dataclasses
+        from types import SimpleNamespace as NS
+        super().__init__(users)
+        base = C.vit_tiny(rank=2, num_groups=2)                        # 2 gender groups, rank 2
+        mcfg = dataclasses.replace(base, lora=dataclasses.replace(base.lora, global_s=True))
+        offsets, numel = _layout(mcfg)
+        assert any(k.endswith("lora_S_global.weight") and s == (2,) for k, (_, s) in offsets.items())
+        self.fed_train_loader_x_dict = {
+            i: NS(dataset=type("D", (), {"__len__": lambda s, n=40 * (i + 1): n,
+                                         "count_by_attribute": lambda s, a, i=i: [10 + i, 5 * (i + 1)]})())
+            for i in range(users)}
+        flat = _flatten(_client_state(mcfg, 99, 0), offsets, numel)
+        self.engine = NS(params=NS(flat=flat, offsets=offsets, keys=list(offsets)), cfg=mcfg)
+        self.mom = torch.zeros_like(flat)
+
+
+def _gs_worker(rank, world, port, outdir):
+    from fairfedmed_amd import federated as F
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = F.FedArgs(num_users=3, frac=1.0, round=2, shared_half_s=True, seed=5)
+    hist = F.run_fedotplora_ranks(_GlobalSTrainer(3), args, log=lambda *_: None)
+    torch.save({"flat": hist["global_flat"]}, os.path.join(outdir, f"gs{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_global_s_with_rank_equal_to_num_groups_over_two_ranks():
+    from fairfedmed_amd import federated as F
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gs_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        got = [torch.load(os.path.join(d, f"gs{r}.pt")) for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])
+    tr = _GlobalSTrainer(3)
+    hist = F.run_fedotplora(tr, F.FedArgs(num_users=3, frac=1.0, round=2, shared_half_s=True, seed=5), log=lambda *_: None)
+    p = tr.engine.params
+    for k, v in hist["global_weights"].items():
+        o, s = p.offsets[k]
+        assert tuple(v.shape) == tuple(s), k                           # no [r] -> [G, r] broadcast
+        ref = v.reshape(-1)
+        assert torch.allclose(got[0]["flat"][o:o + ref.numel()], ref, rtol=1e-5, atol=1e-7), k

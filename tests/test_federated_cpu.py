@@ -124,3 +124,36 @@ def test_round_loop_drives_the_trainer_like_the_reference():
     # lora_S rows use the per-group counts [i+1, 2, 3]: row 0 weight of client i = (i+1)/6
     s = hist["global_weights"]["m.lora_S.weight"]
     assert s.shape == (3, 4) and float(s[1, 0]) != float(s[0, 0])
+
+
+def test_group_s_rule_ignores_1d_tensors_when_rank_equals_num_groups():
+    """GLOBAL_S / SVLoRA keep 1-D [r] tensors whose keys contain 'lora_S'.  With rank == num_groups their
+    shape[0] equals G: they must still get the plain n_k / sum n weights, never the [G, r] block treatment
+    (which on the flat buffer would read G*r elements, over the neighbouring tensors)."""
+    from fairfedmed_amd.fedavg import FedAvgAggregator, element_weights, is_group_s_block
+    G = r = 2
+    assert is_group_s_block("m.lora_S.weight", (G, r), G)
+    assert not is_group_s_block("m.lora_S_global.weight", (r,), G)
+    assert not is_group_s_block("m.lora_S.weight", (r,), G)             # SVLoRA's one diagonal
+    assert not is_group_s_block("m.lora_A.weight", (G, r), G)
+    # flat layout: S_global [r] | lora_B [4, r] | S [G, r]
+    offsets = {"m.lora_S_global.weight": (0, (r,)), "m.lora_B.weight": (4, (4, r)), "m.lora_S.weight": (12, (G, r))}
+    n_client, by_attr = [10, 30], [[1, 3], [3, 1]]
+    w = element_weights(offsets, 16, 0, [0, 1], n_client, by_attr)
+    assert torch.allclose(w[:12], torch.full((12,), 0.25))                # plain weights, the neighbours untouched
+    assert torch.allclose(w[12:16], torch.tensor([0.25, 0.25, 0.75, 0.75]))
+    agg = FedAvgAggregator(torch.zeros(16), offsets, G, r)
+    assert agg.s_offsets.tolist() == [12]
+    # dict form: the 1-D tensor keeps its shape and the plain weights, with and without shared_half_s
+    torch.manual_seed(0)
+    ws = {u: {"m.lora_S_global.weight": torch.randn(r), "m.lora_B.weight": torch.randn(4, r),
+              "m.lora_S.weight": torch.randn(G, r)} for u in range(2)}
+    wg = {k: torch.zeros_like(v) for k, v in ws[0].items()}
+    for half in (False, True):
+        out = F.average_weights_ema(wg, ws, [0, 1], n_client, by_attr, 0, 4, shared_half_s=half)
+        assert out["m.lora_S_global.weight"].shape == (r,)
+        exp = 0.25 * ws[0]["m.lora_S_global.weight"] + 0.75 * ws[1]["m.lora_S_global.weight"]
+        assert torch.allclose(out["m.lora_S_global.weight"], exp)
+        assert torch.allclose(out["m.lora_B.weight"], 0.25 * ws[0]["m.lora_B.weight"] + 0.75 * ws[1]["m.lora_B.weight"])
+    s = out["m.lora_S.weight"]
+    assert float(s[0, 0]) == float(s[1, 0]) and float(s[0, 1]) != float(s[1, 1])   # first half shared, second not

@@ -570,6 +570,44 @@ def test_cli_under_torch_distributed_run_two_ranks(tmp_path):
     assert not (out / "global_flat_final.pth").exists()
 
 
+def test_cli_rank_path_over_rccl_world_one_equals_the_single_process_driver(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 -m fairfedmed_amd.federated_main ...` WITHOUT the gloo test rig:
+    the rank-parallel driver initialises the nccl backend (RCCL) on this box's GPU, its round-boundary all-reduces run
+    through an RCCL communicator, and with one rank the saved per-client weights must equal those of the one-process
+    driver (same clients, same order, same optimizer state)."""
+    import subprocess
+    import sys
+    from fairfedmed_amd import data as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    D.write_synthetic_fairfedmed(str(tmp_path / "DATA"), sites=2, n_train=16, n_test=8, size=64, seed=9)
+    (tmp_path / "tr.yaml").write_text('DATALOADER:\n  TRAIN_X:\n    BATCH_SIZE: 8\n  TEST:\n    BATCH_SIZE: 8\n'
+                                      'INPUT:\n  SIZE: (64, 64)\nMODEL:\n  BACKBONE:\n    NAME: "tiny"\n')
+    flags = ["--root", str(tmp_path / "DATA"), "--model", "FedOTPLoRA", "--trainer", "GLP_OT_SVLoRA", "--num_users", "2",
+             "--frac", "1.0", "--round", "2", "--OT", "None", "--attribute_type", "race", "--attributes", "race", "gender",
+             "--n_ctx", "4", "--num_prompt", "2", "--unfreeze_image_encoder", "True", "--lora_rank", "4", "--lora_alpha", "2",
+             "--lora_type", "FairLoRA", "--shared_half_s", "True", "--config-file", str(tmp_path / "tr.yaml"),
+             "--prec", "fp32", "--save-trainable-only", "--compat-sequential-optimizer"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "FFM_ONE_DEVICE")}
+    probe = ("import torch.distributed as d, fairfedmed_amd.federated as F; o = F.run_fedotplora_ranks\n"
+             "def w(*a, **k):\n    print('BACKEND', d.get_backend(), d.get_world_size(), flush=True); return o(*a, **k)\n"
+             "F.run_fedotplora_ranks = w\n"
+             "import sys; from fairfedmed_amd.federated_main import main; main(sys.argv[1:])")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", "--no-python", sys.executable, "-c", probe] + flags + ["--output-dir", str(tmp_path / "ranks")]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "BACKEND nccl 1" in r.stdout and "global_test_acc_list:" in r.stdout
+    r1 = subprocess.run([sys.executable, "-m", "fairfedmed_amd.federated_main"] + flags + ["--output-dir", str(tmp_path / "one")],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, (r1.stdout[-1500:], r1.stderr[-3000:])
+    for idx in range(2):
+        a = torch.load(tmp_path / "ranks" / f"global_client{idx}_final.pth")
+        b = torch.load(tmp_path / "one" / f"global_client{idx}_final.pth")
+        assert "prompt_learner.ctx" in a and set(a) <= set(b)           # (the rank driver keeps the trainable tensors)
+        for k in a:
+            assert torch.allclose(a[k].float(), b[k].float(), rtol=1e-5, atol=1e-7), k
+
+
 def test_rn_state_dict_keys_order_dtypes_and_live_buffers():
     """CustomCLIP over the RN50 engine: state_dict() has the reference ResNet's keys in ITS order (tests/golden/
     make_golden.py asserts manifest order == the imported reference's), BatchNorm counters are int64, running
