@@ -2,17 +2,22 @@
 #pragma once
 #include "common.h"
 
-// Panel-kernel tile configurations: block tile (16*MF) x (64*NF), 4 waves side by side along N, 16*NF columns each.
-// MF is chosen so that the A-ring pieces, 2*MF (+2 for the rank rows under FFM_EPI_RANKOP), split evenly over the
-// 4 waves (the counted vmcnt waits assume the same number of DMA pieces on every wave).
+// Panel-kernel tile configurations: block tile (16*MF) x (16*PW*NF), PW waves side by side along N, 16*NF columns each.
+// PW = 4: one wave per SIMD (up to 312 accumulator registers per wave); PW = 8: two waves per SIMD (<= 256 registers).
+// With PW = 4, MF is chosen so that the A-ring pieces, 2*MF (+2 for the rank rows under FFM_EPI_RANKOP), split evenly
+// over the waves; with PW = 8 the waves that run out of pieces repeat one (gemm_panel_impl.h, PanelGeom).
 struct ffm_panel_cfg {
     int mf, nf;
     bool rankop;     // instantiated for the FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
     int per_cu;      // blocks that share a CU (registers + LDS): a round is 256 * per_cu blocks
+    int pw;          // waves per block
 };
-constexpr int FFM_PANEL_NCFG = 5;
-constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1}, {16, 4, false, 1}, {10, 2, false, 1}, {11, 2, true, 1},
-                                                          {8, 4, false, 2}};
+constexpr int FFM_PANEL_NCFG = 8;
+constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1, 4}, {16, 4, false, 1, 4}, {10, 2, false, 1, 4}, {11, 2, true, 1, 4},
+                                                          {8, 4, false, 2, 4},
+                                                          // two waves per SIMD: the same tiles as 0, 3 and 2
+                                                          {13, 3, true, 1, 8}, {11, 1, true, 1, 8}, {10, 1, false, 1, 8}};
+constexpr int ffm_panel_bn(const ffm_panel_cfg& c) { return 16 * c.pw * c.nf; }
 
 // -1: use the 128x128 kernel; otherwise the index into FFM_PANEL_CFGS
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);

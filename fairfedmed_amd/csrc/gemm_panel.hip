@@ -3,6 +3,11 @@
 #include "gemm_panel_impl.h"
 #include <cstdlib>
 
+// two-waves-per-SIMD tiles on by default (FFM_PANEL8 overrides)
+#ifndef FFM_PANEL8_DEFAULT
+#define FFM_PANEL8_DEFAULT 0
+#endif
+
 namespace {
 
 // dst[((n16 * K/32 + k32) * 64 + lane) * 8 + i] = src[(n16*16 + (lane & 15)) * ld + k32*32 + (lane >> 4)*8 + i]
@@ -59,38 +64,49 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         return f && (f[0] == 'o' || f[0] == '0');
     }();
     if (panel_off) return -1;
+    // FFM_PANEL8 (A/B runs): 0 = never the two-waves-per-SIMD tiles, 1 (default) = wherever they serve the shape,
+    // or a bit mask over their configuration indices (bit 5 = 208x384 FairLoRA, 6 = 176x128 FairLoRA, 7 = 160x128 plain)
+    static const int pw8_mask = [] {
+        const char* f = getenv("FFM_PANEL8");
+        if (!f) return FFM_PANEL8_DEFAULT;
+        const int v = atoi(f);
+        return v == 1 ? ~0 : v;
+    }();
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     long best = ((t128 + 255) / 256) * 256;
     int pick = -1;
     for (int c = 0; c < FFM_PANEL_NCFG; ++c) {
-        const int bm = 16 * FFM_PANEL_CFGS[c].mf, bn = 64 * FFM_PANEL_CFGS[c].nf;
-        if (N % bn || FFM_PANEL_CFGS[c].rankop != rk) continue;
-        if ((flags & FFM_EPI_ROWSTATS) && (FFM_PANEL_CFGS[c].nf & (FFM_PANEL_CFGS[c].nf - 1))) continue;   // row sums: power-of-two lanes per row
+        const ffm_panel_cfg& cf = FFM_PANEL_CFGS[c];
+        const int bm = 16 * cf.mf, bn = ffm_panel_bn(cf), nfe = bn / 64;      // nfe: the tile's width in 64-column units
+        if (N % bn || cf.rankop != rk) continue;
+        if (cf.pw == 8 && !((pw8_mask >> c) & 1)) continue;
+        if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
-        const int per_cu = FFM_PANEL_CFGS[c].per_cu;
-        if (!rk && FFM_PANEL_CFGS[c].nf >= 4 && K < 1536 && per_cu == 1) continue;
+        const int per_cu = cf.per_cu;
+        if (!rk && nfe >= 4 && K < 1536 && per_cu == 1) continue;
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
         // more than one round of tiles loses to the 128x128 kernel, whose two blocks per CU overlap one tile's epilogue
         // with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
         // ... except the 208x384 FairLoRA tile at several rounds (bs 64: 488 blocks, 3D OCT: 19 700 rows -> 760 blocks): its epilogues
         // run at the HBM rate since round 2, and three rounds of it (~160 us) beat the 128x128 kernel's 206-228 us
-        const bool multi = rk && FFM_PANEL_CFGS[c].nf == 6 && blocks > 256;
+        const bool multi = rk && nfe == 6 && blocks > 256;
         if (blocks > 256 * per_cu && !multi) continue;
         // (a two-per-CU tile that fills less than half of its slots is a one-per-CU tile with a worse shape)
         if (per_cu > 1 && blocks <= 256) continue;
-        const long cost = (long)per_cu * (bm + bn) * (multi ? (blocks + 255) / 256 : 1);
-        if (cost < best) { best = cost; pick = c; }
+        // (the two-waves-per-SIMD twin of a tile wins the tie)
+        const long cost = 2 * (long)per_cu * (bm + bn) * (multi ? (blocks + 255) / 256 : 1) - (cf.pw == 8 ? 1 : 0);
+        if (cost < 2 * best) { best = (cost + 1) / 2; pick = c; }
     }
     return pick;
 }
 
 int ffm_panel_ds_rows(int M, int N, int cfg) {
-    const int bm = 16 * FFM_PANEL_CFGS[cfg].mf, bn = 64 * FFM_PANEL_CFGS[cfg].nf;
+    const int bm = 16 * FFM_PANEL_CFGS[cfg].mf, bn = ffm_panel_bn(FFM_PANEL_CFGS[cfg]);
     return ((M + bm - 1) / bm) * (N / bn);
 }
 
-int ffm_panel_tiles_n(int N, int cfg) { return N / (64 * FFM_PANEL_CFGS[cfg].nf); }
+int ffm_panel_tiles_n(int N, int cfg) { return N / ffm_panel_bn(FFM_PANEL_CFGS[cfg]); }
 
 #define PANEL_CASE(F)                                                                      \
     case F:                                                                                \
@@ -98,6 +114,7 @@ int ffm_panel_tiles_n(int N, int cfg) { return N / (64 * FFM_PANEL_CFGS[cfg].nf)
             case 1: return ffm_panel::launch_panel<16, 4, false, F>(a, s);                 \
             case 2: return ffm_panel::launch_panel<10, 2, false, F>(a, s);                 \
             case 4: return ffm_panel::launch_panel<8, 4, false, F>(a, s);                  \
+            case 7: return ffm_panel::launch_panel<10, 1, false, F, 8>(a, s);              \
         }                                                                                  \
         return FFM_EINVAL;
 

@@ -26,15 +26,18 @@
 
 namespace ffm_panel {
 
-constexpr int PW = 4;                      // waves per block: one per SIMD
-constexpr int PT = PW * 64;
+// Waves per block (template parameter PWV of the kernel): 4 = one per SIMD, each owning 16*NF columns of all rows and up
+// to 312 accumulator registers; 8 = two per SIMD (<= 256 registers each) side by side along N in the same way, so that
+// one wave's MFMAs issue while its SIMD partner sits in an LDS / VMEM issue slot or in the epilogue's VALU work.
 constexpr int PSTAGES = 4;                 // A ring depth (K64 stages)
 typedef bf16x8 frag_t;
 
-template <int MF, bool RK> struct PanelGeom {
+template <int MF, bool RK, int PWV> struct PanelGeom {
     static constexpr int NB8 = 2 * MF + (RK ? 2 : 0);        // 8-row x 128-B DMA pieces per stage (+16 rank rows)
-    static constexpr int NI = NB8 / PW;                      // pieces per wave, the same for all waves (counted waits)
-    static_assert(NB8 % PW == 0, "pick MF so that every wave issues the same number of DMA pieces");
+    // pieces per wave, the same for all waves (the counted waits depend on it): when NB8 is not a multiple of the wave
+    // count, the waves that run out repeat their previous piece (same source rows, same LDS destination: harmless)
+    static constexpr int NI = (NB8 + PWV - 1) / PWV;
+    static_assert(NI >= 2 || NB8 % PWV == 0, "a repeated piece needs a previous one");
     static constexpr int STAGE = NB8 * 1024;
     static constexpr int RING = PSTAGES * STAGE;
 };
@@ -89,18 +92,21 @@ __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }   
 // persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
 // f32 | row groups [BM]
 // | (LNIN) c [BN] f32, row mean / rstd [BM] f32 each
-__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false) {
-    return PW * 16 * nf * 4 + (rk ? PW * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? PW * 16 * nf * 4 + 2 * 16 * mf * 4 : 0);
+__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4) {
+    return pw * 16 * nf * 4 + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0);
 }
 
 // Two blocks per CU (two waves per SIMD) for the 128 x 256 plain tile: 128 accumulator registers and a 64 KiB ring
 // leave room for it, and the second wave issues MFMAs while the first sits in a VMEM / LDS issue slot.
-template <int MF, int NF, bool RK> constexpr int panel_waves_per_eu() { return (MF == 8 && NF == 4 && !RK) ? 2 : 1; }
+template <int MF, int NF, bool RK, int PWV> constexpr int panel_waves_per_eu() {
+    return (PWV == 8 || (MF == 8 && NF == 4 && !RK)) ? 2 : 1;
+}
 
-template <int MF, int NF, bool RK, int FL>
-__global__ __launch_bounds__(PT)
-__attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves_per_eu<MF, NF, RK>()))) void gemm_panel_kernel(ffm_gemm_args p) {
-    using G = PanelGeom<MF, RK>;
+template <int MF, int NF, bool RK, int FL, int PWV = 4>
+__global__ __launch_bounds__(PWV * 64)
+__attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_waves_per_eu<MF, NF, RK, PWV>()))) void gemm_panel_kernel(ffm_gemm_args p) {
+    constexpr int PW = PWV, PT = PWV * 64;
+    using G = PanelGeom<MF, RK, PWV>;
     constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
     static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
@@ -121,9 +127,12 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     // ---- A ring: per-lane source addresses of this wave's DMA pieces (piece = 8 rows x 128 B)
     const int rsub = lane >> 3, slot = lane & 7;
     const char* asrc[G::NI];
+    int apiece[G::NI];
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
-        const int piece = wave + PW * i;
+        int piece = wave + PW * i;
+        if (piece >= G::NB8) piece -= PW;                    // (wave-uniform) out of pieces: repeat the previous one
+        apiece[i] = piece;
         const int chunk = (slot ^ rsub) << 4;
         if (RK && piece >= 2 * MF) {
             const int row = (piece - 2 * MF) * 8 + rsub;
@@ -135,7 +144,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         }
     }
     auto dma_piece = [&](int kt, int i) {                    // piece i of ring stage kt
-        char* dst = smem + ((kt & 3) * G::STAGE) + wave * 1024 + i * (PW * 1024);
+        char* dst = smem + ((kt & 3) * G::STAGE) + apiece[i] * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 128),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
@@ -199,7 +208,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         // round trip behind: with NF MFMAs (16 cycles each) per fragment, AD * NF * 16 cycles must cover it.  The
         // reads are inline asm with counted s_waitcnt lgkmcnt (LDS returns in order): the compiler's own insertion
         // falls back to lgkmcnt(0) around the asm MFMAs and would wait for the prefetches too.
-        constexpr int AD = NF >= 6 ? 2 : (NF >= 4 ? 3 : 5);
+        // (two waves per SIMD: the partner covers the round trip, and the registers are needed elsewhere)
+        constexpr int AD = PW == 8 ? (NF >= 3 ? 2 : 3) : (NF >= 6 ? 2 : (NF >= 4 ? 3 : 5));
         const uint32_t sa = (uint32_t)(uintptr_t)st + (uint32_t)off;
         auto lds_read = [](frag_t& dst, uint32_t addr, auto OFF_) {
             if constexpr ((FFM_PANEL_ABL & 8) != 0) return;
@@ -232,10 +242,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
                 // fragment row, 0.4 us per K step.
                 // (Tiles whose accumulators already fill the register file cannot afford four loop copies: they spill.)
                 if constexpr (WSPEC) {
-                    if constexpr ((mf & (PW - 1)) == decltype(W_)::value)
+                    if constexpr ((mf % PW) == decltype(W_)::value)
                         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 } else {
-                    if ((mf & (PW - 1)) == wv)
+                    if ((mf % PW) == wv)
                         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 }
             }
@@ -279,7 +289,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
     float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
     int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
     constexpr bool LNIN = (flags & FFM_EPI_LNIN) != 0, ROWST = (flags & FFM_EPI_ROWSTATS) != 0;
-    float* Cv = reinterpret_cast<float*>(smem + G::RING + persist_bytes(MF, NF, RK));     // LNIN: c [BN]
+    float* Cv = reinterpret_cast<float*>(smem + G::RING + persist_bytes(MF, NF, RK, false, PW));     // LNIN: c [BN]
     float* Mu = Cv + BNp;                                     // row means [BM]
     float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
     const int r = RK ? p.rank : 0;
@@ -464,10 +474,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
         }
     };
     if constexpr (WSPEC) {                                       // one copy of the loop per wave (see half())
-        if (wave == 0) main_loop(I0{});
-        else if (wave == 1) main_loop(I1{});
-        else if (wave == 2) main_loop(std::integral_constant<int, 2>{});
-        else main_loop(std::integral_constant<int, 3>{});
+        static_for<PW>([&](auto WW_) {
+            if (wave == decltype(WW_)::value) main_loop(WW_);
+        });
     } else {
         main_loop(I0{});
     }
@@ -806,22 +815,23 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK>(), panel_waves
 #endif
 }
 
-template <int MF, int NF, bool RK, int FL>
+template <int MF, int NF, bool RK, int FL, int PWV = 4>
 int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
-    using G = PanelGeom<MF, RK>;
+    constexpr int PW = PWV, PT = PWV * 64;
+    using G = PanelGeom<MF, RK, PWV>;
     const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (PW * 16 * NF));
-    constexpr int lds = G::RING + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0);
+    constexpr int lds = G::RING + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, PW);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((RK ? 16 * MF * 192 : 0) + PW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? PW * 16 * MF * 8 : 0) <= G::RING,
                   "epilogue tiles alias the ring");
     static bool done = false;                         // one per instantiation
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL, PWV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL>), dim3(tiles), dim3(PT), lds, s, a);
+    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL, PWV>), dim3(tiles), dim3(PT), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

@@ -193,6 +193,36 @@ def vision_block(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int, attr: Opt
 # trainers/GLP_OT_SVLoRA.py:541-573; BatchNorm in train mode updates its running
 # statistics IN PLACE in `sd`, as nn.BatchNorm2d does during the reference's forward.
 # --------------------------------------------------------------------------
+class _StoreBF16(torch.autograd.Function):
+    """A tensor written to memory as bfloat16 and read back (value AND gradient): what a 16-bit engine does to every
+    activation it keeps.  Not part of the reference's algorithm - see STORE below."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+# Control for the bf16 parity bounds of the RN tower (tests/test_fullsize_gpu.py): None = the reference's fp32
+# algorithm.  Set to `store_bf16` the SAME fp32 algorithm rounds every stored activation of the ResNet trunk (convolution
+# outputs, BatchNorm / ReLU outputs, pooled maps, block outputs) and its gradient to bfloat16 - an independent statement of
+# "this network with 16-bit activation storage", against which the HIP bf16 engine's distance from the fp32 oracle
+# can be judged (ReLU masks flip under 2^-9 perturbations; the fp32-vs-bf16 gradient cosine of a random-weight RN50 is
+# set by that, not by any kernel).
+STORE = None
+
+
+def store_bf16(x: Tensor) -> Tensor:
+    return _StoreBF16.apply(x)
+
+
+def _st(x: Tensor) -> Tensor:
+    return x if STORE is None else STORE(x)
+
+
 def batch_norm(sd: Dict[str, Tensor], p: str, x: Tensor, training: bool) -> Tensor:
     if training:
         sd[p + "num_batches_tracked"] += 1
@@ -210,16 +240,16 @@ def bottleneck(sd: Dict[str, Tensor], p: str, x: Tensor, attr: Optional[Tensor],
                                sd[q + "lora_S.weight"], sd[q + "lora_B.weight"], attr, scaling,
                                sd.get(q + "lora_S_global.weight"))
 
-    out = F.relu(batch_norm(sd, p + "bn1.", lora_conv("conv1", x), training))
-    out = F.relu(batch_norm(sd, p + "bn2.", F.conv2d(out, sd[p + "conv2.weight"], None, padding=1), training))
+    out = _st(F.relu(batch_norm(sd, p + "bn1.", _st(lora_conv("conv1", x)), training)))
+    out = _st(F.relu(batch_norm(sd, p + "bn2.", _st(F.conv2d(out, sd[p + "conv2.weight"], None, padding=1)), training)))
     if stride > 1:
-        out = F.avg_pool2d(out, stride)
-    out = batch_norm(sd, p + "bn3.", lora_conv("conv3", out), training)
+        out = _st(F.avg_pool2d(out, stride))
+    out = batch_norm(sd, p + "bn3.", _st(lora_conv("conv3", out)), training)
     identity = x
     if p + "downsample.0.weight" in sd:
-        identity = F.avg_pool2d(x, stride) if stride > 1 else x
-        identity = batch_norm(sd, p + "downsample.1.", F.conv2d(identity, sd[p + "downsample.0.weight"]), training)
-    return F.relu(out + identity)
+        identity = _st(F.avg_pool2d(x, stride)) if stride > 1 else x
+        identity = _st(batch_norm(sd, p + "downsample.1.", _st(F.conv2d(identity, sd[p + "downsample.0.weight"])), training))
+    return _st(F.relu(out + identity))
 
 
 def attention_pool(sd: Dict[str, Tensor], p: str, x: Tensor, heads: int, scaling: float) -> Tensor:
@@ -249,9 +279,9 @@ def resnet_forward(sd: Dict[str, Tensor], image: Tensor, attr: Optional[Tensor],
     v, ie, sc = cfg.vision, "image_encoder.", cfg.lora.scaling
     x = image
     for i, stride in ((1, 2), (2, 1), (3, 1)):
-        x = F.relu(batch_norm(sd, f"{ie}bn{i}.", F.conv2d(x, sd[f"{ie}conv{i}.weight"], None, stride=stride, padding=1),
-                              training))
-    x = F.avg_pool2d(x, 2)
+        x = _st(F.relu(batch_norm(sd, f"{ie}bn{i}.", _st(F.conv2d(x, sd[f"{ie}conv{i}.weight"], None, stride=stride, padding=1)),
+                                  training)))
+    x = _st(F.avg_pool2d(x, 2))
     for li, nblk in enumerate(v.layers):
         for j in range(nblk):
             x = bottleneck(sd, f"{ie}layer{li + 1}.{j}.", x, attr, 2 if (li > 0 and j == 0) else 1, sc, training)
