@@ -3,9 +3,11 @@
 #include "gemm_panel_impl.h"
 #include <cstdlib>
 
-// two-waves-per-SIMD tiles on by default (FFM_PANEL8 overrides)
-#ifndef FFM_PANEL8_DEFAULT
-#define FFM_PANEL8_DEFAULT 0
+// Default set of the newer configurations (see ffm_panel_select): the two-waves-per-SIMD 208x384 FairLoRA tile
+// (7: c_fc forward 53.8 -> 44.7 us, dX(c_proj) 50.5 -> 44.5 us, tools/bench_panel.py).  The 128-column two-wave twins
+// (5, 6) measured no gain - those shapes are bound by the CU's vector-memory path, not by one wave's in-order issue.
+#ifndef FFM_PANEL_MASK_DEFAULT
+#define FFM_PANEL_MASK_DEFAULT (1 << 7)
 #endif
 
 namespace {
@@ -64,13 +66,12 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         return f && (f[0] == 'o' || f[0] == '0');
     }();
     if (panel_off) return -1;
-    // FFM_PANEL8 (A/B runs): 0 = never the two-waves-per-SIMD tiles, 1 (default) = wherever they serve the shape,
-    // or a bit mask over their configuration indices (bit 5 = 208x384 FairLoRA, 6 = 176x128 FairLoRA, 7 = 160x128 plain)
-    static const int pw8_mask = [] {
-        const char* f = getenv("FFM_PANEL8");
-        if (!f) return FFM_PANEL8_DEFAULT;
-        const int v = atoi(f);
-        return v == 1 ? ~0 : v;
+    // Configurations 5 and up are enabled by a bit mask (default FFM_PANEL_MASK_DEFAULT; FFM_PANEL_MASK=<int> overrides, A/B
+    // runs): 5 = 176x128 FairLoRA two waves per SIMD, 6 = 160x128 plain ditto, 7 = 208x384 FairLoRA ditto, 8 = 160x128
+    // FairLoRA, 9 = 240x256 plain, 10 = 240x256 plain two waves per SIMD
+    static const int exp_mask = [] {
+        const char* f = getenv("FFM_PANEL_MASK");
+        return f ? atoi(f) : FFM_PANEL_MASK_DEFAULT;
     }();
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     long best = ((t128 + 255) / 256) * 256;
@@ -79,12 +80,12 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         const ffm_panel_cfg& cf = FFM_PANEL_CFGS[c];
         const int bm = 16 * cf.mf, bn = ffm_panel_bn(cf), nfe = bn / 64;      // nfe: the tile's width in 64-column units
         if (N % bn || cf.rankop != rk) continue;
-        if (cf.pw == 8 && !((pw8_mask >> c) & 1)) continue;
+        if (c >= 5 && !((exp_mask >> c) & 1)) continue;
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
         const int per_cu = cf.per_cu;
-        if (!rk && nfe >= 4 && K < 1536 && per_cu == 1) continue;
+        if (!rk && nfe >= 4 && K < 1536 && per_cu == 1 && c < 5) continue;
         const long blocks = (long)((M + bm - 1) / bm) * (N / bn);
         // more than one round of tiles loses to the 128x128 kernel, whose two blocks per CU overlap one tile's epilogue
         // with the other's main loop (qkv at bs 32: 720 blocks of 160x128, 36.9 us against 32.5 us)
@@ -114,7 +115,9 @@ int ffm_panel_tiles_n(int N, int cfg) { return N / ffm_panel_bn(FFM_PANEL_CFGS[c
             case 1: return ffm_panel::launch_panel<16, 4, false, F>(a, s);                 \
             case 2: return ffm_panel::launch_panel<10, 2, false, F>(a, s);                 \
             case 4: return ffm_panel::launch_panel<8, 4, false, F>(a, s);                  \
-            case 7: return ffm_panel::launch_panel<10, 1, false, F, 8>(a, s);              \
+            case 6: return ffm_panel::launch_panel<10, 1, false, F, 8>(a, s);              \
+            case 9: return ffm_panel::launch_panel<15, 4, false, F>(a, s);                 \
+            case 10: return ffm_panel::launch_panel<15, 2, false, F, 8>(a, s);             \
         }                                                                                  \
         return FFM_EINVAL;
 

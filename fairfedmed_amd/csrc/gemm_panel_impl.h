@@ -185,9 +185,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (two waves per SIMD: hipcc splits the 256 registers of a wave 128 / 128 between the two files)
+    constexpr int ACC_A = PW == 8 ? 32 : 64;                  // accumulator fragments kept in AGPRs
     auto mma = [&](auto IDX_, f32x4& c, const frag_t& a, const frag_t& b) {
         if constexpr ((FFM_PANEL_ABL & 4) != 0) return;
-        if constexpr (decltype(IDX_)::value < 64)
+        if constexpr (decltype(IDX_)::value < ACC_A)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
         else
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -489,7 +491,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PITCH = stage_pitch(NF);
     constexpr int CPR = 2 * NF;                       // 8-column chunks per row of the wave's slab
     constexpr int NRG = (MF + 1) / 2;                 // 32-row groups
-    constexpr int PF = NRG < 3 ? NRG : 3;             // row groups of residual / pre-activation rows kept in flight
+    // row groups of residual / pre-activation rows kept in flight (two waves per SIMD: the register budget is 256)
+    constexpr int PFMAX = (PW == 8 && NF >= 3) ? 2 : 3;
+    constexpr int PF = NRG < PFMAX ? NRG : PFMAX;
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
     float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + wave * (32 * PITCH);
@@ -657,7 +661,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         FFM_STAMP(10);
         // ts fragments in batches ahead of their MFMAs (the weight-fragment ring is dead; a tile whose accumulators
         // and pre-activation rows already fill the register file takes smaller batches)
-        constexpr int TB = MF * NF > 64 ? 4 : MF;
+        constexpr int TB = (MF * NF > 64 || (PW == 8 && NF >= 3)) ? 4 : MF;
         static_for<(MF + TB - 1) / TB>([&](auto B_) {
             constexpr int b0 = decltype(B_)::value * TB;
             constexpr int nb = (MF - b0) < TB ? (MF - b0) : TB;
@@ -692,7 +696,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             const uint32_t cwl = cw_lane;               // (named outside the if constexpr so that the lambda captures them)
             const f32x4(&accr)[MF][NF] = acc;
             if constexpr (mf < MF) {
-                if constexpr (mf * NF + nf < 64)
+                if constexpr (mf * NF + nf < ACC_A)
                     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(cwl), "a"(accr[mf][nf][e]), "n"(off) : "memory");
                 else
                     asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(cwl), "v"(accr[mf][nf][e]), "n"(off) : "memory");

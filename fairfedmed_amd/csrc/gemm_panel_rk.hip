@@ -6,8 +6,9 @@
         switch (cfg) {                                                                     \
             case 0: return ffm_panel::launch_panel<13, 6, true, F>(a, s);                  \
             case 3: return ffm_panel::launch_panel<11, 2, true, F>(a, s);                  \
-            case 5: return ffm_panel::launch_panel<13, 3, true, F, 8>(a, s);               \
-            case 6: return ffm_panel::launch_panel<11, 1, true, F, 8>(a, s);               \
+            case 5: return ffm_panel::launch_panel<11, 1, true, F, 8>(a, s);               \
+            case 7: return ffm_panel::launch_panel<13, 3, true, F, 8>(a, s);               \
+            case 8: return ffm_panel::launch_panel<10, 2, true, F>(a, s);                  \
         }                                                                                  \
         return FFM_EINVAL;
 
@@ -20,7 +21,8 @@ int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s) {
         case FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS:            // ... leaving row sums for ln_1
             // (the 128-column tiles only: a row's lanes must form a power-of-two group)
             if (cfg == 3) return ffm_panel::launch_panel<11, 2, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS>(a, s);
-            if (cfg == 6) return ffm_panel::launch_panel<11, 1, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS, 8>(a, s);
+            if (cfg == 5) return ffm_panel::launch_panel<11, 1, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS, 8>(a, s);
+            if (cfg == 8) return ffm_panel::launch_panel<10, 2, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS>(a, s);
             return FFM_EINVAL;
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                      // dX of c_proj
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR)                                      // dX of c_fc

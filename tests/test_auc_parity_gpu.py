@@ -80,7 +80,8 @@ CASES = {
     # the fp32 run itself swing between AUC 0.2 and 0.99, tools/rn_auc_sweep.py); bn3.weight x 0.25 (CLIP zero-initialises
     # it, clip/model.py:545-548; with N(1, 0.1) gammas the random trunk is chaotic in every precision)
     "rn_tiny2": (lambda: C.rn_tiny2(rank=4, num_groups=2), "gender", 3,     12,     8,  32,    64,     2e-3, 0.45, 0.25),
-    "vit_b16":  (lambda: C.vit_b16(rank=8),                "race",   2,     4,      8,  8,     64,     2e-2, 0.45, 1.0),
+    # (signal 0.1: the AUC sits at 0.78 after two rounds - at 0.45 the 224 x 224 task saturates at 0.9999, tools/vitb_auc_calib.py)
+    "vit_b16":  (lambda: C.vit_b16(rank=8),                "race",   2,     4,      8,  8,     64,     2e-2, 0.10, 1.0),
 }
 # bf16 tolerance per tower.  ViT: north_star's 0.002.  RN: every stored activation of a ReLU / BatchNorm trunk is a
 # 2^-9 perturbation that flips ReLU masks, and the test measures how far THE ORACLE ITSELF moves when its stored
