@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm
 F32, BF16, F32_X3 = 0, 1, 2
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
 EPI_ROWSTATS, EPI_LNIN = 128, 256
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -99,6 +99,10 @@ SIGNATURES = {
     "ffm_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_ce_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_text_embed": [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_text_tail_fwd": [_vp] * 10 + [_i32] * 4 + [_vp],
+    "ffm_text_tail_bwd": [_vp] * 11 + [_i32] * 5 + [_vp],
+    "ffm_text_ctx_grad": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_sgd_momentum": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "ffm_sgd_momentum_n": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
     "ffm_sgd_momentum_dev": [_vp, _vp, _vp, _i64, _vp, _vp],

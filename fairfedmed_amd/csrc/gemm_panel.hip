@@ -3,11 +3,14 @@
 #include "gemm_panel_impl.h"
 #include <cstdlib>
 
-// Default set of the newer configurations (see ffm_panel_select): the two-waves-per-SIMD 208x384 FairLoRA tile
-// (7: c_fc forward 53.8 -> 44.7 us, dX(c_proj) 50.5 -> 44.5 us, tools/bench_panel.py).  The 128-column two-wave twins
-// (5, 6) measured no gain - those shapes are bound by the CU's vector-memory path, not by one wave's in-order issue.
+// Default set of the newer configurations (tools/bench_panel.py, isolated launches at bs 32; FFM_PANEL_MASK=<int> for A/B):
+//   7  208x384 FairLoRA, two waves per SIMD: c_fc forward 53.8 -> 44.7 us, dX(c_proj) 50.5 -> 44.5 us
+//   8  160x128 FairLoRA (240 blocks where the 176-row tile launches 216): c_proj forward 40.2 -> 38.1, dX(c_fc) 39.6 -> 38.8
+//   10 240x256 plain, two waves per SIMD (243 blocks): qkv forward 31.9 -> 27.7 us (one wave per SIMD, 9: 32.9)
+// Off: the 128-column two-wave twins (5, 6) measured no gain - those shapes are bound by the CU's vector-memory path
+// (LDS-DMA fills + weight fragments at ~70 GB/s per CU), not by one wave's in-order issue.
 #ifndef FFM_PANEL_MASK_DEFAULT
-#define FFM_PANEL_MASK_DEFAULT (1 << 7)
+#define FFM_PANEL_MASK_DEFAULT ((1 << 7) | (1 << 8) | (1 << 10))
 #endif
 
 namespace {

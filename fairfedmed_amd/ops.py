@@ -593,6 +593,46 @@ def head_fwd(f: Tensor, tbar: Tensor, logit_scale: Tensor, fbar: Tensor, rnorm: 
                                   L.dtype_code(f.dtype), L.stream_ptr())
 
 
+def text_embed(prefix: Tensor, ctx: Tensor, suffix: Tensor, pos: Tensor, x: Tensor, n_cls: int, TL: int) -> None:
+    """prompts = [prefix, ctx, suffix] + positional embedding -> text tower input x [n_text * TL, w] (ffm_text_embed)."""
+    _dev(prefix, ctx, suffix, pos, x)
+    n_prompts, n_ctx, w = ctx.shape
+    for t in (prefix, ctx, suffix, pos, x):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert prefix.shape[0] == suffix.shape[0] == n_prompts * n_cls and x.shape[0] >= n_prompts * n_cls * TL and pos.shape[0] >= TL
+    _call("ffm_text_embed", L.ptr(prefix), L.ptr(ctx), L.ptr(suffix), suffix.shape[1], L.ptr(pos), L.ptr(x), n_prompts, n_cls,
+          n_ctx, TL, w, L.stream_ptr())
+
+
+def text_tail_fwd(x: Tensor, eot_row: Tensor, lnw: Tensor, lnb: Tensor, proj: Tensor, tf: Tensor, tn: Tensor, rnorm: Tensor,
+                  stats: Tensor, tbar: Optional[Tensor], n_prompts: int, n_cls: int) -> None:
+    """EOT gather -> ln_final -> text_projection -> normalise (-> mean over the prompts into tbar) (ffm_text_tail_fwd)."""
+    _dev(x, eot_row, lnw, lnb, proj, tf, tn, rnorm, stats, tbar)
+    assert eot_row.dtype == torch.int32 and x.dtype == torch.float32 and proj.dtype == torch.float32 and proj.is_contiguous()
+    w, D = proj.shape
+    assert x.shape[1] == w and tf.shape == tn.shape == (n_prompts * n_cls, D) and tf.is_contiguous() and tn.is_contiguous()
+    _call("ffm_text_tail_fwd", L.ptr(x), L.ptr(eot_row), L.ptr(lnw), L.ptr(lnb), L.ptr(proj), L.ptr(tf), L.ptr(tn), L.ptr(rnorm),
+          L.ptr(stats), L.ptr(tbar), n_prompts, n_cls, w, D, L.stream_ptr())
+
+
+def text_tail_bwd(x: Tensor, eot_row: Tensor, lnw: Tensor, proj: Tensor, tn: Tensor, rnorm: Tensor, stats: Tensor,
+                  dtbar: Optional[Tensor], dtn: Optional[Tensor], dy: Tensor, g: Tensor, n_prompts: int, n_cls: int, TL: int) -> None:
+    """Gradient of the head's text operand -> gradient of the tower's output rows g [n_text * TL, w] (ffm_text_tail_bwd)."""
+    _dev(x, eot_row, lnw, proj, tn, rnorm, stats, dtbar, dtn, dy, g)
+    w, D = proj.shape
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.shape[0] >= n_prompts * n_cls * TL and g.shape[1] == w
+    _call("ffm_text_tail_bwd", L.ptr(x), L.ptr(eot_row), L.ptr(lnw), L.ptr(proj), L.ptr(tn), L.ptr(rnorm), L.ptr(stats),
+          L.ptr(dtbar), L.ptr(dtn), L.ptr(dy), L.ptr(g), n_prompts, n_cls, TL, w, D, L.stream_ptr())
+
+
+def text_ctx_grad(g: Tensor, dctx: Tensor, n_cls: int, TL: int) -> None:
+    """d ctx [n_prompts, n_ctx, w] = the tower input gradient's ctx rows summed over the classes (ffm_text_ctx_grad)."""
+    _dev(g, dctx)
+    n_prompts, n_ctx, w = dctx.shape
+    assert g.dtype == dctx.dtype == torch.float32 and g.is_contiguous() and dctx.is_contiguous()
+    _call("ffm_text_ctx_grad", L.ptr(g), L.ptr(dctx), n_prompts, n_cls, n_ctx, TL, w, L.stream_ptr())
+
+
 def ce_loss(logits_img: Tensor, label: Tensor, logits: Tensor, prob: Tensor, loss: Tensor, dlogits_img: Tensor,
             finite: Optional[Tensor], nb: int, S: int, n_cls: int) -> None:
     _dev(logits_img, label, logits, prob, loss, dlogits_img, finite)

@@ -44,7 +44,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 6   /* 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 7   /* 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -379,6 +379,34 @@ int ffm_ce_loss(const float* logits_img, const int64_t* label, float* logits, fl
 int ffm_head_bwd(const void* f, const float* tbar, const float* logit_scale, const float* fbar,
                  const float* rnorm, const float* dlogits_img, void* df, float* dtbar, int B,
                  int L, int D, int n_cls, int dtype, void* stream);
+
+/*
+ * The two ends of the text tower (float32; n_text = n_prompts * n_cls rows, text row p = n * n_cls + c).
+ *
+ * ffm_text_embed: PromptLearner.forward with the class token at the end + the positional embedding
+ * (trainers/GLP_OT_SVLoRA.py:131-152, :57): x [n_text * TL, w], row (p, t) = {prefix[p] | ctx[p / n_cls][t - 1] |
+ * suffix[p][t - 1 - n_ctx]} + pos[t]; prefix [n_text, 1, w], ctx [n_prompts, n_ctx, w], suffix [n_text, suffix_rows, w]
+ * (the first TL - 1 - n_ctx of its rows are read), pos [>= TL, w].
+ *
+ * ffm_text_tail_fwd: x[eot_row[p]] (eot_row: absolute row of each prompt's EOT token, tokenized_prompts.argmax, :64)
+ * -> ln_final (eps 1e-5) -> @ text_projection [w, D] (:62-64) -> F.normalize (:716): tf [n_text, D] (un-normalised),
+ * tn [n_text, D], rnorm [n_text] = 1 / max(|tf|, 1e-12), stats [n_text, 2] = {mean, rstd} of ln_final, and - when tbar is
+ * not NULL - tbar [n_cls, D] = mean over the prompts of tn (the OT = 'None' head's text operand, :713-717).
+ *
+ * ffm_text_tail_bwd: exactly one of dtbar [n_cls, D] (gradient of that mean) and dtn [n_text, D] (transport heads) ->
+ * g [n_text * TL, w]: the gradient w.r.t. the tower's output, zero on every row that is not an EOT row; dy [n_text, w]
+ * is scratch.  ffm_text_ctx_grad: dctx [n_prompts, n_ctx, w] = the tower's INPUT gradient g at the ctx rows, summed
+ * over the classes that share a prompt's context.
+ */
+int ffm_text_embed(const float* prefix, const float* ctx, const float* suffix, int suffix_rows, const float* pos, float* x,
+                   int n_prompts, int n_cls, int n_ctx, int TL, int w, void* stream);
+int ffm_text_tail_fwd(const float* x, const int32_t* eot_row, const float* lnw, const float* lnb, const float* proj,
+                      float* tf, float* tn, float* rnorm, float* stats, float* tbar, int n_prompts, int n_cls, int w,
+                      int D, void* stream);
+int ffm_text_tail_bwd(const float* x, const int32_t* eot_row, const float* lnw, const float* proj, const float* tn,
+                      const float* rnorm, const float* stats, const float* dtbar, const float* dtn, float* dy, float* g,
+                      int n_prompts, int n_cls, int TL, int w, int D, void* stream);
+int ffm_text_ctx_grad(const float* g, float* dctx, int n_prompts, int n_cls, int n_ctx, int TL, int w, void* stream);
 
 /*
  * uint8 input transport: dst fp32 [B, C1*rep, HW] = (float) src u8 [B, C1, HW] with every source channel repeated
