@@ -305,8 +305,7 @@ class FairLoRAEngine:
             if self.ot not in ops.OT_MODES:
                 raise NotImplementedError(cfg.ot)
             P, M, N = max_images * cfg.n_cls, v.tokens - 1, cfg.n_prompts
-            self.tn_buf = torch.zeros(N * cfg.n_cls, v.out_dim, device=dev, dtype=f32)
-            self.dtn = torch.zeros_like(self.tn_buf)
+            self.dtn = torch.zeros(N * cfg.n_cls, v.out_dim, device=dev, dtype=f32)
             self.ot_sim = torch.zeros(P * M * N, device=dev, dtype=f32)
             self.ot_T = torch.zeros_like(self.ot_sim)
             self.ot_errs = torch.zeros(cfg.ot_max_iter * P, device=dev, dtype=f32)
@@ -315,8 +314,17 @@ class FairLoRAEngine:
             self.ot_dtn_part = torch.zeros(max_images * N * cfg.n_cls * v.out_dim, device=dev, dtype=f32)
         self.step_plans: Dict[tuple, list] = {}
         self.use_replay = True                        # replay recorded launch plans (host-side "graph")
+        # the two ends of the text tower (csrc/text.hip): absolute EOT row of every prompt, the un-normalised / normalised
+        # text features, 1 / norm and ln_final's statistics kept for the way back, the projection's input gradient
         self.eot_rows = torch.tensor([i * self.txt_len + cfg.eot[i % cfg.n_cls] for i in range(self.n_text)],
-                                     device=dev, dtype=torch.int64)
+                                     device=dev, dtype=torch.int32)
+        self.tf_buf = torch.zeros(self.n_text, v.out_dim, device=dev, dtype=f32)
+        self.tn_all = torch.zeros(self.n_text, v.out_dim, device=dev, dtype=f32)
+        self.t_rnorm = torch.zeros(self.n_text, device=dev, dtype=f32)
+        self.t_stats = torch.zeros(self.n_text, 2, device=dev, dtype=f32)
+        self.t_dy = torch.zeros(self.n_text, t.width, device=dev, dtype=f32)
+        if self.ot:
+            self.tn_buf = self.tn_all                     # the transport heads read every prompt's normalised feature
         # The text tower (308 token rows) is latency-bound and independent of the vision tower until the
         # logits head, so it runs on its own HIP stream beside it (forward and backward).
         self.side = self._side0 = torch.cuda.Stream(device=self.device)
@@ -581,9 +589,10 @@ class FairLoRAEngine:
         return st.x[st.layers][:rows]
 
     def _stack_backward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
-                        need_input_grad: bool) -> Tensor:
-        """st.g[:rows] holds dL/d(tower output); on return it holds dL/d(tower input)
-        (if need_input_grad).  LoRA gradients are written into params.grad."""
+                        need_input_grad: bool, grad_in_last: bool = False) -> Tensor:
+        """st.g[:rows] holds dL/d(tower output) (a FairLoRA tower with grad_in_last: st.g_l[layers - 1] does - the buffer the
+        last block's reductions read - and no copy is made); on return st.g holds dL/d(tower input) (if need_input_grad).
+        LoRA gradients are written into params.grad."""
         lo = self.cfg.lora
         r, G, w = st.rank, lo.num_groups, st.width
         gemm = st.gemm
@@ -597,7 +606,7 @@ class FairLoRAEngine:
             if r:
                 # gradient w.r.t. this block's output lives in its own buffer (read later by the side stream)
                 gi, dpre = st.g_l[i][:rows], st.dpre_l[i][:rows]
-                if i == st.layers - 1:
+                if i == st.layers - 1 and not grad_in_last:
                     self._glue(lambda gi=gi, g=g: gi.copy_(g))
                 u, us2, us1 = st.u[:rows], st.us2[i][:rows], st.us1[i][:rows]
                 pt = st.part[i]
@@ -742,59 +751,27 @@ class FairLoRAEngine:
             return self.ctx.__exit__(*a)
 
     # --------------------------------------------------------------- text --
-    def _text_glue_in(self) -> None:
-        """prompts = [prefix, ctx, suffix] + pos -> text tower input (trainers/GLP_OT_SVLoRA.py:131-152,57)."""
-        cfg, t = self.cfg, self.cfg.text
-        ctx = self.params.view("prompt_learner.ctx")
-        ctx_rows = ctx.unsqueeze(1).expand(cfg.n_prompts, cfg.n_cls, cfg.n_ctx, t.width).reshape(
-            self.n_text, cfg.n_ctx, t.width)
-        TL = self.txt_len
-        prompts = torch.cat([self.tok_prefix, ctx_rows, self.tok_suffix[:, :TL - 1 - cfg.n_ctx]], dim=1) + self.txt_pos[:TL]
-        rows = self.n_text * TL
-        self.txt.x[0][:rows].copy_(prompts.reshape(rows, t.width))
-
-    def _text_glue_out(self, with_grad: bool) -> None:
-        """EOT gather, ln_final, projection, normalise (, mean over prompts) -> tbar_buf [n_cls, D], or with a transport
-        head every prompt's normalised feature tn_buf [N*n_cls, D]
-        (trainers/GLP_OT_SVLoRA.py:62-64, 709-715).  4 rows: PyTorch glue, with autograd for the way back."""
-        cfg, t = self.cfg, self.cfg.text
+    def _text_forward(self, with_grad: bool = True, stream=None) -> None:
+        """prompts = [prefix, ctx, suffix] + pos -> text tower -> EOT gather, ln_final, projection, normalise (, mean over
+        the prompts) -> tbar_buf [n_cls, D], or with a transport head every prompt's normalised feature tn_buf [N*n_cls, D]
+        (trainers/GLP_OT_SVLoRA.py:131-152, 55-66, 709-718): HIP kernels end to end (csrc/text.hip)."""
+        cfg = self.cfg
         rows = self.n_text * self.txt_len
-        xe = self.txt.x[self.txt.layers][:rows][self.eot_rows].float()
-        with torch.set_grad_enabled(with_grad):
-            if with_grad:
-                xe.requires_grad_(True)
-            y = torch.nn.functional.layer_norm(xe, (t.width,), self.lnfinal[0], self.lnfinal[1], 1e-5)
-            tf = (y @ self.text_proj).view(cfg.n_prompts, cfg.n_cls, -1)
-            tn = torch.nn.functional.normalize(tf, dim=2)
-            tout = tn.reshape(cfg.n_prompts * cfg.n_cls, -1) if self.ot else tn.mean(0)
-        self._tbar, self._xe = tout, xe
-        (self.tn_buf if self.ot else self.tbar_buf).copy_(tout.detach())
-
-    def _text_glue_back_in(self) -> None:
-        rows = self.n_text * self.txt_len
-        self._tbar.backward(self.dtn if self.ot else self.dtbar)
-        g = self.txt.g[:rows]
-        g.zero_()
-        g[self.eot_rows] = self._xe.grad.to(self.txt.dtype)
-        self._tbar = self._xe = None
-
-    def _text_glue_back_out(self) -> None:
-        cfg, t = self.cfg, self.cfg.text
-        rows = self.n_text * self.txt_len
-        d = self.txt.g[:rows].float().view(cfg.n_prompts, cfg.n_cls, self.txt_len, t.width)
-        self.params.view("prompt_learner.ctx", "grad").copy_(d[:, :, 1:1 + cfg.n_ctx, :].sum(1))
-
-    def _text_forward(self, with_grad: bool, stream=None) -> None:
-        rows = self.n_text * self.txt_len
-        self._glue(self._text_glue_in, stream)
+        ops.text_embed(self.tok_prefix, self.params.view("prompt_learner.ctx"), self.tok_suffix, self.txt_pos, self.txt.x[0],
+                       cfg.n_cls, self.txt_len)
         self._stack_forward(self.txt, rows, self.n_text, None, self.txt_len)
-        self._glue(lambda: self._text_glue_out(with_grad), stream)
+        ops.text_tail_fwd(self.txt.x[self.txt.layers], self.eot_rows, self.lnfinal[0], self.lnfinal[1], self.text_proj, self.tf_buf,
+                          self.tn_all, self.t_rnorm, self.t_stats, None if self.ot else self.tbar_buf, cfg.n_prompts, cfg.n_cls)
 
     def _text_backward(self, stream=None) -> None:
+        """dtbar (or dtn) -> gradient of the tower's EOT rows -> tower backward -> d ctx."""
+        cfg = self.cfg
         rows = self.n_text * self.txt_len
-        self._glue(self._text_glue_back_in, stream)
+        ops.text_tail_bwd(self.txt.x[self.txt.layers], self.eot_rows, self.lnfinal[0], self.text_proj, self.tn_all, self.t_rnorm,
+                          self.t_stats, None if self.ot else self.dtbar, self.dtn if self.ot else None, self.t_dy, self.txt.g,
+                          cfg.n_prompts, cfg.n_cls, self.txt_len)
         self._stack_backward(self.txt, rows, self.n_text, None, self.txt_len, True)
-        self._glue(self._text_glue_back_out, stream)
+        ops.text_ctx_grad(self.txt.g, self.params.view("prompt_learner.ctx", "grad"), cfg.n_cls, self.txt_len)
 
     # ------------------------------------------------------------- vision --
     def _as_f32(self, image: Tensor) -> Tensor:
@@ -898,9 +875,11 @@ class FairLoRAEngine:
         rows = images * L
         a32 = self.attr_i32[:b] if has_attr else None
         ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
+        # (straight into the buffer the last block's LoRA-gradient reductions read: no copy on the main stream)
+        gl = self.vis.rank > 0
         ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
-                          self.post_stats[1], None, self.vis.g[:rows])
-        self._stack_backward(self.vis, rows, images, a32, L * S, self.is3d)
+                          self.post_stats[1], None, (self.vis.g_l[v.layers - 1] if gl else self.vis.g)[:rows])
+        self._stack_backward(self.vis, rows, images, a32, L * S, self.is3d, grad_in_last=gl)
         if self.is3d:
             # dL/d(tokens) -> ln_pre / pos-add backward -> dX of the patch embedding (columns of the patches)
             P = v.grid * v.grid

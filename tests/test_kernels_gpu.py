@@ -713,3 +713,55 @@ def test_reduce_partials_many_rows_of_a_short_tensor():
             ref = ref.view(tk, tr).t().reshape(-1)
         ref = ref + 2.0
         assert float((out.double() - ref).abs().max()) < 2e-3 * (ns ** 0.5) / 10, (ns, n)
+
+
+# ------------------------------------------------------ text tower's two ends ---
+@pytest.mark.parametrize("use_ot", [False, True], ids=["mean-over-prompts", "per-prompt"])
+@pytest.mark.parametrize("N,n_cls,n_ctx,TL,w,D", [(2, 2, 4, 10, 512, 512), (3, 2, 2, 7, 128, 192)])
+def test_text_tower_ends_vs_autograd(ops, use_ot, N, n_cls, n_ctx, TL, w, D):
+    """csrc/text.hip against the PyTorch statement of the same ops (trainers/GLP_OT_SVLoRA.py:131-152, 55-66, 713-717):
+    prompt assembly + positional embedding; EOT gather -> ln_final -> projection -> normalise (-> mean over prompts);
+    their backward down to the tower's output rows; d ctx summed over the classes."""
+    n_text = N * n_cls
+    prefix, suffix = rnd(n_text, 1, w, seed=1), rnd(n_text, 20, w, seed=2)
+    ctx, pos = rnd(N, n_ctx, w, seed=3), rnd(TL + 5, w, seed=4)
+    x0 = torch.full((n_text * TL, w), float("nan"), device="cuda")
+    ops.text_embed(prefix, ctx, suffix, pos, x0, n_cls, TL)
+    ctx_rows = ctx.unsqueeze(1).expand(N, n_cls, n_ctx, w).reshape(n_text, n_ctx, w)
+    ref0 = torch.cat([prefix, ctx_rows, suffix[:, :TL - 1 - n_ctx]], dim=1) + pos[:TL]
+    assert torch.equal(x0, ref0.reshape(n_text * TL, w))
+    # tail forward
+    x = rnd(n_text * TL, w, seed=5) * 1.5 + 0.3
+    eot_pos = [TL - 1 - (i % n_cls) for i in range(n_text)]
+    eot_row = torch.tensor([i * TL + e for i, e in enumerate(eot_pos)], device="cuda", dtype=torch.int32)
+    lnw, lnb, proj = 1 + 0.1 * rnd(w, seed=6), 0.1 * rnd(w, seed=7), rnd(w, D, seed=8) * w ** -0.5
+    tf, tn = torch.empty(n_text, D, device="cuda"), torch.empty(n_text, D, device="cuda")
+    rn, st = torch.empty(n_text, device="cuda"), torch.empty(n_text, 2, device="cuda")
+    tbar = None if use_ot else torch.empty(n_cls, D, device="cuda")
+    ops.text_tail_fwd(x, eot_row, lnw, lnb, proj, tf, tn, rn, st, tbar, N, n_cls)
+    xd = x.double().requires_grad_(True)
+    xe = xd[eot_row.long()]
+    y = torch.nn.functional.layer_norm(xe, (w,), lnw.double(), lnb.double(), 1e-5)
+    tfr = y @ proj.double()
+    tnr = torch.nn.functional.normalize(tfr.view(N, n_cls, D), dim=2)
+    out_ref = tnr.reshape(n_text, D) if use_ot else tnr.mean(0)
+    check(tf, tfr, 2e-6, "tf")
+    check(tn, tnr.reshape(n_text, D), 2e-6, "tn")
+    if not use_ot:
+        check(tbar, out_ref, 2e-6, "tbar")
+    # tail backward
+    dout = rnd(*out_ref.shape, seed=9)
+    out_ref.backward(dout.double())
+    g = torch.full((n_text * TL, w), float("nan"), device="cuda")
+    dy = torch.empty(n_text, w, device="cuda")
+    ops.text_tail_bwd(x, eot_row, lnw, proj, tn, rn, st, None if use_ot else dout, dout if use_ot else None, dy, g, N, n_cls, TL)
+    check(g, xd.grad, 5e-6, "d(tower output)")
+    rows = torch.ones(n_text * TL, dtype=torch.bool, device="cuda")
+    rows[eot_row.long()] = False
+    assert float(g[rows].abs().max()) == 0.0                               # every non-EOT row is exactly zero
+    # d ctx = input-gradient rows 1 .. n_ctx of every prompt, summed over the classes
+    gin = rnd(n_text * TL, w, seed=10)
+    dctx = torch.empty(N, n_ctx, w, device="cuda")
+    ops.text_ctx_grad(gin, dctx, n_cls, TL)
+    refc = gin.double().view(N, n_cls, TL, w)[:, :, 1:1 + n_ctx, :].sum(1)
+    check(dctx, refc, 1e-6, "dctx")

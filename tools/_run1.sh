@@ -1,9 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 500 python bench.py > gpurun_out/r03_v1_bench.json 2> gpurun_out/r03_v1_bench.err; echo "bench rc=$?"
-bash tools/prof.sh r03_v1_bench
-bash tools/prof.sh r03_v1_serial --serial
-python tools/trace_timeline.py gpurun_out/r03_v1_bench_kernel_trace.csv > gpurun_out/r03_v1_timeline.txt 2>&1 || true
-rm -f gpurun_out/*_kernel_trace.csv
-cut -c1-600 gpurun_out/r03_v1_bench.json
-head -30 gpurun_out/r03_v1_timeline.txt
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py tests/test_trainer_gpu.py tests/test_ot_head_gpu.py tests/test_edge_gpu.py tests/test_engine_rn_gpu.py -x -q -k "not rccl" > gpurun_out/t3.log 2>&1; echo "rc=$?" >> gpurun_out/t3.log
+tail -15 gpurun_out/t3.log
+for i in 1 2; do timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --no-trainer --no-roofline 2>/dev/null | python -c "import json,sys; j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('ms/step', j['ms_per_step'], 'enqueue', j['config']['host_enqueue_ms_per_step'])"; done
