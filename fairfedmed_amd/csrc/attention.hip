@@ -524,6 +524,11 @@ template <typename F> int set_lds(F fn, int bytes) {
 // exactly zero probability.
 // ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+// Diagnostic builds only (tools/attn_phases.sh): -DFFM_ATTN_ABL=1 the attn2 kernels return behind their load phase,
+// =2 they skip the tile DMA and compute on whatever LDS holds (results are garbage): prices the two phases.
+#ifndef FFM_ATTN_ABL
+#define FFM_ATTN_ABL 0
+#endif
 
 // 16-B chunk c of row `row` in a row-major [rows][64] bf16 tile (128-byte rows): the same image as rm_off<bf16_t>
 __device__ __forceinline__ int rm2(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }
@@ -533,6 +538,7 @@ __device__ __forceinline__ int rm2(int row, int c) { return row * 128 + ((c ^ (r
 template <int NW>
 __device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ src, int ld, int L, int nrows, char* dst, int wave, int lane) {
     const int rsub = lane >> 3, slot = lane & 7;
+    if constexpr ((FFM_ATTN_ABL & 2) != 0) return;
     for (int pc = wave; pc < nrows / 8; pc += NW) {
         int row = pc * 8 + rsub;
         const int chunk = slot ^ (row & 7);
@@ -568,11 +574,42 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int fd, int l
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// tr_frag with the address split into a lane part the caller keeps in ONE register and cheap per-use arithmetic:
+//   address(s, fd) = ((lane0 + 4096 s) ^ (fd << 5)) [+ 2048 for the second half]
+// lane0 = tr_lane0(lane) is the address for s = 0, fd = 0: row 4 g + q, chunk (p >> 1) ^ (row & 7), + 8 bytes for odd p.
+// A different fd only flips bits 5-6 of the chunk field (c = 2 fd + (p >> 1), swizzle = c ^ (row & 7)), and the step
+// offset 4096 s never reaches them - so the XOR comes AFTER the add.  Four precomputed addresses (what hipcc makes of
+// tr_frag in a loop) cost the dK/dV kernel two scratch reloads with an s_waitcnt vmcnt(0) each per k-step at its
+// 80-register budget.  Rows must lie inside the tile (the unclamped steps).
+__device__ __forceinline__ uint32_t tr_lane0(const char* tile, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    return (uint32_t)(uintptr_t)tile + (uint32_t)(rm2(4 * g + q, p >> 1) + (p & 1) * 8);
+}
+template <int FD>
+__device__ __forceinline__ bf16x8 tr_frag_x(uint32_t lane_step, int tile_off) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    uint32_t a = lane_step ^ (uint32_t)(FD << 5);
+    // (the optimiser must not fold the XOR into four loop-invariant addresses again)
+    asm volatile("" : "+v"(a));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(a + tile_off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(a + tile_off + 2048));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // (b, h) pair and half of a block id: ids b and b + 8 (one XCD under round-robin placement: speed only) are the two
 // halves of one pair
 __device__ __forceinline__ void unit_of_block(int bid, int& bh, int& half) {
     bh = (bid >> 4) * 8 + (bid & 7);
     half = (bid >> 3) & 1;
+}
+
+template <typename F> __device__ __forceinline__ void static_for4(F&& f) {
+    f(std::integral_constant<int, 0>{});
+    f(std::integral_constant<int, 1>{});
+    f(std::integral_constant<int, 2>{});
+    f(std::integral_constant<int, 3>{});
 }
 
 constexpr int A2_NW = 7;            // waves per block = 16-row tiles of half a head (L <= 224)
@@ -610,7 +647,7 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     for (int ks = 0; ks < 2; ++ks) qf[ks] = gfrag<bf16_t>(base, ld, active ? q : 0, L, ks, g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!active) return;                                          // whole waves only (the transposed reads need EXEC = all ones)
+    if (!active || (FFM_ATTN_ABL & 1)) return;                                          // whole waves only (the transposed reads need EXEC = all ones)
 
     float m = -INFINITY, l = 0.f;
     f32x4 o[4];
@@ -740,7 +777,7 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     const float lq2 = lse[((size_t)b * heads + h) * L + (qs < L ? qs : L - 1)] * A2_LOG2E;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!active) return;
+    if (!active || (FFM_ATTN_ABL & 1)) return;
 
     float dl = 0.f;
 #pragma unroll
@@ -841,12 +878,13 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!active) return;
+    if (!active || (FFM_ATTN_ABL & 1)) return;
 
     f32x4 dv[4], dk[4];
 #pragma unroll
     for (int fd = 0; fd < 4; ++fd) { dv[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[fd] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     constexpr int NS = (NF + 1) / 2;
+    const uint32_t tr0 = tr_lane0(Qs, lane);                          // (dOs = Qs + R8 * 128: an immediate offset)
     // one k-step = 32 queries (fragments 2 st, 2 st + 1).  The loop is NOT unrolled (unrolled, the compiler hoists the
     // reads of several steps and the kernel leaves the 80 registers that three blocks per CU allow); the last step is
     // peeled: it alone can touch rows beyond the tile or a phantom fragment.
@@ -884,10 +922,19 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
                 for (int e = 0; e < 4; ++e) { pf[4 * hf + e] = (bf16_t)0.f; df[4 * hf + e] = (bf16_t)0.f; }
             }
         }
+        if constexpr (LAST) {
 #pragma unroll
-        for (int fd = 0; fd < 4; ++fd) {
-            dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LAST>(dOs, st, fd, lane, rmax), pf, dv[fd], 0, 0, 0);
-            dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LAST>(Qs, st, fd, lane, rmax), df, dk[fd], 0, 0, 0);
+            for (int fd = 0; fd < 4; ++fd) {
+                dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<true>(dOs, st, fd, lane, rmax), pf, dv[fd], 0, 0, 0);
+                dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<true>(Qs, st, fd, lane, rmax), df, dk[fd], 0, 0, 0);
+            }
+        } else {
+            const uint32_t ls = tr0 + (uint32_t)st * 4096u;          // one lane register for all eight transposed reads
+            static_for4([&](auto FD_) {
+                constexpr int fd = decltype(FD_)::value;
+                dv[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_x<fd>(ls, R8 * 128), pf, dv[fd], 0, 0, 0);
+                dk[fd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag_x<fd>(ls, 0), df, dk[fd], 0, 0, 0);
+            });
         }
     };
 #pragma unroll 1
