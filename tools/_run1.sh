@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "attention or attn" 2>&1 | tail -2
-for i in 1 2; do
-echo old; FFM_LIB_PATH=$GRAFT_REPO_ROOT/tools/proto/libffm_old.so timeout -k 10 200 python tools/bench_attn.py 2>&1 | grep -v amdgpu
-echo new; timeout -k 10 200 python tools/bench_attn.py 2>&1 | grep -v amdgpu
-done
+(time timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/full2.log 2>&1) 2> gpurun_out/full2.time; echo "rc=$?" >> gpurun_out/full2.log
+tail -14 gpurun_out/full2.log
+grep "AUC per round\|oracle with" gpurun_out/full2.log
+bash tools/pmc.sh r03
+python3 tools/pmc_traffic.py gpurun_out/r03_fetch.csv gpurun_out/r03_write.csv > gpurun_out/r03_traffic.json
+python3 tools/sq_counters.py gpurun_out/r03_sq.csv > gpurun_out/r03_sq_counters.json
+rm -f gpurun_out/r03_fetch.csv gpurun_out/r03_write.csv gpurun_out/r03_sq.csv
+head -c 1500 gpurun_out/r03_traffic.json
