@@ -84,10 +84,17 @@ def model_cfg_from_reference(cfg, classnames: Sequence[str], clip_sd: Dict[str, 
     got, lora = cfg.TRAINER.GLP_OT, getattr(cfg.TRAINER, "GLP_OT_LORA", None)
     assert cfg.INPUT.SIZE[0] == vision.image_size, \
         f"cfg_imsize ({cfg.INPUT.SIZE[0]}) must equal to clip_imsize ({vision.image_size})"       # :79
+    # The other prompt variants of PromptLearner (trainers/GLP_OT_SVLoRA.py:84-175) are not merely unused by the FairLoRA
+    # scripts: with this trainer's N prompts they do not run in the reference either.  CTX_INIT leaves a 2-D ctx that
+    # forward() permutes as 4-D (:133-136); CSC allocates ctx [n_cls, n_ctx, d] and views it as [N * n_cls, ...]
+    # (consistent only when N == n_cls); 'middle' / 'front' assemble n_cls prompts (`for i in range(self.n_cls)`,
+    # :152-175) for N * n_cls tokenised rows.  There is no behaviour to match, so they stay an explicit error here.
     if getattr(got, "CTX_INIT", False) or getattr(got, "CSC", False):
-        raise NotImplementedError("CTX_INIT / CSC prompts (no FairLoRA script sets them)")
+        raise NotImplementedError("CTX_INIT / CSC prompts: no FairLoRA script sets them, and the reference's PromptLearner "
+                                  "does not run with them for N > 1 prompts (ctx shape mismatch in forward())")
     if getattr(got, "CLASS_TOKEN_POSITION", "end") != "end":
-        raise NotImplementedError(got.CLASS_TOKEN_POSITION)
+        raise NotImplementedError(f"CLASS_TOKEN_POSITION={got.CLASS_TOKEN_POSITION!r}: the reference assembles n_cls prompts "
+                                  "for N * n_cls tokenised rows in that branch; only 'end' is a working configuration")
     is3d = getattr(cfg.DATASET, "MODALITY_TYPE", "slo_fundus") in MODALITIES_3D
     if lora is not None and getattr(lora, "UNFREEZE_IMAGE_ENCODER", True):
         ltype = getattr(lora, "TYPE", "FairLoRA")

@@ -273,18 +273,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         }
     }
 
-    // ---- prologue: ring stages 0..2 and the B fragments of half-steps 0..2, drained once before the loop
-    dma(0);
-    dma(1);
-    dma(2);
-    fence();
-    loadB(0, bq[0]);
-    loadB(1, bq[1]);
-    loadB(2, bq[2]);
-    fence();
-    FFM_STAMP(6);
-
-    // ---- persistent epilogue operands (their loads overlap the first ring fills)
+    // ---- persistent epilogue operands first (a handful of small loads), then the ring: see below
     float* Bias = reinterpret_cast<float*>(smem + G::RING);
     bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
@@ -365,8 +354,33 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
         }
     }
+    FFM_STAMP(6);
+    // ---- prologue of the ring: stages 0..2 and the B fragments of half-steps 0..2 in the order the steady state would
+    // have issued them (step k issues Bh(2k+3), A(k+3), Bh(2k+4); run backwards from k = 0 that is A0, A1, Bh0, Bh1, A2,
+    // Bh2), so that the loop's own counted waits are exact from its first step on and the block only has to wait HERE
+    // for stage 0 and the operands above - everything issued before A1 - not for all three stages (round 3; the full
+    // drain cost ~1 us of every launch, tools/panel_stamps.py "pro: wait for all")
+#if defined(FFM_PANEL_FULL_DRAIN)
+    dma(0); dma(1); dma(2);
+    fence();
+    loadB(0, bq[0]); loadB(1, bq[1]); loadB(2, bq[2]);
+    fence();
     FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    dma(0);
+    dma(1);
+    fence();
+    loadB(0, bq[0]);
+    loadB(1, bq[1]);
+    fence();
+    dma(2);
+    fence();
+    loadB(2, bq[2]);
+    fence();
+    FFM_STAMP(7);
+    wait_vm<2 * G::NI + 3 * NF>();
+#endif
     asm volatile("" : "+v"(sgv));
 #pragma unroll
     for (int it = 0; it < NBI; ++it) {
