@@ -54,6 +54,7 @@ SIGNATURES = {
     "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
     "ffm_gemm_tiles_m": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_gemm_tiles_n": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "ffm_gemm_tile_shape": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)],
     "ffm_pack_b": [_vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_multi": [_vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_ln": [_vp, _i32, _i32, _vp],

@@ -1103,6 +1103,16 @@ extern "C" int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dt
     return (N + BN - 1) / BN;
 }
 
+extern "C" int ffm_gemm_tile_shape(int M, int N, int K, int flags, int rank, int dtype, int packed, int32_t* shape3) {
+    const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
+    if (shape3) {
+        shape3[0] = cfg >= 0 ? 16 * FFM_PANEL_CFGS[cfg].mf : BM;
+        shape3[1] = cfg >= 0 ? ffm_panel_bn(FFM_PANEL_CFGS[cfg]) : BN;
+        shape3[2] = cfg >= 0 ? FFM_PANEL_CFGS[cfg].pw * FFM_PANEL_CFGS[cfg].per_cu : 8;      // waves per CU
+    }
+    return cfg;
+}
+
 extern "C" int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream) {
     if (!descs_dev || ndesc <= 0 || max_K <= 0) return FFM_EINVAL;
     dim3 grid((RK_ROWS * max_K + 255) / 256, ndesc);

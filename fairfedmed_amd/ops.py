@@ -109,6 +109,14 @@ def gemm_tiles_n(M: int, N: int, K: int, flags: int = 0, rank: int = 0, dtype=to
     return L.load().ffm_gemm_tiles_n(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
 
 
+def gemm_tile_shape(M: int, N: int, K: int, flags: int = 0, rank: int = 0, dtype=torch.float32, packed: bool = False):
+    """(configuration index or -1, tile rows, tile columns, waves per CU) of the kernel ffm_gemm_nt picks (diagnostics)."""
+    import ctypes
+    shp = (ctypes.c_int32 * 3)()
+    cfg = L.load().ffm_gemm_tile_shape(M, N, K, flags, rank, L.dtype_code(dtype), int(packed), shp)
+    return cfg, shp[0], shp[1], shp[2]
+
+
 class LnIn:
     """FFM_EPI_LNIN: the LayerNorm in front of a product, folded into it.  part [np, M, 2]: partial row sums of the
     product's A rows (a producer's `rowstats`, or embed_lnpre's), c [N]: row sums of the gamma-scaled weight;

@@ -134,6 +134,9 @@ int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int pa
 /* column tiles (= rows of rowstat_part under FFM_EPI_ROWSTATS) of that kernel; FFM_EUNSUP when no kernel serves the
  * flags for this shape (FFM_EPI_ROWSTATS / FFM_EPI_LNIN exist in the bf16 panel kernel only: ask before relying on them) */
 int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dtype, int packed);
+/* which kernel / tile that is (diagnostics, tests): returns the panel-kernel configuration index (csrc/gemm_panel.h) or
+ * -1 for the 128x128 kernel, and writes {tile rows, tile columns, waves per CU} to shape3 (optional) */
+int ffm_gemm_tile_shape(int M, int N, int K, int flags, int rank, int dtype, int packed, int32_t* shape3);
 /*
  * dst = src [N, K] bf16 (row stride ld) in MFMA-fragment order: [N/16][K/32][64 lanes][8] with lane l holding
  * row (l & 15), k-group (l >> 4).  N % 16 == 0, K % 32 == 0.  Load-time only (weights are frozen).

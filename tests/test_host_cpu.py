@@ -408,3 +408,35 @@ def test_reference_constructor_arguments_to_engine_inputs(golden_dir, tag, mk, n
     # a caller-supplied tokenizer (the reference's clip.tokenize) serves any other class name
     fake = lambda s: torch.tensor([[49406, 343, 343, 343, 343, 1000, 269, 49407] + [0] * 69])
     assert A.tokenize_prompts(["Cardiomegaly"], 4, tokenize=fake).shape == (1, 77)
+
+
+def test_bench_shapes_select_the_documented_tiles():
+    """Kernel selection is host logic (ffm_gemm_tile_shape needs no GPU): at the bench workload's shapes (6 304 token rows,
+    bf16, frozen weights packed) the eight GEMMs of a vision block run on the tiles DESIGN section 4.4 describes, each in ONE
+    round of <= 256 blocks; at the 3D OCT workload's 19 700 rows the FairLoRA products take the 208 x 384 tile at several
+    rounds and the N = 768 products a one-round 240 x 256 tile."""
+    import torch
+    from fairfedmed_amd import ops
+    bf, W, E = torch.bfloat16, 768, _lib
+    rk = E.EPI_LORA | E.EPI_RANKOP
+    shapes = {
+        "qkv": (3 * W, W, E.EPI_BIAS | E.EPI_LNIN, 0), "out": (W, W, E.EPI_BIAS | E.EPI_RESIDUAL | E.EPI_ROWSTATS, 0),
+        "c_fc": (4 * W, W, E.EPI_BIAS | E.EPI_GELU | E.EPI_LNIN | rk, 8),
+        "c_proj": (W, 4 * W, E.EPI_BIAS | E.EPI_RESIDUAL | E.EPI_ROWSTATS | rk, 8),
+        "dx_c_proj": (4 * W, W, E.EPI_LORA_KR | E.EPI_DGELU | rk, 8), "dx_c_fc": (W, 4 * W, E.EPI_LORA_KR | rk, 8),
+        "dx_out": (W, W, 0, 0), "dx_qkv": (W, 3 * W, 0, 0)}
+    want = {"qkv": (240, 256, 8), "out": (160, 128, 4), "c_fc": (208, 384, 8), "c_proj": (160, 128, 4),
+            "dx_c_proj": (208, 384, 8), "dx_c_fc": (160, 128, 4), "dx_out": (160, 128, 4), "dx_qkv": (160, 128, 4)}
+    M = 32 * 197
+    for name, (N, K, fl, r) in shapes.items():
+        cfg, bm, bn, waves = ops.gemm_tile_shape(M, N, K, fl, r, bf, True)
+        assert cfg >= 0 and (bm, bn, waves) == want[name], (name, cfg, bm, bn, waves)
+        assert ((M + bm - 1) // bm) * (N // bn) <= 256, name                 # one round of tiles
+        assert ops.gemm_tile_shape(M, N, K, fl, r, bf, False)[0] == -1       # unpacked weights: the 128 x 128 kernel
+        assert ops.gemm_tile_shape(M, N, K, fl & ~(E.EPI_LNIN | E.EPI_ROWSTATS), r, torch.float32, True)[0] == -1   # fp32 mode
+    M = 100 * 197
+    for name in ("c_fc", "dx_c_proj"):
+        N, K, fl, _ = shapes[name]
+        cfg, bm, bn, waves = ops.gemm_tile_shape(M, N, K, fl, 16, bf, True)
+        assert (bm, bn, waves) == (208, 384, 8) and ((M + bm - 1) // bm) * (N // bn) > 512, name
+    assert ops.gemm_tile_shape(M, W, 3 * W, 0, 0, bf, True)[1:] == (240, 256, 8)
