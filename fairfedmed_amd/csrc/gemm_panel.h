@@ -11,17 +11,21 @@ struct ffm_panel_cfg {
     bool rankop;     // instantiated for the FFM_EPI_RANKOP epilogues (true) or for the plain ones (false)
     int per_cu;      // blocks that share a CU (registers + LDS): a round is 256 * per_cu blocks
     int pw;          // waves per block
+    int ks;          // 1: the 8 waves are 4 column slabs x 2 K halves (gemm_panel_impl.h, KS) - the tile is 64*nf wide
 };
-constexpr int FFM_PANEL_NCFG = 11;
-constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1, 4}, {16, 4, false, 1, 4}, {10, 2, false, 1, 4}, {11, 2, true, 1, 4},
-                                                          {8, 4, false, 2, 4},
+constexpr int FFM_PANEL_NCFG = 13;
+constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1, 4, 0}, {16, 4, false, 1, 4, 0}, {10, 2, false, 1, 4, 0}, {11, 2, true, 1, 4, 0},
+                                                          {8, 4, false, 2, 4, 0},
                                                           // two waves per SIMD: the same tiles as 3, 2 and 0
-                                                          {11, 1, true, 1, 8}, {10, 1, false, 1, 8}, {13, 3, true, 1, 8},
+                                                          {11, 1, true, 1, 8, 0}, {10, 1, false, 1, 8, 0}, {13, 3, true, 1, 8, 0},
                                                           // 8: the 160-row FairLoRA tile for N = 768 (240 blocks at 6304
                                                           // rows where the 176-row tile launches 216); 9 / 10: 240 x 256
                                                           // for qkv (243 blocks), one and two waves per SIMD
-                                                          {10, 2, true, 1, 4}, {15, 4, false, 1, 4}, {15, 2, false, 1, 8}};
-constexpr int ffm_panel_bn(const ffm_panel_cfg& c) { return 16 * c.pw * c.nf; }
+                                                          {10, 2, true, 1, 4, 0}, {15, 4, false, 1, 4, 0}, {15, 2, false, 1, 8, 0},
+                                                          // 11 / 12: the 160x128 tiles (FairLoRA / plain) with 8 waves as
+                                                          // 4 column slabs x 2 K halves (K % 256 == 0)
+                                                          {10, 2, true, 1, 8, 1}, {10, 2, false, 1, 8, 1}};
+constexpr int ffm_panel_bn(const ffm_panel_cfg& c) { return 16 * (c.ks ? c.pw / 2 : c.pw) * c.nf; }
 
 // -1: use the 128x128 kernel; otherwise the index into FFM_PANEL_CFGS
 int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool packed);

@@ -7,8 +7,11 @@
 //   7  208x384 FairLoRA, two waves per SIMD: c_fc forward 53.8 -> 44.7 us, dX(c_proj) 50.5 -> 44.5 us
 //   8  160x128 FairLoRA (240 blocks where the 176-row tile launches 216): c_proj forward 40.2 -> 38.1, dX(c_fc) 39.6 -> 38.8
 //   10 240x256 plain, two waves per SIMD (243 blocks): qkv forward 31.9 -> 27.7 us (one wave per SIMD, 9: 32.9)
-// Off: the 128-column two-wave twins (5, 6) measured no gain - those shapes are bound by the CU's vector-memory path
-// (LDS-DMA fills + weight fragments at ~70 GB/s per CU), not by one wave's in-order issue.
+// Off: the 128-column two-wave twins as eight column slabs (5, 6: no gain, twice the LDS fragment reads), and the K split
+// of the 160x128 tiles (11, 12: 4 column slabs x 2 K halves - isolated c_proj forward 39.6 -> 36.9 us, dX(c_fc) 38.9 ->
+// 36.1, dX(qkv) 25.0 -> 23.7, but IN THE STEP, beside the text tower and the LoRA-gradient reductions, the same launches
+// take what the 4-wave tiles take (44.0 / 43.8, 40.5 / 38.4 us) and the step is 0.03 ms slower: 4.73 -> 4.77 ms twice in
+// one call).  All of them stay instantiated and tested (tests/test_kernels_gpu.py runs the panel tests under both masks).
 #ifndef FFM_PANEL_MASK_DEFAULT
 #define FFM_PANEL_MASK_DEFAULT ((1 << 7) | (1 << 8) | (1 << 10))
 #endif
@@ -71,7 +74,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
     if (panel_off) return -1;
     // Configurations 5 and up are enabled by a bit mask (default FFM_PANEL_MASK_DEFAULT; FFM_PANEL_MASK=<int> overrides, A/B
     // runs): 5 = 176x128 FairLoRA two waves per SIMD, 6 = 160x128 plain ditto, 7 = 208x384 FairLoRA ditto, 8 = 160x128
-    // FairLoRA, 9 = 240x256 plain, 10 = 240x256 plain two waves per SIMD
+    // FairLoRA, 9 = 240x256 plain, 10 = 240x256 plain two waves per SIMD, 11 / 12 = 160x128 FairLoRA / plain with the K split
     static const int exp_mask = [] {
         const char* f = getenv("FFM_PANEL_MASK");
         return f ? atoi(f) : FFM_PANEL_MASK_DEFAULT;
@@ -84,6 +87,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         const int bm = 16 * cf.mf, bn = ffm_panel_bn(cf), nfe = bn / 64;      // nfe: the tile's width in 64-column units
         if (N % bn || cf.rankop != rk) continue;
         if (c >= 5 && !((exp_mask >> c) & 1)) continue;
+        if (cf.ks && K % 256) continue;                       // the K-split loop is unrolled by four K64 steps
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
@@ -99,7 +103,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         // (a two-per-CU tile that fills less than half of its slots is a one-per-CU tile with a worse shape)
         if (per_cu > 1 && blocks <= 256) continue;
         // (the two-waves-per-SIMD twin of a tile wins the tie)
-        const long cost = 2 * (long)per_cu * (bm + bn) * (multi ? (blocks + 255) / 256 : 1) - (cf.pw == 8 ? 1 : 0);
+        const long cost = 2 * (long)per_cu * (bm + bn) * (multi ? (blocks + 255) / 256 : 1) - (cf.pw == 8 ? 1 : 0);   // (pw 8: two waves per SIMD)
         if (cost < 2 * best) { best = (cost + 1) / 2; pick = c; }
     }
     return pick;
@@ -121,6 +125,7 @@ int ffm_panel_tiles_n(int N, int cfg) { return N / ffm_panel_bn(FFM_PANEL_CFGS[c
             case 6: return ffm_panel::launch_panel<10, 1, false, F, 8>(a, s);              \
             case 9: return ffm_panel::launch_panel<15, 4, false, F>(a, s);                 \
             case 10: return ffm_panel::launch_panel<15, 2, false, F, 8>(a, s);             \
+            case 12: return ffm_panel::launch_panel<10, 2, false, F, 8, 1>(a, s);          \
         }                                                                                  \
         return FFM_EINVAL;
 

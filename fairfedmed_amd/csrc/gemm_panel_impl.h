@@ -102,12 +102,20 @@ template <int MF, int NF, bool RK, int PWV> constexpr int panel_waves_per_eu() {
     return (PWV == 8 || (MF == 8 && NF == 4 && !RK)) ? 2 : 1;
 }
 
-template <int MF, int NF, bool RK, int FL, int PWV = 4>
+// KS (K split, needs PWV = 8): the eight waves are 4 column slabs x 2 K halves.  Waves 0-3 take the first 32 of every
+// 64-deep K step of the ring stage, waves 4-7 the second 32, each with accumulators for the block's WHOLE slab (the
+// 128-column tiles: 10 x 2 fragments = 80 registers), summed through LDS behind the loop; the epilogue runs on waves
+// 0-3.  Unlike eight column slabs (section 4.4 of DESIGN.md: no gain on these tiles) this keeps the LDS fragment reads
+// and the weight-fragment loads per step exactly those of the 4-wave kernel - every A half-fragment is read by four
+// waves, every B fragment loaded once - while each SIMD gets a second wave whose MFMAs fill the other's issue stalls.
+template <int MF, int NF, bool RK, int FL, int PWV = 4, int KS = 0>
 __global__ __launch_bounds__(PWV * 64)
 __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_waves_per_eu<MF, NF, RK, PWV>()))) void gemm_panel_kernel(ffm_gemm_args p) {
     constexpr int PW = PWV, PT = PWV * 64;
+    static_assert(!KS || PWV == 8, "K split: 4 column slabs x 2 K halves");
+    constexpr int CW = KS ? PW / 2 : PW;                     // column slabs (waves side by side along N)
     using G = PanelGeom<MF, RK, PWV>;
-    constexpr int BMp = 16 * MF, BNp = PW * 16 * NF, WN = 16 * NF;
+    constexpr int BMp = 16 * MF, BNp = CW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
     static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
@@ -120,7 +128,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     const int tiles_m = (p.M + BMp - 1) / BMp;
     const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = logical / tiles_n, tn = logical % tiles_n;
-    const int m0 = tm * BMp, n0 = tn * BNp, n0w = n0 + wave * WN;
+    const int colw = KS ? (wave & (CW - 1)) : wave;           // column slab of this wave
+    const int kg = KS ? wave / CW : 0;                        // K half (K split only)
+    const int m0 = tm * BMp, n0 = tn * BNp, n0w = n0 + colw * WN;
     const int KT = p.K >> 6;
     const int frow = lane & 15, fgrp = lane >> 4;
 
@@ -186,7 +196,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // (two waves per SIMD: hipcc splits the 256 registers of a wave 128 / 128 between the two files)
-    constexpr int ACC_A = PW == 8 ? 32 : 64;                  // accumulator fragments kept in AGPRs
+    // (K split: none - the partial accumulators are added with ordinary VALU code, and 20-odd fragments leave room)
+    constexpr int ACC_A = KS ? 0 : (PW == 8 ? 32 : 64);       // accumulator fragments kept in AGPRs
     auto mma = [&](auto IDX_, f32x4& c, const frag_t& a, const frag_t& b) {
         if constexpr ((FFM_PANEL_ABL & 4) != 0) return;
         if constexpr (decltype(IDX_)::value < ACC_A)
@@ -195,7 +206,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     };
     // RANKOP: t = A_rows . rk^T for the block's rows; wave w owns fragment rows w, w+4, ... (VGPR accumulators)
-    constexpr int TI = (MF + PW - 1) / PW;
+    constexpr int TI = (MF + CW - 1) / CW;
     constexpr bool WSPEC = RK && MF * NF <= 32;               // specialise the main loop per wave (t fragment rows)
     f32x4 tacc[TI];
 #pragma unroll
@@ -222,7 +233,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         if constexpr (RK) lds_read(kf, sa, std::integral_constant<int, MF * 2048>{});
         static_for<(AD < MF ? AD : MF)>([&](auto I_) { lds_read(a[decltype(I_)::value], sa, std::integral_constant<int, decltype(I_)::value * 2048>{}); });
         f32x4(&tr)[TI] = tacc;                      // (named outside the if constexpr so that the lambdas capture it)
-        const int wv = wave;
+        const int wv = colw;
         static_for<MF>([&](auto MF_) {
             constexpr int mf = decltype(MF_)::value;
             if constexpr (mf + AD < MF) lds_read(a[(mf + AD) % (AD + 1)], sa, std::integral_constant<int, (mf + AD) * 2048>{});
@@ -244,11 +255,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 // fragment row, 0.4 us per K step.
                 // (Tiles whose accumulators already fill the register file cannot afford four loop copies: they spill.)
                 if constexpr (WSPEC) {
-                    if constexpr ((mf % PW) == decltype(W_)::value)
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                    if constexpr ((mf % CW) == decltype(W_)::value)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 } else {
-                    if ((mf % PW) == wv)
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / PW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                    if ((mf % CW) == wv)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 }
             }
             issue(MF_);
@@ -274,13 +285,16 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     }
 
     // ---- persistent epilogue operands first (a handful of small loads), then the ring: see below
-    float* Bias = reinterpret_cast<float*>(smem + G::RING);
+    // (K split: the partial accumulators of waves 4-7 are staged over the ring behind the loop, [CW][MF*NF + TI] KiB)
+    constexpr int PARTB = KS ? CW * (MF * NF + (RK ? TI : 0)) * 1024 : 0;
+    constexpr int PBASE = PARTB > G::RING ? PARTB : G::RING;
+    float* Bias = reinterpret_cast<float*>(smem + PBASE);
     bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
     float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
     int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
     constexpr bool LNIN = (flags & FFM_EPI_LNIN) != 0, ROWST = (flags & FFM_EPI_ROWSTATS) != 0;
-    float* Cv = reinterpret_cast<float*>(smem + G::RING + persist_bytes(MF, NF, RK, false, PW));     // LNIN: c [BN]
+    float* Cv = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, false, CW));     // LNIN: c [BN]
     float* Mu = Cv + BNp;                                     // row means [BM]
     float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
     const int r = RK ? p.rank : 0;
@@ -368,18 +382,36 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     FFM_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-    dma(0);
-    dma(1);
-    fence();
-    loadB(0, bq[0]);
-    loadB(1, bq[1]);
-    fence();
-    dma(2);
-    fence();
-    loadB(2, bq[2]);
-    fence();
-    FFM_STAMP(7);
-    wait_vm<2 * G::NI + 3 * NF>();
+    if constexpr (KS) {
+        // K split: a wave loads the B fragments of ITS half of a step only; steady-state order per step is B(k), A(k)
+        loadB(0 + kg, bq[0]);
+        fence();
+        dma(0);
+        fence();
+        loadB(2 + kg, bq[1]);
+        fence();
+        dma(1);
+        fence();
+        loadB(4 + kg, bq[2]);
+        fence();
+        dma(2);
+        fence();
+        FFM_STAMP(7);
+        wait_vm<2 * G::NI + 2 * NF>();                          // everything up to and including stage 0
+    } else {
+        dma(0);
+        dma(1);
+        fence();
+        loadB(0, bq[0]);
+        loadB(1, bq[1]);
+        fence();
+        dma(2);
+        fence();
+        loadB(2, bq[2]);
+        fence();
+        FFM_STAMP(7);
+        wait_vm<2 * G::NI + 3 * NF>();
+    }
 #endif
     asm volatile("" : "+v"(sgv));
 #pragma unroll
@@ -478,20 +510,64 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             block_barrier();
         }
     };
-    auto main_loop = [&](auto W_) {
-        int kt = 0;
-        for (; kt < KT - 4; kt += 2) {                           // steady state: no guards, no branches
-            step(W_, kt, I0{}, I0{});
-            step(W_, kt + 1, I1{}, I0{});
-        }
-        for (; kt < KT; kt += 2) {                               // last four steps
-            step(W_, kt, I0{}, I1{});
-            step(W_, kt + 1, I1{}, I1{});
+    // K split: ONE half per step and wave (its K half of the stage), the B ring indexed by step (slot = kt & 3, loaded
+    // three steps ahead).  VMEM order of step kt on every wave: B(kt+3) = NF fragments, then the nA pieces of A(kt+3).
+    //   start of step kt needs B(kt):   younger = A(kt) + steps kt+1, kt+2            = 2 NF + 3 nA   (rem 2: NF + 2 nA, rem 1: nA)
+    //   end of step kt needs A(kt+1):   younger = steps kt+2, kt+3                     = 2 NF + 2 nA   (rem 3: NF + nA, rem 2: 0)
+    auto step_ks = [&](auto W_, int kt, auto S_, auto TAIL_) {
+        constexpr int S = decltype(S_)::value;
+        constexpr bool TAIL = decltype(TAIL_)::value != 0;
+        const int rem = KT - kt;
+        const char* st = smem + (kt & 3) * G::STAGE;
+        if (!TAIL || rem >= 3) wait_vm<2 * NF + 3 * nA>();
+        else if (rem == 2) wait_vm<NF + 2 * nA>();
+        else wait_vm<nA>();
+        tieB(bq[S]);
+        half(W_, st, kg ? offA1 : offA0, bq[S], [&](auto J_) {
+            constexpr int j = decltype(J_)::value;
+            if constexpr (j < NF) {
+                if (!TAIL || rem >= 4) loadB1(2 * (kt + 3) + kg, j, bq[(S + 3) & 3][j]);
+            } else if constexpr (j < NF + nA) {
+                if (!TAIL || rem >= 4) dma_piece(kt + 3, j - NF);
+            }
+        });
+        fence();
+        if (!TAIL || rem >= 2) {
+            if (!TAIL || rem >= 4) wait_vm<2 * NF + 2 * nA>();
+            else if (rem == 3) wait_vm<NF + nA>();
+            else wait_vm<0>();
+            block_barrier();
         }
     };
-    if constexpr (WSPEC) {                                       // one copy of the loop per wave (see half())
-        static_for<PW>([&](auto WW_) {
-            if (wave == decltype(WW_)::value) main_loop(WW_);
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto main_loop = [&](auto W_) {
+        int kt = 0;
+        if constexpr (KS) {
+            for (; kt < KT - 4; kt += 4) {                       // (the selector admits K % 256 == 0 only: KT % 4 == 0)
+                step_ks(W_, kt, I0{}, I0{});
+                step_ks(W_, kt + 1, I1{}, I0{});
+                step_ks(W_, kt + 2, I2{}, I0{});
+                step_ks(W_, kt + 3, I3{}, I0{});
+            }
+            step_ks(W_, kt, I0{}, I1{});
+            step_ks(W_, kt + 1, I1{}, I1{});
+            step_ks(W_, kt + 2, I2{}, I1{});
+            step_ks(W_, kt + 3, I3{}, I1{});
+        } else {
+            for (; kt < KT - 4; kt += 2) {                       // steady state: no guards, no branches
+                step(W_, kt, I0{}, I0{});
+                step(W_, kt + 1, I1{}, I0{});
+            }
+            for (; kt < KT; kt += 2) {                           // last four steps
+                step(W_, kt, I0{}, I1{});
+                step(W_, kt + 1, I1{}, I1{});
+            }
+        }
+    };
+    if constexpr (WSPEC) {                                       // one copy of the loop per column slab (see half())
+        static_for<CW>([&](auto WW_) {
+            if (colw == decltype(WW_)::value) main_loop(WW_);
         });
     } else {
         main_loop(I0{});
@@ -499,6 +575,47 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire before the accumulators are read
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();                                                  // the ring is free from here on
+    constexpr bool ROWST_ = (FL & FFM_EPI_ROWSTATS) != 0;
+    if constexpr (KS) {
+        // waves 4-7 hand their partial accumulators (and partial t) to the wave of the same column slab through LDS,
+        // then only keep the remaining barriers of the block company: the epilogue belongs to waves 0-3
+        f32x4* Pacc = reinterpret_cast<f32x4*>(smem) + ((size_t)colw * (MF * NF + (RK ? TI : 0))) * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) Pacc[(i * NF + j) * 64] = acc[i][j];
+            if constexpr (RK) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) Pacc[(MF * NF + i) * 64] = tacc[i];
+            }
+        }
+        __syncthreads();                                              // partials visible
+        if (kg == 1) {
+            __syncthreads();                                          // (partials consumed)
+            if constexpr (RK) __syncthreads();                        // (the rank-r stage's barrier)
+            if constexpr (ROWST_) __syncthreads();                    // (the row sums' barrier)
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const f32x4 o = Pacc[(i * NF + j) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += o[e];
+            }
+        if constexpr (RK) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const f32x4 o = Pacc[(MF * NF + i) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tacc[i][e] += o[e];
+            }
+        }
+        __syncthreads();                                              // partials consumed: the staging area is free
+    }
+    constexpr int ET = CW * 64;                                       // threads that run the epilogue
     FFM_STAMP(2);
 
     // ---------------- epilogue ----------------
@@ -510,9 +627,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PF = NRG < PFMAX ? NRG : PFMAX;
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
-    float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + wave * (32 * PITCH);
+    float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + colw * (32 * PITCH);
     // ROWSTATS: per-wave partial row sums [PW][BM][2] behind the four waves' output stages
-    float* RowP = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + PW * (32 * PITCH);
+    float* RowP = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + CW * (32 * PITCH);
     static_assert((CPR & (CPR - 1)) == 0 || !(FL & FFM_EPI_ROWSTATS), "row sums: the lanes of a row form a power-of-two group");
     bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
 
@@ -577,7 +694,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         for (int g = 0; g < FFM_MAX_GROUPS; ++g) d_own[g] = 0.f;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int mfi = wave + PW * i;
+            const int mfi = colw + CW * i;
             if (mfi < MF) {
                 const bool mine = __builtin_amdgcn_readfirstlane((int)((unsigned)mfi % (unsigned)tiles_n)) == tn;
                 const int row0 = mfi * 16 + fgrp * 4;
@@ -645,7 +762,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             for (int g = 0; g < FFM_MAX_GROUPS; ++g)
                 if (g < p.G) d_own[g] = rows4(d_own[g]);
             if (fgrp == 0) {
-                float* dst = DsP + wave * ((FFM_MAX_GROUPS + 2) * 16) + j;
+                float* dst = DsP + colw * ((FFM_MAX_GROUPS + 2) * 16) + j;
                 dst[0] = d_all;
                 dst[16] = d_uni;
 #pragma unroll
@@ -659,7 +776,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             const int g = tid / r, jj = tid % r;
             float all = 0.f, own = 0.f, uni = 0.f;
 #pragma unroll
-            for (int w = 0; w < PW; ++w) {
+            for (int w = 0; w < CW; ++w) {
                 const float* src = DsP + w * ((FFM_MAX_GROUPS + 2) * 16) + jj;
                 all += src[0];
                 uni += src[16];
@@ -671,7 +788,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         frag_t lb[NF];
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-            lb[nf] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(LwB) + (wave * WN + nf * 16 + frow) * 64 + fgrp * 16);
+            lb[nf] = *reinterpret_cast<const frag_t*>(reinterpret_cast<const char*>(LwB) + (colw * WN + nf * 16 + frow) * 64 + fgrp * 16);
         FFM_STAMP(10);
         // ts fragments in batches ahead of their MFMAs (the weight-fragment ring is dead; a tile whose accumulators
         // and pre-activation rows already fill the register file takes smaller batches)
@@ -725,14 +842,14 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             float v[8];
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8]);
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8 + 4]);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8]);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[wave * WN + ch * 8 + 4]);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[colw * WN + ch * 8]);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&Bias[colw * WN + ch * 8 + 4]);
             if constexpr (LNIN) {
                 // rstd (x W'^T - mu c) + d: the rows went through the matrix cores un-normalised
                 const int trow = rg * 32 + row < BMp ? rg * 32 + row : BMp - 1;
                 const float mu = Mu[trow], rs = Rs[trow];
-                const f32x4 cv0 = *reinterpret_cast<const f32x4*>(&Cv[wave * WN + ch * 8]);
-                const f32x4 cv1 = *reinterpret_cast<const f32x4*>(&Cv[wave * WN + ch * 8 + 4]);
+                const f32x4 cv0 = *reinterpret_cast<const f32x4*>(&Cv[colw * WN + ch * 8]);
+                const f32x4 cv1 = *reinterpret_cast<const f32x4*>(&Cv[colw * WN + ch * 8 + 4]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     v[c] = rs * (c0[c] - mu * cv0[c]) + b0[c];
@@ -791,8 +908,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     sq += __shfl_xor(sq, o, 64);
                 }
                 if (ch == 0 && rg * 32 + row < BMp) {
-                    RowP[(wave * BMp + rg * 32 + row) * 2] = su;
-                    RowP[(wave * BMp + rg * 32 + row) * 2 + 1] = sq;
+                    RowP[(colw * BMp + rg * 32 + row) * 2] = su;
+                    RowP[(colw * BMp + rg * 32 + row) * 2 + 1] = sq;
                 }
             }
             if (ok) {
@@ -813,11 +930,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     });
     if constexpr (ROWST) {
         __syncthreads();
-        for (int i = tid; i < BMp; i += PT) {
+        for (int i = tid; i < BMp; i += ET) {
             if (m0 + i < p.M) {
                 float su = 0.f, sq = 0.f;
 #pragma unroll
-                for (int w = 0; w < PW; ++w) {
+                for (int w = 0; w < CW; ++w) {
                     su += RowP[(w * BMp + i) * 2];
                     sq += RowP[(w * BMp + i) * 2 + 1];
                 }
@@ -833,23 +950,25 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
 #endif
 }
 
-template <int MF, int NF, bool RK, int FL, int PWV = 4>
+template <int MF, int NF, bool RK, int FL, int PWV = 4, int KS = 0>
 int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
-    constexpr int PW = PWV, PT = PWV * 64;
+    constexpr int PW = PWV, PT = PWV * 64, CW = KS ? PW / 2 : PW;
     using G = PanelGeom<MF, RK, PWV>;
-    const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (PW * 16 * NF));
-    constexpr int lds = G::RING + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, PW);
+    const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (CW * 16 * NF));
+    constexpr int partb = KS ? CW * (MF * NF + (RK ? (MF + CW - 1) / CW : 0)) * 1024 : 0;      // K split: partial accumulators
+    constexpr int lds = (partb > G::RING ? partb : G::RING) + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, CW);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert((RK ? 16 * MF * 192 : 0) + PW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? PW * 16 * MF * 8 : 0) <= G::RING,
+    static_assert((RK ? 16 * MF * 192 : 0) + CW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? CW * 16 * MF * 8 : 0) <= G::RING,
                   "epilogue tiles alias the ring");
+    if (KS && (a.K % 256)) return FFM_EUNSUP;         // the K-split loop is unrolled by four K64 steps
     static bool done = false;                         // one per instantiation
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL, PWV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_panel_kernel<MF, NF, RK, FL, PWV, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL, PWV>), dim3(tiles), dim3(PT), lds, s, a);
+    hipLaunchKernelGGL((gemm_panel_kernel<MF, NF, RK, FL, PWV, KS>), dim3(tiles), dim3(PT), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

@@ -9,6 +9,7 @@
             case 5: return ffm_panel::launch_panel<11, 1, true, F, 8>(a, s);               \
             case 7: return ffm_panel::launch_panel<13, 3, true, F, 8>(a, s);               \
             case 8: return ffm_panel::launch_panel<10, 2, true, F>(a, s);                  \
+            case 11: return ffm_panel::launch_panel<10, 2, true, F, 8, 1>(a, s);           \
         }                                                                                  \
         return FFM_EINVAL;
 
@@ -23,6 +24,7 @@ int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s) {
             if (cfg == 3) return ffm_panel::launch_panel<11, 2, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS>(a, s);
             if (cfg == 5) return ffm_panel::launch_panel<11, 1, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS, 8>(a, s);
             if (cfg == 8) return ffm_panel::launch_panel<10, 2, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS>(a, s);
+            if (cfg == 11) return ffm_panel::launch_panel<10, 2, true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS, 8, 1>(a, s);
             return FFM_EINVAL;
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                      // dX of c_proj
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR)                                      // dX of c_fc

@@ -765,3 +765,21 @@ def test_text_tower_ends_vs_autograd(ops, use_ot, N, n_cls, n_ctx, TL, w, D):
     ops.text_ctx_grad(gin, dctx, n_cls, TL)
     refc = gin.double().view(N, n_cls, TL, w)[:, :, 1:1 + n_ctx, :].sum(1)
     check(dctx, refc, 1e-6, "dctx")
+
+
+@pytest.mark.parametrize("mask,what", [((1 << 5) | (1 << 6) | (1 << 7) | (1 << 10), "two waves per SIMD as eight column slabs"),
+                                       ((1 << 7) | (1 << 9) | (1 << 11) | (1 << 12), "K split + the one-wave 240x256 tile")])
+def test_panel_tile_configurations_behind_the_mask(mask, what):
+    """FFM_PANEL_MASK (read once per process) switches on the panel-kernel configurations that are NOT in the default set
+    (csrc/gemm_panel.hip: the 128-column two-wave twins, the 8-wave K split of the 160 x 128 tiles, the one-wave 240 x 256
+    tile): the panel, row-sum and LayerNorm-folding tests again in a child process, so that every instantiated kernel stays
+    held to float64."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFM_PANEL_MASK=str(mask))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_kernels_gpu.py"), "-k",
+                        "gemm_panel or gemm_rowstats or layernorm_folded"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "deselected" in r.stdout

@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-FFM_SERIAL=1 bash tools/prof_tool.sh r03_rn50_serial bench_rn50.py 32 10
-bash tools/prof_tool.sh r03_rn50 bench_rn50.py 32 10
-FFM_SERIAL=1 bash tools/prof_tool.sh r03_oct3d_serial bench_oct3d.py --json
-rm -f gpurun_out/*_kernel_trace.csv
-python bench.py --config c5 --steps 20 --warmup 3 2>/dev/null | tail -1 | cut -c1-400
+for m in 1408 7552; do
+export FFM_PANEL_MASK=$m
+bash tools/prof.sh ks_$m > /dev/null 2>&1
+python tools/trace_timeline.py gpurun_out/ks_${m}_kernel_trace.csv > gpurun_out/ks_${m}_timeline.txt 2>&1
+rm -f gpurun_out/ks_${m}_kernel_trace.csv
+echo "=== mask $m"; head -28 gpurun_out/ks_${m}_timeline.txt | cut -c1-130
+done
