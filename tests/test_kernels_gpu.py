@@ -774,6 +774,7 @@ def test_panel_tile_configurations_behind_the_mask(mask, what):
     (csrc/gemm_panel.hip: the 128-column two-wave twins, the 8-wave K split of the 160 x 128 tiles, the one-wave 240 x 256
     tile): the panel, row-sum and LayerNorm-folding tests again in a child process, so that every instantiated kernel stays
     held to float64."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
