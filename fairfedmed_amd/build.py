@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libffm_hip.so")
-SOURCES = ["gemm.hip", "gemm_panel.hip", "gemm_panel_rk.hip", "gemm_skinny.hip", "rowwise.hip", "lora.hip", "head.hip", "head_ot.hip", "optim.hip", "attention.hip", "slice3d.hip", "conv.hip", "evalmetrics.hip", "evalsort.hip", "transport.hip", "text.hip"]
+SOURCES = ["gemm.hip", "gemm_panel.hip", "gemm_panel_rk.hip", "gemm_panel_rk2.hip", "gemm_panel_rk3.hip", "gemm_skinny.hip", "rowwise.hip", "lora.hip", "head.hip", "head_ot.hip", "optim.hip", "attention.hip", "slice3d.hip", "conv.hip", "evalmetrics.hip", "evalsort.hip", "transport.hip", "text.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(CSRC, "gemm_panel_impl.h"), os.path.join(ROOT, "include", "ffm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -60,7 +60,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)

@@ -16,11 +16,13 @@ struct ffm_panel_cfg {
 constexpr int FFM_PANEL_NCFG = 13;
 constexpr ffm_panel_cfg FFM_PANEL_CFGS[FFM_PANEL_NCFG] = {{13, 6, true, 1, 4, 0}, {16, 4, false, 1, 4, 0}, {10, 2, false, 1, 4, 0}, {11, 2, true, 1, 4, 0},
                                                           {8, 4, false, 2, 4, 0},
-                                                          // two waves per SIMD: the same tiles as 3, 2 and 0
+                                                          // two waves per SIMD: the same tiles as 3, 2 (5, 6: measured, lost,
+                                                          // not instantiated any more) and 0
                                                           {11, 1, true, 1, 8, 0}, {10, 1, false, 1, 8, 0}, {13, 3, true, 1, 8, 0},
                                                           // 8: the 160-row FairLoRA tile for N = 768 (240 blocks at 6304
                                                           // rows where the 176-row tile launches 216); 9 / 10: 240 x 256
-                                                          // for qkv (243 blocks), one and two waves per SIMD
+                                                          // for qkv (243 blocks), one (9: lost, not instantiated) and two
+                                                          // waves per SIMD
                                                           {10, 2, true, 1, 4, 0}, {15, 4, false, 1, 4, 0}, {15, 2, false, 1, 8, 0},
                                                           // 11 / 12: the 160x128 tiles (FairLoRA / plain) with 8 waves as
                                                           // 4 column slabs x 2 K halves (K % 256 == 0)

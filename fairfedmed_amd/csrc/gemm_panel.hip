@@ -7,11 +7,12 @@
 //   7  208x384 FairLoRA, two waves per SIMD: c_fc forward 53.8 -> 44.7 us, dX(c_proj) 50.5 -> 44.5 us
 //   8  160x128 FairLoRA (240 blocks where the 176-row tile launches 216): c_proj forward 40.2 -> 38.1, dX(c_fc) 39.6 -> 38.8
 //   10 240x256 plain, two waves per SIMD (243 blocks): qkv forward 31.9 -> 27.7 us (one wave per SIMD, 9: 32.9)
-// Off: the 128-column two-wave twins as eight column slabs (5, 6: no gain, twice the LDS fragment reads), and the K split
+// Measured and no longer instantiated: the 128-column two-wave twins as eight column slabs (5, 6: no gain, twice the LDS
+// fragment reads) and the one-wave 240x256 tile (9).  Off but instantiated: the K split
 // of the 160x128 tiles (11, 12: 4 column slabs x 2 K halves - isolated c_proj forward 39.6 -> 36.9 us, dX(c_fc) 38.9 ->
 // 36.1, dX(qkv) 25.0 -> 23.7, but IN THE STEP, beside the text tower and the LoRA-gradient reductions, the same launches
 // take what the 4-wave tiles take (44.0 / 43.8, 40.5 / 38.4 us) and the step is 0.03 ms slower: 4.73 -> 4.77 ms twice in
-// one call).  All of them stay instantiated and tested (tests/test_kernels_gpu.py runs the panel tests under both masks).
+// one call); tests/test_kernels_gpu.py runs the panel tests with it switched on and on the round-2 tiles alone.
 #ifndef FFM_PANEL_MASK_DEFAULT
 #define FFM_PANEL_MASK_DEFAULT ((1 << 7) | (1 << 8) | (1 << 10))
 #endif
@@ -87,6 +88,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         const int bm = 16 * cf.mf, bn = ffm_panel_bn(cf), nfe = bn / 64;      // nfe: the tile's width in 64-column units
         if (N % bn || cf.rankop != rk) continue;
         if (c >= 5 && !((exp_mask >> c) & 1)) continue;
+        if (c == 5 || c == 6 || c == 9) continue;              // measured in round 3, lost, no longer instantiated
         if (cf.ks && K % 256) continue;                       // the K-split loop is unrolled by four K64 steps
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
@@ -122,8 +124,6 @@ int ffm_panel_tiles_n(int N, int cfg) { return N / ffm_panel_bn(FFM_PANEL_CFGS[c
             case 1: return ffm_panel::launch_panel<16, 4, false, F>(a, s);                 \
             case 2: return ffm_panel::launch_panel<10, 2, false, F>(a, s);                 \
             case 4: return ffm_panel::launch_panel<8, 4, false, F>(a, s);                  \
-            case 6: return ffm_panel::launch_panel<10, 1, false, F, 8>(a, s);              \
-            case 9: return ffm_panel::launch_panel<15, 4, false, F>(a, s);                 \
             case 10: return ffm_panel::launch_panel<15, 2, false, F, 8>(a, s);             \
             case 12: return ffm_panel::launch_panel<10, 2, false, F, 8, 1>(a, s);          \
         }                                                                                  \
