@@ -337,6 +337,8 @@ class FairLoRAEngine:
         self.ev_head_bwd = torch.cuda.Event()
         self.ev_text_bwd = torch.cuda.Event()
         self.ev_start = torch.cuda.Event()
+        self.ev_pack = torch.cuda.Event()
+        self._pack_event = None
 
     # ---------------------------------------------------- vision tower hooks --
     def _init_vision(self, max_images: int) -> None:
@@ -832,13 +834,12 @@ class FairLoRAEngine:
         P, L = v.grid * v.grid, v.tokens
         rows = images * L
         a32 = self.attr_i32[:b] if has_attr else None
-        if self.fused_rank:
-            self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
         if self.sops.glob:
             self._glue(self.sops.prepare)             # S_eff = S + S_global
         ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
                         self.vis.x[0][:rows], images, L, rowstat=self.vis.rowp[0] if self.vis.rowp is not None else None)
+        self._rank_operands_ready()                   # LoRA matrices -> GEMM rank operands (they change every step)
         out = self._stack_forward(self.vis, rows, images, a32, L * S)
         ops.layernorm_fwd(out, self.hpost[:rows], self.lnpost[0], self.lnpost[1], self.post_stats[0],
                           self.post_stats[1])
@@ -846,6 +847,21 @@ class FairLoRAEngine:
         if wait is not None:
             self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
         self._head_forward(rows, images, L)
+
+    def _pack_rank_operands(self) -> None:
+        """ffm_lora_pack_multi over every adapter (one or two launches) on the CURRENT stream."""
+        plan = getattr(self, "pack_plan", None)
+        if plan is not None and getattr(self, "fused_rank", True):
+            plan.run()
+
+    def _rank_operands_ready(self) -> None:
+        """In a training step the packing runs at the head of the side stream, beside the patch embedding (27 us off the
+        main queue), and the vision chain waits for it here; outside a step (inference) it runs in line."""
+        ev = getattr(self, "_pack_event", None)
+        if ev is None:
+            self._pack_rank_operands()
+        else:
+            self._ev_wait(torch.cuda.current_stream(self.device), ev)
 
     def _head_forward(self, rows: int, images: int, L: int) -> None:
         cfg = self.cfg
@@ -907,9 +923,15 @@ class FairLoRAEngine:
         self._ev_record(self.ev_start, main)
         self._ev_wait(self.side, self.ev_start)           # parameters of the previous step are final
         with self._on(self.side):
+            self._pack_rank_operands()
+            self._ev_record(self.ev_pack, self.side)
             self._text_forward(True, self.side)
         self._ev_record(self.ev_text_fwd, self.side)
-        self._vision_forward(b, S, has_attr, wait=self.ev_text_fwd)
+        self._pack_event = self.ev_pack
+        try:
+            self._vision_forward(b, S, has_attr, wait=self.ev_text_fwd)
+        finally:
+            self._pack_event = None
         ops.ce_loss(self.logits_img, self.label_buf, self.logits, self.prob, self.loss, self.dlogits_img,
                     self.finite, b, S, cfg.n_cls)
         self._head_backward(rows, images, L)

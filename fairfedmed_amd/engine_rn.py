@@ -491,8 +491,6 @@ class RN50Engine(FairLoRAEngine):
         r1 = b * H1 * H1
         a32 = self.attr_i32[:b] if has_attr else None
         sz, sa = [t[:r1] for t in self.sz], [t[:r1] for t in self.sa]
-        if self.pack_plan is not None:
-            self.pack_plan.run()                      # LoRA matrices -> GEMM rank operands (they change every step)
         if self.sops.glob:
             self._glue(self.sops.prepare)             # S_eff = S + S_global (GLOBAL_S)
         t1 = self.stat_rows(r1)
@@ -503,6 +501,7 @@ class RN50Engine(FairLoRAEngine):
             self.sbn[i].fwd(sz[i], sa[i], True, part=self.stat_buf[0], part_rows=ti)
         x = self.p0[:b * H2 * H2]
         ops.avgpool2(sa[2], x, b, H1, H1)
+        self._rank_operands_ready()                   # LoRA matrices -> GEMM rank operands (packed beside the stem)
         for blk in self.blocks:
             x = blk.forward(x, b, a32)
         # attention pool (clip/model.py:75-118): all HW + 1 tokens come back
