@@ -161,20 +161,23 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
     const int b = row / L, l = row % L;
-    const int nchunk = width >> 2;
+    const int nchunk = width >> 3;                   // 8-element chunks: 16-byte loads in bf16 (width % 8 == 0: bad_width)
     const T* src = (l == 0) ? cls : patch + ((size_t)b * (L - 1) + (l - 1)) * width;
     const T* pr = pos + (size_t)l * width;
-    constexpr int MAXC = 8;              // 4-wide chunks here: width <= 4 * 64 * 8
-    f32x4 v[MAXC];
+    constexpr int MAXC = 4;                          // width <= 8 * 64 * 4
+    float v[MAXC][8], g[MAXC][8], bb[MAXC][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const f32x4 a = Vec4<T>::load(src + c * 4);
-            const f32x4 p = Vec4<T>::load(pr + c * 4);
+            float a[8], p[8];
+            Vec8<T>::load(src + c * 8, a);
+            Vec8<T>::load(pr + c * 8, p);
+            load8f(gamma + c * 8, g[i]);             // (requested with the row: not a second round trip behind the sums)
+            load8f(beta + c * 8, bb[i]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 8; ++e) {
                 // the reference rounds (token + pos) to the activation dtype before ln_pre
                 v[i][e] = Elem<T>::to_f(Elem<T>::from_f(a[e] + p[e]));
                 s += v[i][e];
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
         const int c = lane + 64 * i;
         if (c < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + 1e-5f);
@@ -198,17 +201,15 @@ __global__ __launch_bounds__(256) void embed_lnpre_kernel(const T* __restrict__ 
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane + 64 * i;
         if (c < nchunk) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c * 4);
-            f32x4 o;
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (v[i][e] - mean) * rstd * g[i][e] + bb[i][e];
                 const float st = Elem<T>::to_f(Elem<T>::from_f(o[e]));       // the row as stored
                 so += st;
                 qo += st * st;
             }
-            Vec4<T>::store(xr + c * 4, o);
+            Vec8<T>::store(xr + c * 8, o);
         }
     }
     if (rowstat) {          // {sum, sum of squares} of the OUTPUT row: the first block's ln_1 folded into its qkv GEMM
