@@ -189,6 +189,138 @@ __global__ __launch_bounds__(LD_WAVES * 64) void lora_down_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// lora_down on the matrix cores (bf16, rank <= 16, P given as [r][K] rows: the backward direction u = g B^T).
+// The VALU kernel above stages P (K x r floats: 98 KB at K = 3072) into LDS in EVERY block - as many bytes again as
+// the activation rows it reads - and ran at 1.2 TB/s where it stood alone on the critical path: the last down projection
+// of a step (block 0 has no dX(c_fc) GEMM to ride in), 31.7 us for 38.7 MB.  Here a block is 16 rows x 4 K slices (one
+// wave each): x fragments straight from global memory (16 B per lane), P fragments converted to bf16 in registers
+// (the same rounding the VALU kernel applies element by element), v_mfma_f32_16x16x32_bf16, slices summed through LDS,
+// then ts = scaling * t * s_b and the block's dS partial as in the panel GEMM's rank stage.
+// ---------------------------------------------------------------------------
+constexpr int LDM_ROWS = 16, LDM_WAVES = 4, LDM_U = 4;       // rows per block, K slices, k32 steps of loads in flight
+
+__global__ __launch_bounds__(LDM_WAVES * 64) void lora_down_mfma_kernel(
+    const bf16_t* __restrict__ x, int ldx, const float* __restrict__ P, const float* __restrict__ S,
+    const int32_t* __restrict__ attr, int M, int K, int r, int G, int rows_per_sample, float scaling, float lambda_group,
+    float* __restrict__ t_out, float* __restrict__ ts_out, const float* __restrict__ t_fwd, float* __restrict__ ds_part) {
+    __shared__ f32x4 red[LDM_WAVES][64];
+    __shared__ float dsum[(FFM_MAX_GROUPS + 2) * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kgp = lane >> 4;                  // A: row col, B: rank slot col; 8 consecutive k each
+    const int row0 = blockIdx.x * LDM_ROWS;
+    int arow = row0 + col;
+    arow = arow < M ? arow : M - 1;
+    const int ksl = K / LDM_WAVES;                                // K slice of this wave (a multiple of 32)
+    const bf16_t* xa = x + (size_t)arow * ldx + wave * ksl + kgp * 8;
+    const float* pb = P + (size_t)(col < r ? col : 0) * K + wave * ksl + kgp * 8;
+    const bool bok = col < r;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int steps = ksl >> 5;
+    for (int s0 = 0; s0 < steps; s0 += LDM_U) {
+        bf16x8 av[LDM_U];
+        f32x4 b0[LDM_U], b1[LDM_U];
+#pragma unroll
+        for (int u = 0; u < LDM_U; ++u) {
+            const int st = s0 + u < steps ? s0 + u : steps - 1;  // (clamped: the surplus products are skipped below)
+            av[u] = *reinterpret_cast<const bf16x8*>(xa + st * 32);
+            b0[u] = *reinterpret_cast<const f32x4*>(pb + st * 32);
+            b1[u] = *reinterpret_cast<const f32x4*>(pb + st * 32 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < LDM_U; ++u) {
+            if (s0 + u >= steps) break;
+            bf16x8 bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bv[e] = bok ? (bf16_t)b0[u][e] : (bf16_t)0.f;
+                bv[4 + e] = bok ? (bf16_t)b1[u][e] : (bf16_t)0.f;
+            }
+            // D[j][row] += sum_k P[j][k] x[row][k]: lane (column = row `col`... ) - operand order (P, x) puts the rank slot on
+            // the accumulator's row index 4 kgp + e and the activation row on its column `col`
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av[u], acc, 0, 0, 0);
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    f32x4 t4 = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < LDM_WAVES; ++w) {
+        const f32x4 o = red[w][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] += o[e];
+    }
+    // lane: activation row `col` of the block, rank slots j = 4 kgp + e
+    const int grow = row0 + col;
+    const bool rok = grow < M;
+    const int sample = (rok ? grow : M - 1) / rows_per_sample;
+    const int ga = attr ? attr[sample] : -1;
+    const float w_own = lambda_group, w_oth = (1.0f - lambda_group) / (float)(G > 1 ? G - 1 : 1), w_uni = 1.0f / (float)G;
+    const bool do_ds = t_fwd && ds_part;
+    float wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = 4 * kgp + e;
+        wv[e] = 0.f;
+        if (j < r && rok) {
+            float sb = 0.f;
+            for (int g = 0; g < G; ++g) sb += (ga < 0 ? w_uni : (ga == g ? w_own : w_oth)) * S[g * r + j];
+            if (t_out) t_out[(size_t)grow * r + j] = t4[e];
+            if (ts_out) ts_out[(size_t)grow * r + j] = scaling * t4[e] * sb;
+            if (do_ds) wv[e] = scaling * t_fwd[(size_t)grow * r + j] * t4[e];
+        }
+    }
+    if (!do_ds) return;
+    // dS partial of the block's 16 rows: sum over the rows (lanes of equal kgp: the low four lane bits) per rank slot, split
+    // into all rows / rows without a group / rows of group g, combined as the panel GEMM's rank stage does
+    float d_all[4], d_uni[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        d_all[e] = ga < 0 ? 0.f : wv[e];
+        d_uni[e] = ga < 0 ? wv[e] : 0.f;
+    }
+    auto rows16 = [](float v) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        d_all[e] = rows16(d_all[e]);
+        d_uni[e] = rows16(d_uni[e]);
+    }
+    if (col == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dsum[0 * 16 + 4 * kgp + e] = d_all[e];
+            dsum[1 * 16 + 4 * kgp + e] = d_uni[e];
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float o = rows16(ga == g ? wv[e] : 0.f);
+            if (col == 0) dsum[(2 + g) * 16 + 4 * kgp + e] = o;
+        }
+    }
+    // (one wave: the LDS writes above are visible to it after the wait the compiler puts in front of the reads)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < G * r) {
+        const int g = lane / r, j = lane % r;
+        ds_part[((size_t)blockIdx.x * G + g) * r + j] = w_uni * dsum[16 + j] + w_oth * dsum[j] + (w_own - w_oth) * dsum[(2 + g) * 16 + j];
+    }
+    for (int i = lane + 64; i < G * r; i += 64) {
+        const int g = i / r, j = i % r;
+        ds_part[((size_t)blockIdx.x * G + g) * r + j] = w_uni * dsum[16 + j] + w_oth * dsum[j] + (w_own - w_oth) * dsum[(2 + g) * 16 + j];
+    }
+}
+
+static bool down_mfma_ok(int M, int K, int r, int dtype, int layout_rk) {
+    return dtype == FFM_BF16 && layout_rk && r <= 16 && M >= 1024 && K % (32 * LDM_WAVES) == 0;
+}
+
 // K slices per block: enough waves to fill the chip (>= ~2000) while every lane of a slice has work
 static int down_kq(int K, int es) {
     const int nch = K * es / 16;
@@ -569,6 +701,8 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ffm_reduce_desc
 }  // namespace
 
 extern "C" int ffm_lora_down_blocks(int M, int K, int r, int dtype) {
+    // dS partial rows a BACKWARD call (P given as [r][K] rows, t_fwd / ds_part set: the only calls that write them) produces
+    if (down_mfma_ok(M, K, r, dtype, 1)) return (M + LDM_ROWS - 1) / LDM_ROWS;
     const int rows = (LD_WAVES / down_kq(K, dtype == FFM_BF16 ? 2 : 4)) * (64 / down_rp(r, dtype));
     return (M + rows - 1) / rows;
 }
@@ -587,6 +721,12 @@ extern "C" int ffm_lora_down(const void* x, int ldx, const float* P, int layout_
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
     if (((size_t)K * es) % 16 || ((size_t)ldx * es) % 16 || ((uintptr_t)x & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (down_mfma_ok(M, K, r, dtype, layout_rk)) {
+        hipLaunchKernelGGL(lora_down_mfma_kernel, dim3((M + LDM_ROWS - 1) / LDM_ROWS), dim3(LDM_WAVES * 64), 0, s, (const bf16_t*)x,
+                           ldx, P, S, attr, M, K, r, G, rows_per_sample, scaling, lambda_group, t, ts, t_fwd, ds_part);
+        FFM_CHECK_LAUNCH();
+        return FFM_OK;
+    }
 #define DOWN(T, RP, RR, J0) launch_down<T, RP>(x, ldx, P, layout_rk, S, attr, M, K, RR, G, rows_per_sample, scaling, \
                                                lambda_group, t, ts, t_fwd, ds_part, r, J0, s)
     if (r > 16) {                       // rank 17..32: two passes over the rank (second pass re-reads x)

@@ -385,7 +385,11 @@ def mix(attr, G, lam=0.7):
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 @pytest.mark.parametrize("M,K,r,G,rps,rk,use_attr", [(1000, 768, 8, 3, 197, False, True), (333, 3072, 16, 3, 50, True, True),
                                                       (70, 128, 4, 2, 17, False, False), (300, 256, 32, 3, 100, True, True),
-                                                      (300, 256, 12, 3, 100, False, True)])
+                                                      (300, 256, 12, 3, 100, False, True),
+                                                      # bf16 + [r, K] rows + >= 1024 rows: the matrix-core kernel (the step's last
+                                                      # down projection, u = dpre B_fc^T), ragged last block, 1..16 rank slots
+                                                      (6304, 3072, 8, 3, 197, True, True), (2000, 768, 16, 2, 50, True, False),
+                                                      (1030, 512, 5, 3, 197, True, True)])
 def test_lora_down(ops, dt, M, K, r, G, rps, rk, use_attr):
     x = rnd(M, K, dt=dt, seed=25)
     P = rnd(r, K, scale=0.1, seed=26) if rk else rnd(K, r, scale=0.1, seed=26)
