@@ -665,12 +665,17 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Ks + rm2(row, ks * 4 + g)), qf[ks], acc, 0, 0, 0);
-            if ((F0 + f) * 16 + 15 >= L) {                        // the fragment that straddles L (uniform branch)
+            // only the LAST key fragment can straddle L (NF = ceil(L / 16)): a compile-time test in the unrolled loop - as a
+            // run-time one hipcc turned it into compare + select on every element of every fragment
+            if (F0 + f == NF - 1 && (F0 + f) * 16 + 15 >= L) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if ((F0 + f) * 16 + g * 4 + e >= L) acc[e] = -INFINITY;
             }
             s[f] = acc;
+            // (hipcc puts a canonicalising v_max_f32 x, x in front of fmaxf on every MFMA result; v_max3_f32 by inline asm
+            // is NOT the way out: the hazard recogniser does not see an asm statement as a reader of the MFMA's registers,
+            // inserts no wait states in front of it, and the maximum comes out as garbage - measured, round 3)
             mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
         }
         if constexpr (CP > CF) s[CF] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
                     sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Ks + rm2(row, ks * 4 + g)), qf[ks], sa, 0, 0, 0);
                     pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Vs + rm2(row, ks * 4 + g)), dof[ks], pa, 0, 0, 0);
                 }
-                if (f * 16 + 15 >= L) {
+                if (f == NF - 1 && f * 16 + 15 >= L) {               // (compile-time: only the last fragment can straddle L)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (f * 16 + g * 4 + e >= L) sa[e] = -INFINITY;
