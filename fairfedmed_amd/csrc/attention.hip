@@ -600,9 +600,10 @@ __device__ __forceinline__ bf16x8 tr_frag_x(uint32_t lane_step, int tile_off) {
 
 // (b, h) pair and half of a block id: ids b and b + 8 (one XCD under round-robin placement: speed only) are the two
 // halves of one pair
-__device__ __forceinline__ void unit_of_block(int bid, int& bh, int& half) {
-    bh = (bid >> 4) * 8 + (bid & 7);
-    half = (bid >> 3) & 1;
+// (P parts per pair instead of two halves: ids b, b + 8, ..., b + 8 (P - 1))
+template <int P> __device__ __forceinline__ void unit_of_block(int bid, int& bh, int& part) {
+    bh = (bid / (8 * P)) * 8 + (bid & 7);
+    part = (bid >> 3) % P;
 }
 
 template <typename F> __device__ __forceinline__ void static_for4(F&& f) {
@@ -612,11 +613,15 @@ template <typename F> __device__ __forceinline__ void static_for4(F&& f) {
     f(std::integral_constant<int, 3>{});
 }
 
-constexpr int A2_NW = 7;            // waves per block = 16-row tiles of half a head (L <= 224)
+// waves per block = 16-row tiles of one part of a head (L <= 224: 14 tiles): P = 2 halves of 7 waves, three blocks per CU at
+// <= 80 registers; P = 4 quarters of 4 waves, three blocks per CU = 3 waves per SIMD at <= 168 registers, two full rounds
+// of 768 blocks (FFM_ATTN_PARTS=4: measured in round 3, see run_fwd2s)
+template <int P> constexpr int a2_nw() { return P == 2 ? 7 : 4; }
+template <int P> constexpr int a2_wpe() { return P == 2 ? 6 : 3; }
 constexpr float A2_C = 0.125f * 1.44269504088896341f;
 
-template <int NF, bool SH>
-__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int NF, bool SH, int P = 2>
+__global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu(a2_wpe<P>(), a2_wpe<P>()))) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                float* __restrict__ lse, int L, int heads, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CA = 8, CB = NF - CA;                           // key fragments of the two chunks
@@ -627,7 +632,8 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     char* Vs = smem;                                              // [R8][128 B]
     char* Ks = smem + R8 * 128;
     int bh, half;
-    unit_of_block(blockIdx.x, bh, half);
+    constexpr int A2_NW = a2_nw<P>();
+    unit_of_block<P>(blockIdx.x, bh, half);
     if (bh >= BH) return;
     const int b = bh / heads, h = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -635,9 +641,9 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
-    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
-    const int qt = half * h0 + wave;                              // this wave's 16-query tile
-    const bool active = qt < (half ? NFq : h0);
+    const int NFq = (L + 15) >> 4, tb = NFq / P, tr = NFq % P;    // tiles of part p: tb + (p < tr), from p tb + min(p, tr)
+    const int qt = half * tb + (half < tr ? half : tr) + wave;    // this wave's 16-query tile
+    const bool active = wave < tb + (half < tr ? 1 : 0);
 
     dma_tile<A2_NW>(base + 2 * E, ld, L, R8, Vs, wave, lane);
     dma_tile<A2_NW>(base + E, ld, L, R8, Ks, wave, lane);
@@ -724,16 +730,26 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     }
 }
 
-template <int NF, bool SH>
-int run_fwd2s(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+// FFM_ATTN_PARTS=4 (A/B runs): quarter heads of 4 waves instead of half heads of 7
+inline int attn_parts() {
+    static const int p = (getenv("FFM_ATTN_PARTS") && getenv("FFM_ATTN_PARTS")[0] == '4') ? 4 : 2;
+    return p;
+}
+
+template <int NF, bool SH, int P>
+int run_fwd2p(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
     constexpr int lds = 2 * (SH ? NF * 16 - 8 : NF * 16) * 128;
-    int e = set_lds(attn2_fwd_kernel<NF, SH>, lds);
+    int e = set_lds(attn2_fwd_kernel<NF, SH, P>, lds);
     if (e) return e;
     const int BH = B * heads;
-    hipLaunchKernelGGL((attn2_fwd_kernel<NF, SH>), dim3(((BH + 7) / 8) * 16), dim3(A2_NW * 64), lds, s, (const bf16_t*)qkv, (bf16_t*)out,
-                       lse, L, heads, BH);
+    hipLaunchKernelGGL((attn2_fwd_kernel<NF, SH, P>), dim3(((BH + 7) / 8) * 8 * P), dim3(a2_nw<P>() * 64), lds, s, (const bf16_t*)qkv,
+                       (bf16_t*)out, lse, L, heads, BH);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
+}
+template <int NF, bool SH>
+int run_fwd2s(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+    return attn_parts() == 4 ? run_fwd2p<NF, SH, 4>(qkv, out, lse, B, L, heads, s) : run_fwd2p<NF, SH, 2>(qkv, out, lse, B, L, heads, s);
 }
 template <int NF>
 int run_fwd2(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
@@ -746,8 +762,8 @@ constexpr float A2_LOG2E = 1.44269504088896341f;
 // dQ (and delta = rowsum(dO * O), which the dK/dV kernel reads back): a wave owns a 16-query tile, the key on the MFMA
 // row.  S^T = K Q^T and dP^T = V dO^T share the lane layout; dP's accumulator starts at -delta, so dS^T = p * acc with
 // p = exp2(c s - log2(e) lse): one FMA, one exp and one multiply per element (the 1/8 goes onto the dQ tile at the end).
-template <int NF, bool SH>
-__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+template <int NF, bool SH, int P = 2>
+__global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu(a2_wpe<P>(), a2_wpe<P>()))) void attn2_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                   const float* __restrict__ lse, const bf16_t* __restrict__ o_fwd,
                                                                   bf16_t* __restrict__ dqkv, float* __restrict__ delta, int L,
                                                                   int heads, int BH) {
@@ -756,7 +772,8 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     char* Ks = smem;
     char* Vs = smem + R8 * 128;
     int bh, half;
-    unit_of_block(blockIdx.x, bh, half);
+    constexpr int A2_NW = a2_nw<P>();
+    unit_of_block<P>(blockIdx.x, bh, half);
     if (bh >= BH) return;
     const int b = bh / heads, h = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -765,9 +782,9 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
-    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
-    const int qt = half * h0 + wave;
-    const bool active = qt < (half ? NFq : h0);
+    const int NFq = (L + 15) >> 4, tb = NFq / P, tr = NFq % P;
+    const int qt = half * tb + (half < tr ? half : tr) + wave;
+    const bool active = wave < tb + (half < tr ? 1 : 0);
 
     dma_tile<A2_NW>(base + E, ld, L, R8, Ks, wave, lane);
     dma_tile<A2_NW>(base + 2 * E, ld, L, R8, Vs, wave, lane);
@@ -843,8 +860,8 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
 // dK / dV: a wave owns a 16-key tile and sweeps the queries, the query on the MFMA row: S = Q K^T, dP = dO V^T (its
 // accumulator starts at -delta[q]), then dV^T += dO^T P and dK^T += Q^T dS with the transposed operands read from the
 // same row-major Q / dO tiles (ds_read_b64_tr_b16).  lse (times log2 e) and delta sit in LDS per query.
-template <int NF, bool SH>
-__global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6))) void attn2_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+template <int NF, bool SH, int P = 2>
+__global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu(a2_wpe<P>(), a2_wpe<P>()))) void attn2_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    bf16_t* __restrict__ dqkv, int L, int heads, int BH) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -854,7 +871,8 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);     // [NF * 16]
     float* del_s = lse_s + NF * 16;
     int bh, half;
-    unit_of_block(blockIdx.x, bh, half);
+    constexpr int A2_NW = a2_nw<P>();
+    unit_of_block<P>(blockIdx.x, bh, half);
     if (bh >= BH) return;
     const int b = bh / heads, h = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -863,9 +881,9 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, g = lane >> 4;
-    const int NFq = (L + 15) >> 4, h0 = (NFq + 1) >> 1;
-    const int kt = half * h0 + wave;
-    const bool active = kt < (half ? NFq : h0);
+    const int NFq = (L + 15) >> 4, tb = NFq / P, tr = NFq % P;
+    const int kt = half * tb + (half < tr ? half : tr) + wave;
+    const bool active = wave < tb + (half < tr ? 1 : 0);
 
     dma_tile<A2_NW>(base, ld, L, R8, Qs, wave, lane);
     dma_tile<A2_NW>(dob, E, L, R8, dOs, wave, lane);
@@ -958,24 +976,30 @@ __global__ __launch_bounds__(A2_NW * 64) __attribute__((amdgpu_waves_per_eu(6, 6
     }
 }
 
-template <int NF, bool SH>
-int run_bwd2s(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
+template <int NF, bool SH, int P>
+int run_bwd2p(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
               int heads, hipStream_t s) {
     constexpr int R8 = SH ? NF * 16 - 8 : NF * 16;
     constexpr int lds_dq2 = 2 * NF * 16 * 128, lds_dkv2 = 2 * R8 * 128 + 2 * NF * 16 * 4;
     const int BH = B * heads;
-    int e = set_lds(attn2_bwd_dq_kernel<NF, false>, lds_dq2);
+    int e = set_lds(attn2_bwd_dq_kernel<NF, false, P>, lds_dq2);
     if (e) return e;
-    e = set_lds(attn2_bwd_dkv_kernel<NF, SH>, lds_dkv2);
+    e = set_lds(attn2_bwd_dkv_kernel<NF, SH, P>, lds_dkv2);
     if (e) return e;
-    const dim3 grid(((BH + 7) / 8) * 16), block(A2_NW * 64);
-    hipLaunchKernelGGL((attn2_bwd_dq_kernel<NF, false>), grid, block, lds_dq2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+    const dim3 grid(((BH + 7) / 8) * 8 * P), block(a2_nw<P>() * 64);
+    hipLaunchKernelGGL((attn2_bwd_dq_kernel<NF, false, P>), grid, block, lds_dq2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        (const bf16_t*)out, (bf16_t*)dqkv, delta, L, heads, BH);
     FFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NF, SH>), grid, block, lds_dkv2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
+    hipLaunchKernelGGL((attn2_bwd_dkv_kernel<NF, SH, P>), grid, block, lds_dkv2, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse,
                        (const float*)delta, (bf16_t*)dqkv, L, heads, BH);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
+}
+template <int NF, bool SH>
+int run_bwd2s(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
+              int heads, hipStream_t s) {
+    return attn_parts() == 4 ? run_bwd2p<NF, SH, 4>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s)
+                             : run_bwd2p<NF, SH, 2>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
 }
 template <int NF>
 int run_bwd2(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L,
