@@ -788,3 +788,17 @@ def test_panel_tile_configurations_behind_the_mask(mask, what):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "deselected" in r.stdout
+
+
+def test_attention_quarter_head_blocks_switch():
+    """FFM_ATTN_PARTS=4 (read once per process): the attn2_* kernels as quarter heads of 4 waves instead of half heads of
+    7 (csrc/attention.hip; measured slower, kept as a switch) - the attention tests again in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_kernels_gpu.py"), "-k",
+                        "test_attention_fwd_bwd"], env=dict(os.environ, FFM_ATTN_PARTS="4"), cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
