@@ -87,7 +87,7 @@ class GemmTimer:
     launching stream."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.orig_conv, self.rec = ops, ops.gemm_nt, ops.conv3x3, []
+        self.ops, self.orig, self.orig_conv, self.rec, self.empty = ops, ops.gemm_nt, ops.conv3x3, [], []
 
     def _pair(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -121,6 +121,19 @@ class GemmTimer:
 
     def __exit__(self, *a):
         self.ops.gemm_nt, self.ops.conv3x3 = self.orig, self.orig_conv
+
+    def calibrate(self, k=8):
+        """k event pairs with nothing between them, in the same backed-up queue: what a pair costs by itself."""
+        for _ in range(k):
+            e0, e1 = self._pair()
+            e0.record()
+            e1.record()
+            self.empty.append((e0, e1))
+
+    def pair_floor_us(self):
+        torch.cuda.synchronize()
+        t = sorted(e0.elapsed_time(e1) for e0, e1 in self.empty)
+        return t[len(t) // 2] * 1e3 if t else None
 
     def summary(self, min_rows=0):
         torch.cuda.synchronize()
@@ -480,8 +493,10 @@ def main():
             for _ in range(args.steps):
                 torch.cuda._sleep(spin)
                 eager_step()
+                gt.calibrate()
             n, ms, fl = gt.summary(min_rows=wl.min_rows)   # the vision tower's GEMMs (not the text tower's 40 rows)
             n_all, ms_all, fl_all = gt.summary()
+            floor_us = gt.pair_floor_us()
         eng.set_overlap(True)
         peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
         ach = fl / (ms * 1e-3) / 1e12
@@ -509,6 +524,10 @@ def main():
                 "traffic_source": tsrc,
                 "launches_per_step": n // args.steps, "avg_launch_us": ms * 1e3 / n,
                 "gemm_ms_per_step": ms / args.steps,
+                # what an event pair measures with NOTHING between the two records (median, same backed-up queue):
+                # the part of avg_launch_us that is the events' own, which rocprofv3's kernel durations do not contain
+                "event_pair_floor_us": floor_us,
+                "frac_net_of_event_floor": (fl / ((ms * 1e-3) - n * floor_us * 1e-6) / 1e12 / peak) if floor_us else None,
                 "all_gemm_launches": {"launches_per_step": n_all // args.steps, "achieved": fl_all / (ms_all * 1e-3) / 1e12,
                                       "gemm_ms_per_step": ms_all / args.steps,
                                       "note": "includes the text tower's 96 latency-bound launches on 40 rows (4 prompts x 10 tokens)"},
