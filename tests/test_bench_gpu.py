@@ -33,6 +33,8 @@ def test_single_gpu_line_has_roofline_and_cpu_baseline_fields():
     assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 2500.0
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and 0.05 < ro["frac"] < 1.0
     assert ro["traffic"] is None or ro["traffic"] > 1e6
+    # an empty event pair costs a few microseconds; net of it the fraction can only be higher
+    assert 0.0 < ro["event_pair_floor_us"] < ro["avg_launch_us"] and ro["frac"] < ro["frac_net_of_event_floor"] < 1.0
     # GLP_OT_SVLoRA.train(idx) over one client-round (32 steps of 32): the function SURVEY.md section 8(d) names
     t = j["trainer"]
     assert t["steps_per_round"] == 32
