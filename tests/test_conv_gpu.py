@@ -87,7 +87,9 @@ def test_stem_im2col(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
-@pytest.mark.parametrize("rows,C,relu,with_res", [(2 * 16 * 16, 64, True, False), (1000, 256, False, False), (3 * 49, 2048, True, True)])
+@pytest.mark.parametrize("rows,C,relu,with_res", [(2 * 16 * 16, 64, True, False), (1000, 256, False, False), (3 * 49, 2048, True, True),
+                                                   (6272, 256, True, True), (7168, 128, True, False), (7169, 64, True, True),
+                                                   (12000, 256, False, False)])
 def test_batchnorm_train_forward_backward_and_eval(ops, dt, rows, C, relu, with_res):
     x = rnd(rows, C, dt=dt, seed=7) * 1.5 + 0.3
     gamma, beta = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
