@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(const T* __restrict__ qkv
                                                        float* __restrict__ lse, int L, int heads, int causal,
                                                        int qsplit) {
     typedef typename AT<T>::frag_t frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int LP = NFP * 16;
     const int ts = tstride<T>(LP);
     char* Ks = smem;                                              // [LP][64] swizzled
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dq_kernel(const T* __rest
                                                                  const T* __restrict__ o_fwd,
                                                                  T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int LP = NFP * 16;
     const int ts = tstride<T>(LP);
     T* Kt = reinterpret_cast<T*>(smem);                           // [64][ts]
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_dkv_kernel(const T* __res
                                                                   const T* __restrict__ o_fwd,
                                                                   T* __restrict__ dqkv, int L, int heads, int causal) {
     typedef typename AT<T>::frag_t frag_t;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int LP = NFP * 16;
     const int ts = tstride<T>(LP);
     T* Qt = reinterpret_cast<T*>(smem);                           // [64][ts]
@@ -623,7 +623,7 @@ constexpr float A2_C = 0.125f * 1.44269504088896341f;
 template <int NF, bool SH, int P = 2>
 __global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu(a2_wpe<P>(), a2_wpe<P>()))) void attn2_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                float* __restrict__ lse, int L, int heads, int BH) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int CA = 8, CB = NF - CA;                           // key fragments of the two chunks
     static_assert(NF >= 9 && NF <= 14, "two chunks: 8 fragments + 1..6");
     // rows of a tile: 16 NF, or 8 fewer when L leaves the last 8 rows of the last fragment empty (L = 197: 200 rows,
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu
                                                                   const float* __restrict__ lse, const bf16_t* __restrict__ o_fwd,
                                                                   bf16_t* __restrict__ dqkv, float* __restrict__ delta, int L,
                                                                   int heads, int BH) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int R8 = SH ? NF * 16 - 8 : NF * 16, rmax = R8 - 1;
     char* Ks = smem;
     char* Vs = smem + R8 * 128;
@@ -864,7 +864,7 @@ template <int NF, bool SH, int P = 2>
 __global__ __launch_bounds__(a2_nw<P>() * 64) __attribute__((amdgpu_waves_per_eu(a2_wpe<P>(), a2_wpe<P>()))) void attn2_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    bf16_t* __restrict__ dqkv, int L, int heads, int BH) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     constexpr int R8 = SH ? NF * 16 - 8 : NF * 16, rmax = R8 - 1;
     char* Qs = smem;
     char* dOs = smem + R8 * 128;

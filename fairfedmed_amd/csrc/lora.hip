@@ -702,9 +702,15 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ffm_reduce_desc
 
 extern "C" int ffm_lora_down_blocks(int M, int K, int r, int dtype) {
     // dS partial rows a BACKWARD call (P given as [r][K] rows, t_fwd / ds_part set: the only calls that write them) produces
-    if (down_mfma_ok(M, K, r, dtype, 1)) return (M + LDM_ROWS - 1) / LDM_ROWS;
+    // An UPPER bound over both kernels: callers size ds_part once from their largest batch, and a smaller last batch
+    // (rows < 1024) falls back to the VALU kernel, which can write more partial rows per M than the matrix-core one.
     const int rows = (LD_WAVES / down_kq(K, dtype == FFM_BF16 ? 2 : 4)) * (64 / down_rp(r, dtype));
-    return (M + rows - 1) / rows;
+    const int valu = (M + rows - 1) / rows;
+    if (down_mfma_ok(M, K, r, dtype, 1)) {
+        const int mf = (M + LDM_ROWS - 1) / LDM_ROWS;
+        return mf > valu ? mf : valu;
+    }
+    return valu;
 }
 extern "C" int ffm_lora_grad_splits(int M) { return (M + LG_ROWS - 1) / LG_ROWS; }
 

@@ -273,6 +273,11 @@ class FairLoRAEngine:
         # prompts): bit-identical rows, 7.7x fewer of them, and far less interference with the vision chain.
         self.txt_len = min(t.context_length, max(cfg.eot) + 1)
         assert self.txt_len >= 1 + cfg.n_ctx
+        # the text-tail kernels index x[eot_row[p]] without a range check (csrc/text.hip): an EOT position outside the
+        # rows the tower keeps would read another prompt's row
+        if not all(0 <= int(e) < self.txt_len for e in cfg.eot):
+            raise ValueError(f"EOT positions {list(cfg.eot)} must lie inside the {self.txt_len} text rows that are kept "
+                             f"(context_length {t.context_length})")
         # ... and ALWAYS in float32, also in the bf16 throughput mode: the two classes' prompts differ in a few tokens, so
         # the logit difference l1 - l0 = e^ls <f, t1 - t0> rides on the small difference of two nearly equal text features,
         # and 2^-9 roundings of the text activations AND of the text weights land on it many times amplified.  Measured on

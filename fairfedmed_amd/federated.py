@@ -83,6 +83,25 @@ def average_weights_ema(w_g: Dict[str, Tensor], w: Dict[int, Dict[str, Tensor]],
     return out
 
 
+def average_weights(w, idxs_users: Sequence[int], datanumber_client: Sequence[int], datanumber_client_by_attr=None,
+                    islist: bool = False):
+    """Plain weighted FedAvg without the EMA (utils/fed_utils.py:6-40): entries weighted by n_k / sum n, row g of every
+    per-group ``lora_S`` [G, r] block by n_{k,g} / sum_k n_{k,g}.  ``islist``: ``w[u]`` is one tensor per client (the
+    reference's prompt-only trainers pass ``ctx`` this way) instead of a state_dict.  Equal to ``average_weights_ema``
+    at ``epoch = 0`` without ``shared_half_s`` - kept under the reference's name and signature."""
+    idxs_users = [int(u) for u in idxs_users]
+    total = sum(datanumber_client[u] for u in idxs_users)
+    if islist:
+        acc = None
+        for u in idxs_users:
+            term = w[u] * (datanumber_client[u] / total)
+            acc = term if acc is None else acc + term
+        return acc
+    w_g = {k: torch.zeros_like(v) for k, v in w[idxs_users[0]].items()}
+    return average_weights_ema(w_g, w, idxs_users, datanumber_client, datanumber_client_by_attr, 0, 1,
+                               shared_half_s=False)
+
+
 def select_clients(epoch: int, args: FedArgs, dataset_users: int) -> List[int]:
     """federated_main.py:606-613: an explicit list wins; round 0 trains every client; later rounds draw
     max(int(frac * num_users), 1) of them without replacement from numpy's global generator."""

@@ -427,6 +427,27 @@ def golden_fedavg(FU, out, meta):
                                "n_client": n_client, "by_attr": by_attr}
 
 
+FEDAVG_PLAIN_KEYS = {"a.lora_S.weight": (3, 8), "a.lora_A.weight": (16, 8), "prompt_learner.ctx": (2, 4, 8),
+                     "frozen.weight": (5, 5), "b.lora_S.weight": (3, 8)}
+
+
+def golden_fedavg_plain(FU):
+    """utils/fed_utils.py:6-40 (``average_weights``, no EMA): state_dict form with and without the per-attribute
+    counts, and the ``islist`` form on one tensor per client -> tests/golden/fedavg_plain.npz"""
+    out = {}
+    n_client = [100, 50, 25]
+    by_attr = [[50, 30, 20], [10, 20, 20], [5, 5, 15]]
+    for case, (idxs, attr) in {"all_attr": ([0, 1, 2], True), "two_attr": ([2, 0], True), "all_noattr": ([0, 1, 2], False)}.items():
+        w = {u: {k: rng_tensor(f"fedp.{case}.{u}.{k}", s) for k, s in FEDAVG_PLAIN_KEYS.items()} for u in range(3)}
+        res = FU.average_weights(w, idxs, n_client, by_attr if attr else None)
+        for k in FEDAVG_PLAIN_KEYS:
+            out[f"{case}.{k}"] = res[k].numpy()
+    wl = {u: rng_tensor(f"fedp.list.{u}", (2, 4, 8)) for u in range(3)}
+    out["list"] = FU.average_weights(wl, [1, 2], n_client, islist=True).numpy()
+    np.savez_compressed(os.path.join(HERE, "fedavg_plain.npz"), **out)
+    print("fedavg_plain.npz:", sorted(out)[:4], "...")
+
+
 def golden_auc(compute_auc, out, meta):
     g = synth._rng("auc", 7)
     cases = {}
@@ -504,6 +525,7 @@ def main():
     ap.add_argument("--only-dataset", action="store_true", help="regenerate tests/golden/dataset.json only")
     ap.add_argument("--only-svlora", action="store_true", help="regenerate tests/golden/svlora.npz only")
     ap.add_argument("--only-ot", action="store_true", help="regenerate tests/golden/ot.npz (Sinkhorn / COT heads) only")
+    ap.add_argument("--only-fedavg-plain", action="store_true", help="regenerate tests/golden/fedavg_plain.npz only")
     ap.add_argument("--vitb", action="store_true", help="also generate the ViT-B/16 fixtures (minutes)")
     ap.add_argument("--time-ref", action="store_true", help="time the reference CPU step at bs=32")
     args = ap.parse_args()
@@ -519,9 +541,13 @@ def main():
     if args.only_ot:
         golden_ot(M, CLIP)
         return
+    if args.only_fedavg_plain:
+        golden_fedavg_plain(FU)
+        return
     golden_dataset()
     golden_svlora()
     golden_ot(M, CLIP)
+    golden_fedavg_plain(FU)
 
     out, meta = {}, {"torch": torch.__version__, "numpy": np.__version__}
     golden_layers(M, out)

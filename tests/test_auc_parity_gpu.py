@@ -146,11 +146,14 @@ def test_auc_after_equal_rounds(tower, prec, tol):
         finally:
             O.STORE = None
         ctl_auc = [a / 100.0 for a in ctl["auc"]]
-        extra = [abs(c - r) for c, r in zip(ctl_auc, ref_auc)]
+        # capped: a control run that wandered far from the fp32 oracle must not make the bound below vacuous
+        extra = [min(abs(c - r), 0.003) for c, r in zip(ctl_auc, ref_auc)]
         print(tower, "oracle with bf16-stored activations", [round(a, 5) for a in ctl_auc], " its own distance", [round(e, 5) for e in extra])
     for r in range(rounds):
         assert abs(hip_auc[r] - ref_auc[r]) <= tol + extra[r], (r, hip_auc, ref_auc, extra)
-        assert abs(hip["acc"][r] - ref["acc"][r]) <= (1e-9 if prec == "fp32" and tower == "vit_tiny" else 5.0)
+        # accuracy (percent, mean over the clients): fp32 may differ by one test sample of one client, 16-bit modes by 5 points
+        one_sample = 100.0 / (test_b * test_bs)
+        assert abs(hip["acc"][r] - ref["acc"][r]) <= (1e-9 if prec == "fp32" and tower == "vit_tiny" else one_sample if prec == "fp32" else 5.0)
     if prec == "fp32" and tower == "vit_tiny":
         for k, v in ref["global_weights"].items():
             a, b = hip["global_weights"][k].double().cpu(), v.double()

@@ -37,6 +37,22 @@ def test_average_weights_ema_vs_reference(unit, meta, case):
         np.testing.assert_allclose(res[k].numpy(), unit[f"fed.{case}.{k}"], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("case,idxs,attr", [("all_attr", [0, 1, 2], True), ("two_attr", [2, 0], True), ("all_noattr", [0, 1, 2], False)])
+def test_average_weights_plain_vs_reference(golden_dir, case, idxs, attr):
+    """utils/fed_utils.py:6-40 under its own name: fixtures from the imported reference (make_golden.py --only-fedavg-plain)"""
+    from tests.golden.make_golden import rng_tensor, FEDAVG_PLAIN_KEYS
+    gold = np.load(os.path.join(golden_dir, "fedavg_plain.npz"))
+    n_client, by_attr = [100, 50, 25], [[50, 30, 20], [10, 20, 20], [5, 5, 15]]
+    w = {u: {k: rng_tensor(f"fedp.{case}.{u}.{k}", s) for k, s in FEDAVG_PLAIN_KEYS.items()} for u in range(3)}
+    res = F.average_weights(w, idxs, n_client, by_attr if attr else None)
+    assert list(res) == list(FEDAVG_PLAIN_KEYS)
+    for k in FEDAVG_PLAIN_KEYS:
+        np.testing.assert_allclose(res[k].numpy(), gold[f"{case}.{k}"], rtol=1e-6, atol=1e-7)
+    if case == "two_attr":
+        wl = {u: rng_tensor(f"fedp.list.{u}", (2, 4, 8)) for u in range(3)}
+        np.testing.assert_allclose(F.average_weights(wl, [1, 2], n_client, islist=True).numpy(), gold["list"], rtol=1e-6, atol=1e-7)
+
+
 def test_select_clients_matches_the_reference_rule():
     args = F.FedArgs(num_users=8, frac=0.5)
     assert F.select_clients(0, args, 8) == list(range(8))            # round 0: everybody
