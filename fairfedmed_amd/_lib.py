@@ -15,10 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FFM_LIB_PATH: a diagnostic build of the same library (tools/panel_stamps.py); there is still no fallback
 LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm_hip.so")
 
-F32, BF16, F32_X3 = 0, 1, 2
+F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the reference's PREC="fp16")
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
 EPI_ROWSTATS, EPI_LNIN = 128, 256
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "ffm_ot_head_fwd": [_vp] * 10 + [_i32] * 6 + [_f32, _f32, _i32, _f32, _i32, _vp],
     "ffm_ot_head_bwd": [_vp] * 8 + [_i32] * 6 + [_vp],
     "ffm_expand_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "ffm_scale_check": [_vp, _f32, _i64, _vp, _vp],
     "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
@@ -150,7 +151,15 @@ def dtype_code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def is16(dt: torch.dtype) -> bool:
+    """The two 16-bit storage modes (bfloat16: the throughput mode BASELINE.json names; float16: the reference's own
+    PREC="fp16") run the same kernels - every `dtype == torch.bfloat16` decision of the engines is really `is16(dtype)`."""
+    return dt in (torch.bfloat16, torch.float16)
 
 
 def ptr(t: Optional[torch.Tensor]):

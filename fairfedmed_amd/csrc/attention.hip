@@ -1008,11 +1008,15 @@ int run_bwd2(const void* qkv, const void* out, const void* dout, const float* ls
                             : run_bwd2s<NF, false>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);
 }
 
-// FFM_ATTN=v1: always the first-generation kernels (A/B runs)
-inline bool attn_v1_forced() {
-    static const bool v1 = getenv("FFM_ATTN") && getenv("FFM_ATTN")[0] == 'v' && getenv("FFM_ATTN")[1] == '1';
-    return v1;
+// FFM_ATTN=v1: always the first-generation kernels; FFM_ATTN=v2: the second generation where it applies (A/B runs).
+// Default: the third generation (attention3.hip: fat waves on 32x32x16 MFMAs) for 65..256 unmasked tokens in 16-bit storage.
+inline int attn_gen_forced() {
+    static const int g = (getenv("FFM_ATTN") && getenv("FFM_ATTN")[0] == 'v' && getenv("FFM_ATTN")[1] >= '1' && getenv("FFM_ATTN")[1] <= '3')
+                             ? getenv("FFM_ATTN")[1] - '0' : 0;
+    return g;
 }
+inline bool attn_v1_forced() { return attn_gen_forced() == 1; }
+inline bool attn3_allowed() { return attn_gen_forced() == 0 || attn_gen_forced() == 3; }
 
 inline int pick_split(int bh, int NF) {
     // aim for >= ~3 blocks per CU while keeping >= 4 tiles (one per wave) per block
@@ -1093,6 +1097,11 @@ int dispatch_bwd(int nfp, const void* qkv, const void* out, const void* dout, co
 
 }  // namespace
 
+// attention3.hip
+int ffm_attn3_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int dtype, hipStream_t s);
+int ffm_attn3_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
+                  int dtype, hipStream_t s);
+
 extern "C" int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int causal,
                                  int dtype, void* stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || heads <= 0) return FFM_EINVAL;
@@ -1100,6 +1109,10 @@ extern "C" int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return FFM_EINVAL;
     const int nfp = (((L + 15) / 16) + 1) & ~1;
     hipStream_t s = (hipStream_t)stream;
+    if ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed()) {
+        const int e = ffm_attn3_fwd(qkv, out, lse, B, L, heads, dtype, s);
+        if (e != FFM_EUNSUP) return e;
+    }
     if (dtype == FFM_BF16 && !causal && !attn_v1_forced()) {
         switch ((L + 15) / 16) {                        // the vision tower's shapes: attn2_* (half a head per block)
             case 9: return run_fwd2<9>(qkv, out, lse, B, L, heads, s);
@@ -1122,6 +1135,10 @@ extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* d
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return FFM_EINVAL;
     const int nfp = (((L + 15) / 16) + 1) & ~1;
     hipStream_t s = (hipStream_t)stream;
+    if ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed()) {
+        const int e = ffm_attn3_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, dtype, s);
+        if (e != FFM_EUNSUP) return e;
+    }
     if (dtype == FFM_BF16 && !causal && !attn_v1_forced()) {
         switch ((L + 15) / 16) {
             case 9: return run_bwd2<9>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);

@@ -1,0 +1,776 @@
+// Third-generation attention kernels for the vision tower (16-bit storage, no mask, head_dim 64, 65..256 tokens):
+// "fat waves" on v_mfma_f32_32x32x16.
+//
+// What the second generation (attention.hip, attn2_*) spent its time on (profiles/r03_sq_counters.json: MFMA pipes
+// 9-11 % busy, half of all wave cycles parked): a wave owned ONE 16-token tile, so every 16 x 32 operand fragment it
+// read from LDS fed a single 16x16x32 MFMA, seven 80-register waves per block chased each other through the same
+// dependent chain (LDS read -> S -> exp -> pack -> transposed read -> PV), and the whole K / V tile had to land
+// before the first MFMA.  Here:
+//   * a wave owns a 32-token tile (32 queries in the forward / dQ kernels, 32 keys in the dK/dV kernel) and walks the
+//     other index in 32-token tiles with v_mfma_f32_32x32x16: each 1 KiB LDS operand read feeds twice the FLOPs, a
+//     score tile is 16 registers per lane, and the per-element VALU work (scale, exp, pack) is issued beside MFMAs
+//     that hold the vector issue port for 8 of their 32 cycles instead of 8 of 16;
+//   * the first product keeps the OWNED index on the MFMA column (= the lane) and the swept index on the rows
+//     (= the registers): S^T = K Q^T in the forward / dQ kernels, S = Q K^T in the dK/dV kernel.  The accumulator
+//     is then already the B operand of the second product (cdna_hip_programming.md, "An accumulator tile as the
+//     next MFMA's operand"): O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS - nothing crosses LDS
+//     or lanes, and row statistics (max, sum, lse, delta) are per-lane scalars in the forward / dQ kernels;
+//   * lse and delta enter as the INITIAL accumulators of S and dP (p = exp2(c (s - 8 lse)), dS = p (dP - delta)):
+//     one multiply and one exp per element for p, one multiply for dS;
+//   * K / V (Q / dO) tiles land row-major in LDS by LDS-DMA in the 8-row x 32-column sub-tile image that serves the
+//     ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads without bank conflicts (T10, image (a));
+//     the DMA is issued in two halves (first four tiles of both operands, then the rest) behind counted
+//     s_waitcnt vmcnt(N) + raw s_barrier, so the first tiles' MFMAs run under the second half's landing;
+//   * half a head per block (ceil(NT/2) waves, e.g. 4 + 3 tiles for 197 tokens), block ids b and b + 8 are the two
+//     halves of one (batch, head) pair (one XCD under round-robin placement: the second fetch of the tiles is an L2
+//     hit - speed only); 768 blocks at 32 images = three per CU, <= 168 registers.
+// Rows >= L of a tile are copies of row L - 1 (the DMA source is clamped): finite, and always multiplied by an
+// exactly zero probability.  Rows beyond the tile's last 8-row piece are never read: the last tile clamps its rows.
+//
+// Replaces nn.MultiheadAttention's core (clip/model.py:350-352) and its autograd on the vision tower.
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int HD = 64;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((address_space(3))) char lds_char;
+
+constexpr float A3_C = 0.125f * 1.44269504088896341f;     // log2(e) / sqrt(64)
+// Diagnostic builds only (tools/attn_phases.sh): -DFFM_ATTN3_ABL=1 the kernels return once their tiles have landed,
+// =2 they issue no tile DMA and compute on whatever LDS holds (results are garbage): prices the two phases.
+#ifndef FFM_ATTN3_ABL
+#define FFM_ATTN3_ABL 0
+#endif
+// -DFFM_ATTN3_STAMPS: s_memtime stamps at the phase boundaries of every wave (tools/attn_stamps.py reads them through
+// ffm_attn3_read_stamps); the stamps fence the scheduler, so read their SHARES, never this build's run time.
+#ifdef FFM_ATTN3_STAMPS
+constexpr int A3_NSTAMP = 16;
+__device__ unsigned long long a3_stamps[4096 * A3_NSTAMP];
+#define A3_STAMP(i)                                                                                      \
+    do {                                                                                                 \
+        unsigned long long t__;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((threadIdx.x & 63) == 0) a3_stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095) * A3_NSTAMP + (i)] = t__; \
+    } while (0)
+#define A3_RSTAMP(i)                                                                                     \
+    do {                                                                                                 \
+        unsigned long long t__;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if ((threadIdx.x & 63) == 0) a3_stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095) * A3_NSTAMP + (i)] = t__; \
+    } while (0)
+#else
+#define A3_STAMP(i) do { } while (0)
+#define A3_RSTAMP(i) do { } while (0)
+#endif
+
+template <typename T> struct A3;
+template <> struct A3<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct A3<f16_t> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// LDS image of a [rows][64] 16-bit tile: 8-row x 32-column sub-tiles of 512 B (cdna_hip_programming.md T10 (a)).
+// Byte offset of 16-byte chunk ch (0..7) of row `row`:
+__device__ __forceinline__ int img_off(int row, int ch) {
+    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+// One DMA piece = 8 rows x 128 B = 1 KiB, written lane-linearly: lane -> (sub-tile lane >> 5, row (lane >> 2) & 7, slot
+// lane & 3); the image's XOR goes onto the SOURCE chunk.  Source rows are clamped to L - 1.
+// The LDS-DMA is issued from inline asm (M0 = LDS destination, saved and restored in the same statement:
+// cdna_hip_programming.md 5.7): hipcc must not see it, or it drains vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 of every phase (measured in the .s), which would serialise the two DMA halves with the compute.
+// Every wait for these pieces is a hand-counted s_waitcnt vmcnt(N) followed by a raw s_barrier.
+template <typename T>
+__device__ __forceinline__ void dma_piece(const T* __restrict__ src, int ld, int L, int pc, char* tile, int lane) {
+    if constexpr ((FFM_ATTN3_ABL & 2) != 0) return;
+    int row = pc * 8 + ((lane >> 2) & 7);
+    const int ch = ((lane >> 5) << 2) + ((lane & 3) ^ ((row >> 2) & 3));
+    row = row < L ? row : L - 1;
+    const T* g = src + (size_t)row * ld + ch * 8;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char*)tile + (uint32_t)pc * 1024u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+}
+
+// A operand of a 32x32x16 MFMA from tile rows (row = 32 t + (lane & 31), k = 16 ks + 8 (lane >> 5) + 0..7):
+//   address = tile + 4096 t + 512 (ks >> 1) + (ra ^ (32 (ks & 1))),   ra = img_off(lane & 31, lane >> 5)
+__device__ __forceinline__ int row_lane_off(int lane) { return img_off(lane & 31, lane >> 5); }
+template <typename T>
+__device__ __forceinline__ typename A3<T>::frag row_frag(const char* tile, int ra, int t, int ks) {
+    return *reinterpret_cast<const typename A3<T>::frag*>(tile + ((ra ^ (32 * (ks & 1))) + 4096 * t + 512 * (ks >> 1)));
+}
+template <typename T>
+__device__ __forceinline__ typename A3<T>::frag row_frag_clamped(const char* tile, int lane, int t, int ks, int rmax) {
+    int row = 32 * t + (lane & 31);
+    row = row < rmax ? row : rmax;
+    return *reinterpret_cast<const typename A3<T>::frag*>(tile + img_off(row, 2 * ks + (lane >> 5)));
+}
+
+// A operand X^T [32 columns of X (d = 32 dt + (lane & 31))][16 rows of X] for the k-step s of token tile t, with the k
+// order of an accumulator used as the B operand: element j of lane half h is token 32 t + 16 s + 8 (j >> 2) + 4 h + (j & 3).
+// Two transposed reads (T10): lane 4q + p of a 16-lane group G addresses row q, columns 4p .. 4p + 3 of the group's
+// 4 x 16 block (rows 32 t + 16 s + 4 (G >> 1) [+ 8], columns 32 dt + 16 (G & 1)):
+//   address = tile + 4096 t + 2048 s + 512 dt + ta            (tokens + 0..3)
+//           = tile + 4096 t + 2048 s + 512 dt + 1024 + (ta ^ 32)   (tokens + 8..11: next 8-row group, swizzle ^ 2)
+__device__ __forceinline__ int tr_lane_off(int lane) {
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = G >> 1;
+    return 64 * (4 * h + q) + 16 * ((2 * (G & 1) + (p >> 1)) ^ h) + 8 * (p & 1);
+}
+template <typename T>
+__device__ __forceinline__ typename A3<T>::frag tr_frag(const char* tile, int ta, int t, int s, int dt) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    const int o = 4096 * t + 2048 * s + 512 * dt;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(tile + (ta + o)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(tile + ((ta ^ 32) + o + 1024)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename A3<T>::frag, v);
+}
+template <typename T>
+__device__ __forceinline__ typename A3<T>::frag tr_frag_clamped(const char* tile, int lane, int t, int s, int dt, int rmax) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = G >> 1;
+    int r0 = 32 * t + 16 * s + 4 * h + q, r1 = r0 + 8;
+    r0 = r0 < rmax ? r0 : rmax;
+    r1 = r1 < rmax ? r1 : rmax;
+    const int ch = 4 * dt + 2 * (G & 1) + (p >> 1), b = 8 * (p & 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(tile + img_off(r0, ch) + b));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(uintptr_t)(tile + img_off(r1, ch) + b));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename A3<T>::frag, v);
+}
+
+// registers 8 s .. 8 s + 7 of a 32 x 32 accumulator -> the B operand of k-step s
+template <typename T>
+__device__ __forceinline__ typename A3<T>::frag pack8(const f32x16& a, int s) {
+    typename A3<T>::frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (T)a[8 * s + j];
+    return f;
+}
+
+// the other 32-lane half's value (rows of a 32 x 32 accumulator are split 4 h + ... over the two halves)
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// token row of register r of a 32 x 32 accumulator for lane half h
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }   // + 4 h
+
+// (b, h) pair and half of a block id: ids b and b + 8 are the two halves of one pair
+__device__ __forceinline__ void unit_of_block(int bid, int& bh, int& part) {
+    bh = (bid >> 4) * 8 + (bid & 7);
+    part = (bid >> 3) & 1;
+}
+
+// 16-byte operand fragments straight from global memory, hidden from hipcc's s_waitcnt bookkeeping: beside LDS-DMA in
+// flight it would wait vmcnt(0) at their first use (cdna_hip_programming.md section 5, "Pipelining across barriers").
+// The caller waits with wait_frags<N>() (which names every destination) before the first use.
+template <int OFF>
+__device__ __forceinline__ void asm_load16(u32x4& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void asm_load4(float& dst, const void* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_frags(u32x4 (&a)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void block_sync() {
+    // raw barrier: __syncthreads() would drain the LDS-DMA still in flight (vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// a 32-row x 64-column tile of the (normalised / scaled) transposed accumulators -> rows of a token-major matrix.
+// Register group i of d-tile dt holds columns 32 dt + 8 i + 4 h + 0..3 of row (lane & 31): pairs of groups are swapped
+// between the lane halves (v_permlane32_swap, T21) so that every lane stores 16 contiguous bytes.
+template <typename T>
+__device__ __forceinline__ void store_rows(T* __restrict__ row_ptr, const f32x16 (&o)[2], float scale, int lane) {
+    const int hb = (lane >> 5) * 16;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            t4 a = {(T)(o[dt][4 * i] * scale), (T)(o[dt][4 * i + 1] * scale), (T)(o[dt][4 * i + 2] * scale), (T)(o[dt][4 * i + 3] * scale)};
+            t4 b = {(T)(o[dt][4 * i + 4] * scale), (T)(o[dt][4 * i + 5] * scale), (T)(o[dt][4 * i + 6] * scale), (T)(o[dt][4 * i + 7] * scale)};
+            u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+            const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(row_ptr) + 64 * dt + 16 * i + hb) = v;
+        }
+}
+
+template <int NT> struct Geo {
+    static constexpr int NW = (NT + 1) / 2;                     // waves per block = 32-token tiles of the larger half
+    static constexpr int PPW = (4 * NT + NW - 1) / NW;          // DMA pieces per wave and tile (the waves that run out repeat their last)
+    static constexpr int CA = NT < 4 ? NT : 4, CB = NT - CA;    // swept tiles of the two DMA halves
+    static constexpr int IA = (4 * CA + NW - 1) / NW;           // piece rounds that cover the first half
+};
+
+// ---------------------------------------------------------------------------
+// forward: a wave owns 32 queries; S^T = K Q^T per 32-key tile, running maximum over the two DMA halves, O^T = V^T P^T
+// ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse, int L, int heads, int BH) {
+    typedef typename A3<T>::frag frag;
+    typedef Geo<NT> GE;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int R8 = (L + 7) & ~7, NP = R8 >> 3, rmax = R8 - 1;
+    char* Ks = smem;                                            // [R8][128 B]; reads past it land in Vs
+    char* Vs = smem + R8 * 128;
+    int bh, part;
+    unit_of_block(blockIdx.x, bh, part);
+    if (bh >= BH) return;
+    const int b = bh / heads, hd = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + hd * HD;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = (NT + 1) / 2;
+    const int qt = part ? n0 + wave : wave;
+    const bool active = part ? wave < NT - n0 : wave < n0;
+    const int q = qt * 32 + r;
+
+    A3_RSTAMP(14);
+    A3_STAMP(0);
+    u32x4 qv[4];
+    {
+        const int qr = active && q < L ? q : L - 1;
+        const T* qp = base + (size_t)qr * ld + 8 * h;
+        asm_load16<0>(qv[0], qp);
+        asm_load16<32>(qv[1], qp);
+        asm_load16<64>(qv[2], qp);
+        asm_load16<96>(qv[3], qp);
+    }
+    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+#pragma unroll
+    for (int i = 0; i < GE::IA; ++i) dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
+#pragma unroll
+    for (int i = 0; i < GE::IA; ++i) dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
+#pragma unroll
+    for (int i = GE::IA; i < GE::PPW; ++i) dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
+#pragma unroll
+    for (int i = GE::IA; i < GE::PPW; ++i) dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
+    constexpr int REST = GE::PPW - GE::IA;
+    if constexpr ((FFM_ATTN3_ABL & 1) != 0) { wait_frags<0>(qv); return; }
+    A3_STAMP(1);
+
+    const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
+    const bool skip_last_step = L - 32 * (NT - 1) <= 16;        // the last tile's second k-step holds no key < L
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    frag qf[4];
+
+    auto chunk = [&](auto F0_, auto CF_, auto FIRST_) {
+        constexpr int F0 = decltype(F0_)::value, CF = decltype(CF_)::value;
+        constexpr bool FIRST = decltype(FIRST_)::value;
+        // K tiles of this half have landed (all waves' pieces: barrier)
+        if constexpr (FIRST) {
+            wait_frags<GE::IA + 2 * REST>(qv);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(frag, qv[ks]);
+        } else {
+            wait_vm<REST>();
+        }
+        block_sync();
+        A3_STAMP(FIRST ? 2 : 7);
+        if (active) {
+            f32x16 s[CF];
+            float mx = m;
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int t = F0 + f;
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = A3<T>::mma(row_frag<T>(Ks, ra, t, ks), qf[ks], acc);
+                if (F0 + f == NT - 1) {                         // only the last key tile can straddle L
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (32 * (NT - 1) + acc_row(e) + 4 * h >= L) acc[e] = -INFINITY;
+                }
+                s[f] = acc;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+            }
+            A3_STAMP(FIRST ? 3 : 8);
+            mx = fmaxf(mx, xhalf(mx));
+            const float mc = mx * A3_C;
+            if constexpr (!FIRST) {
+                // running maximum: everything accumulated so far is rescaled by 2^(c (m - mx))
+                const float alpha = __builtin_amdgcn_exp2f((m - mx) * A3_C);
+                l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            }
+            m = mx;
+#pragma unroll
+            for (int f = 0; f < CF; ++f)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[f][e], A3_C, -mc));
+                    s[f][e] = p;
+                    l += p;
+                }
+            A3_STAMP(FIRST ? 4 : 9);
+            // V tiles of this half have landed
+            if constexpr (FIRST) wait_vm<2 * REST>(); else wait_vm<0>();
+            block_sync();
+            A3_STAMP(FIRST ? 5 : 10);
+#pragma unroll
+            for (int f = 0; f < CF; ++f) {
+                const int t = F0 + f;
+                if (F0 + f == NT - 1) {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        if (st == 1 && skip_last_step) break;
+                        const frag pf = pack8<T>(s[f], st);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag_clamped<T>(Vs, lane, t, st, dt, rmax), pf, o[dt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const frag pf = pack8<T>(s[f], st);
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag<T>(Vs, ta, t, st, dt), pf, o[dt]);
+                    }
+                }
+            }
+            A3_STAMP(FIRST ? 6 : 11);
+        } else {
+            if constexpr (FIRST) wait_vm<2 * REST>(); else wait_vm<0>();
+            block_sync();
+        }
+    };
+    chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, GE::CA>{}, std::true_type{});
+    if constexpr (GE::CB > 0) chunk(std::integral_constant<int, GE::CA>{}, std::integral_constant<int, GE::CB>{}, std::false_type{});
+    if (!active) return;
+
+    l += xhalf(l);
+    if (q < L) {
+        store_rows<T>(out + ((size_t)b * L + q) * E + hd * HD, o, 1.0f / l, lane);
+        if (h == 0 && lse) lse[((size_t)b * heads + hd) * L + q] = m * 0.125f + __logf(l);
+    }
+    A3_STAMP(12);
+    A3_RSTAMP(15);
+}
+
+// ---------------------------------------------------------------------------
+// dQ (and delta = rowsum(dO * O), which the dK/dV kernel reads back): a wave owns 32 queries.
+// S^T = K Q^T - 8 lse and dP^T = V dO^T - delta per 32-key tile, dS^T = exp2(c S^T) dP^T, dQ^T += K^T dS^T.
+// ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
+                         const T* __restrict__ o_fwd, T* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, int BH) {
+    typedef typename A3<T>::frag frag;
+    typedef Geo<NT> GE;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int R8 = (L + 7) & ~7, NP = R8 >> 3, rmax = R8 - 1;
+    char* Ks = smem;
+    char* Vs = smem + R8 * 128;
+    int bh, part;
+    unit_of_block(blockIdx.x, bh, part);
+    if (bh >= BH) return;
+    const int b = bh / heads, hd = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + hd * HD;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = (NT + 1) / 2;
+    const int qt = part ? n0 + wave : wave;
+    const bool active = part ? wave < NT - n0 : wave < n0;
+    const int q = qt * 32 + r;
+    const int qr = active && q < L ? q : L - 1;
+
+    u32x4 qv[4], dov[4], ov[4];
+    float lq;
+    {
+        const T* qp = base + (size_t)qr * ld + 8 * h;
+        const T* dp = d_o + ((size_t)b * L + qr) * E + hd * HD + 8 * h;
+        const T* op = o_fwd + ((size_t)b * L + qr) * E + hd * HD + 8 * h;
+        asm_load16<0>(qv[0], qp); asm_load16<32>(qv[1], qp); asm_load16<64>(qv[2], qp); asm_load16<96>(qv[3], qp);
+        asm_load16<0>(dov[0], dp); asm_load16<32>(dov[1], dp); asm_load16<64>(dov[2], dp); asm_load16<96>(dov[3], dp);
+        asm_load16<0>(ov[0], op); asm_load16<32>(ov[1], op); asm_load16<64>(ov[2], op); asm_load16<96>(ov[3], op);
+        asm_load4(lq, lse + ((size_t)b * heads + hd) * L + qr);
+    }
+    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+#pragma unroll
+    for (int i = 0; i < GE::IA; ++i) {
+        dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
+        dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
+    }
+#pragma unroll
+    for (int i = GE::IA; i < GE::PPW; ++i) {
+        dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
+        dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
+    }
+    constexpr int REST = GE::PPW - GE::IA;
+    const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
+    const bool skip_last_step = L - 32 * (NT - 1) <= 16;
+
+    // the 13 fragment loads are older than every DMA piece: they are back when the first half's pieces are
+    asm volatile("s_waitcnt vmcnt(%13)"
+                 : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(dov[0]), "+v"(dov[1]), "+v"(dov[2]), "+v"(dov[3]),
+                   "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(lq)
+                 : "n"((FFM_ATTN3_ABL & 1) ? 0 : 2 * REST)
+                 : "memory");
+    if constexpr ((FFM_ATTN3_ABL & 1) != 0) return;
+    frag qf[4], dof[4];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = __builtin_bit_cast(frag, qv[ks]);
+        dof[ks] = __builtin_bit_cast(frag, dov[ks]);
+        const frag of = __builtin_bit_cast(frag, ov[ks]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)of[e] * (float)dof[ks][e];
+    }
+    dl += xhalf(dl);
+    if (active && h == 0 && q < L) delta[((size_t)b * heads + hd) * L + q] = dl;
+    const float s0 = -8.0f * lq, p0 = -dl;
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+
+    auto tile = [&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        constexpr bool LAST = t == NT - 1;
+        f32x16 sa, pa;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sa[e] = s0; pa[e] = p0; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sa = A3<T>::mma(row_frag<T>(Ks, ra, t, ks), qf[ks], sa);           // (the last tile reads on into Vs: masked)
+            if constexpr (LAST) pa = A3<T>::mma(row_frag_clamped<T>(Vs, lane, t, ks, rmax), dof[ks], pa);
+            else pa = A3<T>::mma(row_frag<T>(Vs, ra, t, ks), dof[ks], pa);
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (32 * (NT - 1) + acc_row(e) + 4 * h >= L) sa[e] = -INFINITY;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sa[e] = __builtin_amdgcn_exp2f(sa[e] * A3_C) * pa[e];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (LAST && st == 1 && skip_last_step) break;
+            const frag df = pack8<T>(sa, st);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                if constexpr (LAST) dq[dt] = A3<T>::mma(tr_frag_clamped<T>(Ks, lane, t, st, dt, rmax), df, dq[dt]);
+                else dq[dt] = A3<T>::mma(tr_frag<T>(Ks, ta, t, st, dt), df, dq[dt]);
+            }
+        }
+    };
+    block_sync();                                                               // first half of K and V landed
+    if (active) {
+        if constexpr (GE::CA > 0) tile(std::integral_constant<int, 0>{});
+        if constexpr (GE::CA > 1) tile(std::integral_constant<int, 1>{});
+        if constexpr (GE::CA > 2) tile(std::integral_constant<int, 2>{});
+        if constexpr (GE::CA > 3) tile(std::integral_constant<int, 3>{});
+    }
+    if constexpr (GE::CB > 0) {
+        wait_vm<0>();
+        block_sync();
+        if (active) {
+            if constexpr (GE::CB > 0) tile(std::integral_constant<int, GE::CA + 0>{});
+            if constexpr (GE::CB > 1) tile(std::integral_constant<int, GE::CA + 1>{});
+            if constexpr (GE::CB > 2) tile(std::integral_constant<int, GE::CA + 2>{});
+            if constexpr (GE::CB > 3) tile(std::integral_constant<int, GE::CA + 3>{});
+        }
+    }
+    if (active && q < L) store_rows<T>(dqkv + ((size_t)b * L + q) * ld + hd * HD, dq, 0.125f, lane);
+}
+
+// ---------------------------------------------------------------------------
+// dK / dV: a wave owns 32 keys and sweeps the queries in 32-row tiles, the key on the MFMA column (= lane):
+// S = Q K^T - 8 lse[q], dP = dO V^T - delta[q] (row constants as the initial accumulators, from LDS), P = exp2(c S),
+// dS = P dP; dV^T += dO^T P and dK^T += Q^T dS take P / dS straight from the accumulators and the transposed Q / dO
+// operands from the same row-major tiles.
+// ---------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
+                          const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH) {
+    typedef typename A3<T>::frag frag;
+    typedef Geo<NT> GE;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int R8 = (L + 7) & ~7, NP = R8 >> 3, rmax = R8 - 1;
+    char* Qs = smem;
+    char* dOs = smem + R8 * 128;
+    float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);              // [32 NT]: -8 lse (-inf beyond L)
+    float* del_s = lse_s + 32 * NT;                                             // [32 NT]: -delta (0 beyond L)
+    int bh, part;
+    unit_of_block(blockIdx.x, bh, part);
+    if (bh >= BH) return;
+    const int b = bh / heads, hd = bh % heads;
+    const int E = heads * HD, ld = 3 * E;
+    const T* base = qkv + (size_t)b * L * ld + hd * HD;
+    const T* dob = d_o + (size_t)b * L * E + hd * HD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = (NT + 1) / 2;
+    const int kt = part ? n0 + wave : wave;
+    const bool active = part ? wave < NT - n0 : wave < n0;
+    const int key = kt * 32 + r;
+
+    A3_RSTAMP(14);
+    A3_STAMP(0);
+    u32x4 kv[4], vv[4];
+    float lv[2], dv_[2];
+    constexpr int NTH = 64 * GE::NW, NLD = (32 * NT + NTH - 1) / NTH;           // lse / delta values per thread (<= 2)
+    static_assert(NLD <= 2, "row constants: at most two per thread");
+    {
+        const int kr = active && key < L ? key : L - 1;
+        const T* kp = base + E + (size_t)kr * ld + 8 * h;
+        const T* vp = base + 2 * E + (size_t)kr * ld + 8 * h;
+        asm_load16<0>(kv[0], kp); asm_load16<32>(kv[1], kp); asm_load16<64>(kv[2], kp); asm_load16<96>(kv[3], kp);
+        asm_load16<0>(vv[0], vp); asm_load16<32>(vv[1], vp); asm_load16<64>(vv[2], vp); asm_load16<96>(vv[3], vp);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * NTH;
+            const size_t o = ((size_t)b * heads + hd) * L + (i < L ? i : L - 1);
+            asm_load4(lv[j], lse + o);
+            asm_load4(dv_[j], delta + o);
+        }
+    }
+    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+#pragma unroll
+    for (int i = 0; i < GE::IA; ++i) {
+        dma_piece<T>(base, ld, L, piece(i), Qs, lane);
+        dma_piece<T>(dob, E, L, piece(i), dOs, lane);
+    }
+#pragma unroll
+    for (int i = GE::IA; i < GE::PPW; ++i) {
+        dma_piece<T>(base, ld, L, piece(i), Qs, lane);
+        dma_piece<T>(dob, E, L, piece(i), dOs, lane);
+    }
+    constexpr int REST = GE::PPW - GE::IA;
+    const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
+    const bool skip_last_step = L - 32 * (NT - 1) <= 16;
+
+    asm volatile("s_waitcnt vmcnt(%12)"
+                 : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]),
+                   "+v"(lv[0]), "+v"(lv[1]), "+v"(dv_[0]), "+v"(dv_[1])
+                 : "n"((FFM_ATTN3_ABL & 1) ? 0 : 2 * REST)
+                 : "memory");
+    if constexpr ((FFM_ATTN3_ABL & 1) != 0) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + j * NTH;
+        if (i < 32 * NT) {
+            lse_s[i] = i < L ? -8.0f * lv[j] : -INFINITY;
+            del_s[i] = i < L ? -dv_[j] : 0.f;
+        }
+    }
+    frag kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = __builtin_bit_cast(frag, kv[ks]);
+        vf[ks] = __builtin_bit_cast(frag, vv[ks]);
+    }
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dv[dt][e] = 0.f; dk[dt][e] = 0.f; }
+
+    auto tile = [&](auto T_) {
+        constexpr int t = decltype(T_)::value;
+        constexpr bool LAST = t == NT - 1;
+        f32x16 sa, pa;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&lse_s[32 * t + 8 * i + 4 * h]);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(&del_s[32 * t + 8 * i + 4 * h]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sa[4 * i + e] = l4[e]; pa[4 * i + e] = d4[e]; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (LAST) {
+                sa = A3<T>::mma(row_frag_clamped<T>(Qs, lane, t, ks, rmax), kf[ks], sa);
+                pa = A3<T>::mma(row_frag_clamped<T>(dOs, lane, t, ks, rmax), vf[ks], pa);
+            } else {
+                sa = A3<T>::mma(row_frag<T>(Qs, ra, t, ks), kf[ks], sa);
+                pa = A3<T>::mma(row_frag<T>(dOs, ra, t, ks), vf[ks], pa);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sa[e] = __builtin_amdgcn_exp2f(sa[e] * A3_C);
+            pa[e] *= sa[e];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (LAST && st == 1 && skip_last_step) break;
+            const frag pf = pack8<T>(sa, st), df = pack8<T>(pa, st);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                if constexpr (LAST) {
+                    dv[dt] = A3<T>::mma(tr_frag_clamped<T>(dOs, lane, t, st, dt, rmax), pf, dv[dt]);
+                    dk[dt] = A3<T>::mma(tr_frag_clamped<T>(Qs, lane, t, st, dt, rmax), df, dk[dt]);
+                } else {
+                    dv[dt] = A3<T>::mma(tr_frag<T>(dOs, ta, t, st, dt), pf, dv[dt]);
+                    dk[dt] = A3<T>::mma(tr_frag<T>(Qs, ta, t, st, dt), df, dk[dt]);
+                }
+            }
+        }
+    };
+    A3_STAMP(1);
+    block_sync();                                                               // first half of Q and dO, lse_s, del_s
+    A3_STAMP(2);
+    if (active) {
+        if constexpr (GE::CA > 0) tile(std::integral_constant<int, 0>{});
+        if constexpr (GE::CA > 1) tile(std::integral_constant<int, 1>{});
+        if constexpr (GE::CA > 2) tile(std::integral_constant<int, 2>{});
+        if constexpr (GE::CA > 3) tile(std::integral_constant<int, 3>{});
+    }
+    A3_STAMP(3);
+    if constexpr (GE::CB > 0) {
+        wait_vm<0>();
+        block_sync();
+        A3_STAMP(4);
+        if (active) {
+            if constexpr (GE::CB > 0) tile(std::integral_constant<int, GE::CA + 0>{});
+            if constexpr (GE::CB > 1) tile(std::integral_constant<int, GE::CA + 1>{});
+            if constexpr (GE::CB > 2) tile(std::integral_constant<int, GE::CA + 2>{});
+            if constexpr (GE::CB > 3) tile(std::integral_constant<int, GE::CA + 3>{});
+        }
+    }
+    A3_STAMP(5);
+    if (active && key < L) {
+        T* drow = dqkv + ((size_t)b * L + key) * ld + hd * HD;
+        store_rows<T>(drow + E, dk, 0.125f, lane);
+        store_rows<T>(drow + 2 * E, dv, 1.0f, lane);
+    }
+    A3_STAMP(6);
+    A3_RSTAMP(15);
+}
+
+template <typename F> int set_lds3(F fn, int bytes) {
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <typename T, int NT>
+int run_fwd3(const void* qkv, void* out, float* lse, int B, int L, int heads, hipStream_t s) {
+    const int R8 = (L + 7) & ~7, lds = 2 * R8 * 128, BH = B * heads;
+    int e = set_lds3(attn3_fwd_kernel<T, NT>, lds);
+    if (e) return e;
+    hipLaunchKernelGGL((attn3_fwd_kernel<T, NT>), dim3(((BH + 7) / 8) * 16), dim3(64 * Geo<NT>::NW), lds, s, (const T*)qkv, (T*)out, lse, L,
+                       heads, BH);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+template <typename T, int NT>
+int run_bwd3(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
+             hipStream_t s) {
+    const int R8 = (L + 7) & ~7, lds_dq = 2 * R8 * 128, lds_dkv = 2 * R8 * 128 + 2 * 32 * NT * 4, BH = B * heads;
+    int e = set_lds3(attn3_bwd_dq_kernel<T, NT>, lds_dq);
+    if (e) return e;
+    e = set_lds3(attn3_bwd_dkv_kernel<T, NT>, lds_dkv);
+    if (e) return e;
+    const dim3 grid(((BH + 7) / 8) * 16), block(64 * Geo<NT>::NW);
+    hipLaunchKernelGGL((attn3_bwd_dq_kernel<T, NT>), grid, block, lds_dq, s, (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv,
+                       delta, L, heads, BH);
+    FFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn3_bwd_dkv_kernel<T, NT>), grid, block, lds_dkv, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta,
+                       (T*)dqkv, L, heads, BH);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+}  // namespace
+
+#ifdef FFM_ATTN3_STAMPS
+extern "C" int ffm_attn3_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(a3_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// Entry points for attention.hip's dispatcher (same library, not part of the C ABI): FFM_EUNSUP = not this kernel's shape.
+int ffm_attn3_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int dtype, hipStream_t s) {
+    if (L <= 64 || L > 256) return FFM_EUNSUP;
+#define FWD3(T)                                                          \
+    switch ((L + 31) / 32) {                                             \
+        case 3: return run_fwd3<T, 3>(qkv, out, lse, B, L, heads, s);    \
+        case 4: return run_fwd3<T, 4>(qkv, out, lse, B, L, heads, s);    \
+        case 5: return run_fwd3<T, 5>(qkv, out, lse, B, L, heads, s);    \
+        case 6: return run_fwd3<T, 6>(qkv, out, lse, B, L, heads, s);    \
+        case 7: return run_fwd3<T, 7>(qkv, out, lse, B, L, heads, s);    \
+        case 8: return run_fwd3<T, 8>(qkv, out, lse, B, L, heads, s);    \
+    }
+    if (dtype == FFM_BF16) { FWD3(bf16_t) }
+    if (dtype == FFM_F16) { FWD3(f16_t) }
+#undef FWD3
+    return FFM_EUNSUP;
+}
+int ffm_attn3_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
+                  int dtype, hipStream_t s) {
+    if (L <= 64 || L > 256) return FFM_EUNSUP;
+#define BWD3(T)                                                                               \
+    switch ((L + 31) / 32) {                                                                  \
+        case 3: return run_bwd3<T, 3>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 4: return run_bwd3<T, 4>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 5: return run_bwd3<T, 5>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 6: return run_bwd3<T, 6>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 7: return run_bwd3<T, 7>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 8: return run_bwd3<T, 8>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+    }
+    if (dtype == FFM_BF16) { BWD3(bf16_t) }
+    if (dtype == FFM_F16) { BWD3(f16_t) }
+#undef BWD3
+    return FFM_EUNSUP;
+}

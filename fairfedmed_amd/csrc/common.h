@@ -4,9 +4,30 @@
 #include <stdint.h>
 #include "../../include/ffm_hip.h"
 
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+#ifndef FFM_TWIN_F16
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define FFM_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_bf16"
+#else
+// The IEEE-half twin of a translation unit (fairfedmed_amd/build.py compiles every 16-bit kernel file a second time with
+// -DFFM_TWIN_F16 and links it under renamed symbols): "the 16-bit storage type of this file" becomes _Float16 - the kernels are
+// written against bf16_t / bf16x8 as THE 16-bit type, convert by casts only (no bit tricks on the encoding) and name the matrix
+// instruction through the two macros below.  The two dtype codes swap so that `dtype == FFM_BF16` selects the 16-bit kernels
+// for half inputs; a dtype VALUE passed on to another file is always the caller's real code.
+typedef _Float16 bf16_t;
+typedef f16x8 bf16x8;
+typedef f16x4 bf16x4;
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define FFM_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_f16"
+#undef FFM_BF16
+#undef FFM_F16
+#define FFM_BF16 3
+#define FFM_F16 1
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 

@@ -201,9 +201,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     auto mma = [&](auto IDX_, f32x4& c, const frag_t& a, const frag_t& b) {
         if constexpr ((FFM_PANEL_ABL & 4) != 0) return;
         if constexpr (decltype(IDX_)::value < ACC_A)
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+            asm volatile(FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
         else
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+            asm volatile(FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     };
     // RANKOP: t = A_rows . rk^T for the block's rows; wave w owns fragment rows w, w+4, ... (VGPR accumulators)
     constexpr int TI = (MF + CW - 1) / CW;
@@ -256,10 +256,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 // (Tiles whose accumulators already fill the register file cannot afford four loop copies: they spill.)
                 if constexpr (WSPEC) {
                     if constexpr ((mf % CW) == decltype(W_)::value)
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                        asm volatile(FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 } else {
                     if ((mf % CW) == wv)
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
+                        asm volatile(FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+v"(tr[mf / CW]) : "v"(a[mf % (AD + 1)]), "v"(kf));
                 }
             }
             issue(MF_);

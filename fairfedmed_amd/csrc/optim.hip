@@ -116,6 +116,17 @@ inline int grid_for(int64_t n) {
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
+// p *= s in place; *finite_flag = 0 if any product is not finite (the overflow guard of the IEEE-half mode's gradient scale)
+__global__ __launch_bounds__(256) void scale_check_kernel(float* __restrict__ p, float sc, int64_t n, int32_t* __restrict__ finite_flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = p[i] * sc;
+        p[i] = v;
+        bad |= !(fabsf(v) <= 3.4028234e38f);
+    }
+    if (finite_flag && __any(bad) && (threadIdx.x & 63) == 0) *finite_flag = 0;
+}
+
 }  // namespace
 
 extern "C" int ffm_abi_version(void) { return FFM_ABI_VERSION; }
@@ -148,6 +159,13 @@ extern "C" int ffm_sgd_momentum_dev(float* p, const float* g, float* buf, int64_
 extern "C" int ffm_scale_by(const float* p, const float* w, float* out, int64_t n, void* stream) {
     if (!p || !w || !out || n <= 0) return FFM_EINVAL;
     hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, w, out, n);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_scale_check(float* p, float scale, int64_t n, int32_t* finite_flag, void* stream) {
+    if (!p || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(scale_check_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, scale, n, finite_flag);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

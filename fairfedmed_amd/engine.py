@@ -20,12 +20,14 @@ epilogue of the dX GEMM, so the dense dW = A diag(s) B is never formed.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import _lib as L
+from ._lib import is16 as _is16
 from . import ops
 from .config import ModelCfg
 from .synth import manifest, trainable_keys
@@ -213,8 +215,8 @@ class _Stack:
         self.act = [e(T, 4 * w) for _ in range(layers)]
         # partial row sums {sum, sum of squares} of every block input, left behind by its producer (FFM_EPI_ROWSTATS /
         # embed_lnpre) for the ln_1 that is folded into the qkv product: up to 8 column tiles
-        self.rowp = [f(8 * T * 2) for _ in range(layers + 1)] if (rank and dtype == torch.bfloat16) else None
-        self.rowp2 = [f(8 * T * 2) for _ in range(layers)] if (rank and dtype == torch.bfloat16) else None   # ... of xm (ln_2)
+        self.rowp = [f(8 * T * 2) for _ in range(layers + 1)] if (rank and _is16(dtype)) else None
+        self.rowp2 = [f(8 * T * 2) for _ in range(layers)] if (rank and _is16(dtype)) else None   # ... of xm (ln_2)
         self.fold = {}                                       # rows -> (np of the c_proj forward, ok) decision cache
         self.fold2 = {}                                      # rows -> np of the out-proj forward (ln_2 into c_fc)
         if rank:
@@ -285,7 +287,7 @@ class FairLoRAEngine:
         # f32 activations on bf16 weights 0.0020, all f32 0.0005.  Beside a bf16 vision tower the 40-row products run on
         # the bf16 matrix cores as hi/lo pairs (FFM_F32_X3, csrc/gemm_skinny.hip) instead of the 16x slower f32 MFMA.
         self.txt = _Stack(t.width, t.heads, t.layers, self.txt_len, self.n_text, True, 0, torch.float32, self.device,
-                          x3=(dtype == torch.bfloat16))
+                          x3=(_is16(dtype)))
         dev, f32 = self.device, torch.float32
         self._init_vision(max_images)                 # tower-specific buffers (ViT here, RN50 in engine_rn.py)
         self.load_frozen(state_dict)
@@ -300,6 +302,11 @@ class FairLoRAEngine:
         self.prob = torch.zeros_like(self.logits)
         self.loss = torch.zeros(1, device=dev, dtype=f32)
         self.finite = torch.ones(1, device=dev, dtype=torch.int32)
+        # IEEE-half storage: dloss/dlogits is scaled by 2^k before the backward pass (every backward kernel is linear in
+        # the incoming gradient) and the factor comes out of the fp32 gradient buffer in front of the SGD step, with the
+        # finite flag as the overflow guard.  Unscaled, the 16-bit activation gradients of ViT-B/16 sit in half's
+        # subnormals (2.8 % error on the lora_S gradient norms at batch 8; 0.3 % scaled: tests/test_engine_gpu.py).
+        self.grad_scale = float(os.environ.get("FFM_F16_GRAD_SCALE", "4096")) if dtype == torch.float16 else 1.0
         self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
@@ -391,11 +398,11 @@ class FairLoRAEngine:
                 self.rk.append(pk)
                 # the same matrices as [K, 32] rows: the `lw` operand of the GEMM whose OUTPUT columns they span
                 wd = {role: torch.zeros(buf.shape[1], 32, device=dev, dtype=dtype) for role, buf in pk.items()} \
-                    if dtype == torch.bfloat16 else {}
+                    if _is16(dtype) else {}
                 self.lw_wide.append(wd)
                 for role, buf in pk.items():
                     ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf, wd.get(role)))
-                if dtype == torch.bfloat16:
+                if _is16(dtype):
                     # ln_2 folded into c_fc: the rank operand gamma-scaled, and its two correction rows (ops.LnIn.rk)
                     pk["fc_A_ln"] = torch.zeros(16, w, device=dev, dtype=dtype)
                     pk["fc_A_lnrk"] = torch.zeros(32, device=dev, dtype=torch.float32)
@@ -437,7 +444,7 @@ class FairLoRAEngine:
                 w_proj=W(sd[p + pj + "weight"]), w_proj_t=WT(sd[p + pj + "weight"]),
                 b_proj=self._f(sd[p + pj + "bias"]),
             )
-            if lora and stack.dtype == torch.bfloat16:
+            if lora and _is16(stack.dtype):
                 w32 = sd[p + "attn.in_proj_weight"].to(self.device, torch.float32)
                 g1, b1 = blk.ln1_w, blk.ln1_b
                 blk.w_in_ln = W(w32 * g1[None, :])
@@ -455,7 +462,7 @@ class FairLoRAEngine:
                     if isinstance(val, torch.Tensor):
                         getattr(old[i], name).copy_(val)
                 blk = old[i]
-            if lora and stack.dtype == torch.bfloat16:
+            if lora and _is16(stack.dtype):
                 # frozen weights in MFMA-fragment order for the panel GEMM (csrc/gemm_panel_impl.h)
                 if blk.packed is None:
                     blk.packed = {}
@@ -939,6 +946,8 @@ class FairLoRAEngine:
             self._pack_event = None
         ops.ce_loss(self.logits_img, self.label_buf, self.logits, self.prob, self.loss, self.dlogits_img,
                     self.finite, b, S, cfg.n_cls)
+        if self.grad_scale != 1.0:
+            ops.scale_check(self.dlogits_img[:b * S], self.grad_scale)
         self._head_backward(rows, images, L)
         self._ev_record(self.ev_head_bwd, main)
         self._ev_wait(self.side, self.ev_head_bwd)
@@ -978,6 +987,8 @@ class FairLoRAEngine:
                 assert self.params.offsets["proj_per_3d_slice.bias"][0] == off + nw - 3
                 nblk = ops.slice_blocks(self.cfg.vision.image_size, self.cfg.vision.image_size)
                 ops.reduce_partials(self.wpart, images * nblk, nw, self.params.grad[off:off + nw])
+            if self.grad_scale != 1.0:
+                ops.scale_check(self.params.grad, 1.0 / self.grad_scale, self.finite)
         return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
 
     @torch.no_grad()

@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
+from ._lib import is16 as _is16
 from .engine import FairLoRAEngine, _round_up
 from .synth import buffer_keys
 
@@ -305,7 +306,7 @@ class RN50Engine(FairLoRAEngine):
             raise ValueError("ModifiedResNet needs an image size divisible by 32")
         self.is3d = False
         self.vis = None
-        self.kq = 64 if dt == torch.bfloat16 else 32             # GEMM K granularity (128 bytes)
+        self.kq = 64 if _is16(dt) else 32             # GEMM K granularity (128 bytes)
         self.rnw: Dict[str, Tensor] = {}
         self.bns: List[_BN] = []
         self.bn_scratch = self.bn_cmax = self.stat_scratch = 0

@@ -65,7 +65,8 @@ class CustomCLIP(nn.Module):
             ref_cfg, classnames = cfg, list(state_dict)
             cfg, state_dict, self.tokenized_prompts = from_reference_args(ref_cfg, classnames, clip_model, tokenize)
             if dtype is None:
-                dtype = torch.float32 if ref_cfg.TRAINER.GLP_OT.PREC in ("fp32", "amp") else torch.bfloat16
+                from .trainer import resolve_precision
+                dtype = resolve_precision(ref_cfg.TRAINER.GLP_OT.PREC)
             if max_images is None:
                 try:
                     max_images = max(ref_cfg.DATALOADER.TRAIN_X.BATCH_SIZE, ref_cfg.TEST.BATCH_SIZE)

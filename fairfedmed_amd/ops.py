@@ -130,9 +130,9 @@ class LnIn:
 
 
 def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """Frozen bf16 weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
+    """Frozen 16-bit weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
     _dev(w, out)
-    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    assert L.is16(w.dtype) and w.dim() == 2 and w.stride(1) == 1
     N, K = w.shape
     if out is None:
         out = torch.empty(N * K, device=w.device, dtype=w.dtype)
@@ -556,7 +556,7 @@ def lora_grad_partial_ln(x: Tensor, v: Tensor, mean: Tensor, rstd: Tensor, gamma
     """lora_grad_partial for x = LayerNorm(x_raw) that was folded into its consumer: x holds the RAW rows."""
     _dev(x, v, mean, rstd, gamma, beta, part)
     M, K = x.shape
-    assert x.dtype == torch.bfloat16 and K % 128 == 0 and r <= 16
+    assert L.is16(x.dtype) and K % 128 == 0 and r <= 16
     _call("ffm_lora_grad_partial_ln", L.ptr(x), _ld(x), L.ptr(_f32(v)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
           L.ptr(_f32(gamma)), L.ptr(_f32(beta)), M, K, r, L.ptr(_f32(part)), L.dtype_code(x.dtype), L.stream_ptr())
 
@@ -682,6 +682,13 @@ def sgd_momentum_dev(p: Tensor, g: Tensor, buf: Tensor, hp: Tensor) -> None:
 def scale_by(p: Tensor, w: Tensor, out: Tensor) -> None:
     _dev(p, w, out)
     _call("ffm_scale_by", L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(out)), p.numel(), L.stream_ptr())
+
+
+def scale_check(p: Tensor, scale: float, finite: Optional[Tensor] = None) -> None:
+    """p *= scale in place; clears the int32 flag when a product is not finite (ffm_scale_check)."""
+    _dev(p, finite)
+    assert p.is_contiguous() and (finite is None or finite.dtype == torch.int32)
+    _call("ffm_scale_check", L.ptr(_f32(p)), float(scale), p.numel(), L.ptr(finite), L.stream_ptr())
 
 
 def fedavg_finish(avg: Tensor, prev: Tensor, out: Tensor, s_offsets: Optional[Tensor], G: int, r: int,

@@ -127,22 +127,18 @@ class SyntheticFedData:
 
 
 def resolve_precision(prec: str):
-    """TRAINER.GLP_OT.PREC -> compute dtype of the engine.  The reference knows 'fp16' (its GPU default,
+    """TRAINER.GLP_OT.PREC -> storage dtype of the engine.  The reference knows 'fp16' (its GPU default,
     federated_main.py:85: convert_weights halves the CLIP weights, clip/model.py:609-630), 'fp32' and 'amp'
-    (fp32 weights under autocast, trainers/GLP_OT_SVLoRA.py:833-835, 900-907).  MI355X's throughput mode here is bf16
-    (fp32 accumulation, fp32 trainable tensors; BASELINE.json configs[1] names bf16), and there is no fp16 engine:
-    'fp16' therefore runs as bf16 - same flag value, different 16-bit format (8 significand bits instead of 11, no
-    overflow at 65504) - and says so once."""
+    (fp32 weights under autocast, trainers/GLP_OT_SVLoRA.py:833-835, 900-907).  'fp16' is IEEE half here too (activations
+    and frozen weights in float16, fp32 accumulation and fp32 trainable tensors, the device-side finite flag as the
+    overflow guard: FFM_F16, the half twins of the 16-bit kernels); 'bf16' is MI355X's throughput mode that
+    BASELINE.json configs[1] names (same kernels, 8 significand bits instead of 11, no overflow at 65504)."""
     if prec in ("fp32", "amp"):
         return torch.float32
     if prec == "bf16":
         return torch.bfloat16
     if prec == "fp16":
-        import warnings
-        warnings.warn("TRAINER.GLP_OT.PREC='fp16' runs as bf16 on this engine (no fp16 path on the MI355X build): "
-                      "activations / frozen weights in bfloat16, accumulation and trainable tensors in float32; "
-                      "use PREC='fp32' for parity-grade numerics", UserWarning, stacklevel=2)
-        return torch.bfloat16
+        return torch.float16
     raise ValueError(f"TRAINER.GLP_OT.PREC={prec!r}: expected 'fp16', 'bf16', 'fp32' or 'amp'")
 
 

@@ -35,6 +35,9 @@ extern "C" {
  * operands split into bf16 hi + lo pairs (hi*hi + lo*hi + hi*lo, f32 accumulation: ~2^-16 instead of the f32 MFMA's
  * 2^-24, at 5x its rate); products of at most 64 rows (the text tower beside a bf16 vision tower), FFM_EUNSUP otherwise */
 #define FFM_F32_X3 2
+/* IEEE half storage (the reference's PREC="fp16", federated_main.py:85 / clip/model.py:609-630): activations and
+ * frozen weights in fp16, fp32 accumulation and fp32 trainable tensors exactly as under FFM_BF16 */
+#define FFM_F16 3
 
 #define FFM_OK 0
 #define FFM_EINVAL (-1)
@@ -44,7 +47,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 7   /* 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 8   /* 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -474,6 +477,15 @@ int ffm_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, 
  */
 int ffm_sgd_momentum_n(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
                        float weight_decay, int first_step, int repeats, void* stream);
+
+/*
+ * p[i] *= scale in place; clears *finite_flag (may be NULL) when a product is not finite.  The IEEE-half mode (FFM_F16)
+ * scales dloss/dlogits by 2^k before the backward pass so that the 16-bit activation gradients stay clear of half's
+ * subnormals (the reference's fp16 mode lets them underflow: no GradScaler outside PREC='amp',
+ * trainers/GLP_OT_SVLoRA.py:889-907) and takes the factor out of the fp32 gradient buffer here, in front of the SGD
+ * step; the flag is the overflow guard (Dassl/dassl/engine/trainer.py:260-262 raises on the host from it).
+ */
+int ffm_scale_check(float* p, float scale, int64_t n, int32_t* finite_flag, void* stream);
 
 /* The same update with {lr, momentum, weight_decay} read from DEVICE memory (hp[3]) and a momentum buffer
  * that starts at zero: safe to capture in a hipGraph while the LR schedule changes lr between replays. */

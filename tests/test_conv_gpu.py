@@ -7,8 +7,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F = torch.nn.functional
-DT = [torch.float32, torch.bfloat16]
-IDS = ["f32", "bf16"]
+DT = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ["f32", "bf16", "f16"]
 
 
 def tol(dt):
@@ -45,7 +45,7 @@ def test_conv3x3_forward_and_input_gradient(ops, dt, B, H, C, Co, stride):
     x = rnd(B, C, H, H, dt=dt, seed=1)
     w = rnd(Co, C, 3, 3, dt=dt, scale=(9 * C) ** -0.5, seed=2)
     Ho = ops.conv_out(H, stride)
-    ke = 64 if dt == torch.bfloat16 else 32
+    ke = 64 if dt != torch.float32 else 32
     Kp = (9 * C + ke - 1) // ke * ke
     cols = torch.empty(B * Ho * Ho, Kp, device="cuda", dtype=dt)
     ops.im2col3x3(nhwc(x), cols, B, H, H, stride)
@@ -185,7 +185,7 @@ def _rows_bwd(w, Kp):
 def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, Co):
     """ffm_conv3x3_nhwc: the patches are never materialised; forward and (with the re-ordered weight) the input
     gradient against F.conv2d and its autograd, incl. non-square maps, tile-ragged pixel counts and padded K."""
-    kq = 64 if dt == torch.bfloat16 else 32
+    kq = 64 if dt != torch.float32 else 32
     rup = lambda v: (v + kq - 1) // kq * kq
     x = rnd(B, C, H, W, dt=dt, seed=1)
     w = rnd(Co, C, 3, 3, dt=dt, scale=1.0 / math.sqrt(9 * C), seed=2)
@@ -236,7 +236,7 @@ def test_gemm_column_sums_feed_batchnorm(ops, dt, M, N, K):
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 def test_conv3x3_column_sums(ops, dt):
     """ffm_conv3x3_nhwc(colstat_part): partial rows as ffm_conv3x3_colstat_rows says, none when the launch splits K."""
-    kq = 64 if dt == torch.bfloat16 else 32
+    kq = 64 if dt != torch.float32 else 32
     rup = lambda v: (v + kq - 1) // kq * kq
     zeros = torch.zeros(64, device="cuda", dtype=dt)
     for (B, H, C, Co, sc) in [(5, 28, 64, 64, False), (4, 14, 256, 256, True), (2, 16, 32, 64, True)]:

@@ -206,16 +206,19 @@ def test_resize_image_against_hand_derived_values():
         assert out.min() >= x.min() and out.max() <= x.max()
 
 
-def test_fp16_precision_flag_is_mapped_to_bf16_with_a_warning():
-    """The reference's GPU default PREC='fp16' (federated_main.py:85) has no fp16 engine here: it runs as bf16 and says so."""
+def test_precision_flags_map_to_storage_types():
+    """The reference's GPU default PREC='fp16' (federated_main.py:85) is IEEE half here too (FFM_F16); 'bf16' is the
+    MI355X throughput mode; every documented value is silent."""
     import warnings
     import torch
     from fairfedmed_amd.trainer import resolve_precision
+    from fairfedmed_amd import _lib
     with warnings.catch_warnings():
-        warnings.simplefilter("error")                                  # the documented values are silent
+        warnings.simplefilter("error")
         assert resolve_precision("bf16") is torch.bfloat16
+        assert resolve_precision("fp16") is torch.float16
         assert resolve_precision("fp32") is torch.float32 and resolve_precision("amp") is torch.float32
-    with pytest.warns(UserWarning, match="fp16.*bf16"):
-        assert resolve_precision("fp16") is torch.bfloat16
+    assert (_lib.dtype_code(torch.float32), _lib.dtype_code(torch.bfloat16), _lib.dtype_code(torch.float16)) == (0, 1, 3)
+    assert _lib.is16(torch.float16) and _lib.is16(torch.bfloat16) and not _lib.is16(torch.float32)
     with pytest.raises(ValueError):
         resolve_precision("int8")

@@ -32,7 +32,7 @@ def rel(got, ref):
                                        (24, 3, 4),      # beyond 16: stand-alone down projection + VALU kernels
                                        (32, 8, 9),      # FFM_MAX_RANK, FFM_MAX_GROUPS
                                        (2, 2, 1)])      # smallest even rank, one image
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_step_vs_oracle_over_ranks_and_groups(rank, G, bs, dtype):
     from oracle import fairlora_oracle as O
     from fairfedmed_amd.engine import FairLoRAEngine

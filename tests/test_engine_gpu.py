@@ -57,7 +57,7 @@ def to_dev(batch):
     ("tiny_svlora_globals", C.vit_tiny_lora("SVLoRA", True), 8, "random"),   # the attribute is ignored
     ("tiny_lora", C.vit_tiny_lora("LoRA", False), 8, "random"),
 ])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
     from oracle import fairlora_oracle as O
     gold = np.load(os.path.join(golden_dir, gold_file(mcfg)))
@@ -69,15 +69,15 @@ def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
     img, attr, label = to_dev(batch)
     out = eng.forward_backward(img, attr, label)
     torch.cuda.synchronize()
-    f32 = dtype == torch.float32
-    # against the reference's own numbers
-    assert rel(out["logits"], gold[f"{tag}.logits"]) < (1e-5 if f32 else 2e-2)
+    f32, f16 = dtype == torch.float32, dtype == torch.float16
+    # against the reference's own numbers (IEEE half: 11 significand bits - held 5x tighter than bfloat16)
+    assert rel(out["logits"], gold[f"{tag}.logits"]) < (1e-5 if f32 else 4e-3 if f16 else 2e-2)
     l0 = meta[f"{tag}.loss0"]
-    assert abs(float(out["loss"]) - l0) <= (1e-5 if f32 else 5e-3) * abs(l0)
+    assert abs(float(out["loss"]) - l0) <= (1e-5 if f32 else 1e-3 if f16 else 5e-3) * abs(l0)
     assert int(out["finite"]) == 1
     # against the oracle run here on the host
     loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
-    assert rel(out["logits"], logits) < (1e-5 if f32 else 2e-2)
+    assert rel(out["logits"], logits) < (1e-5 if f32 else 4e-3 if f16 else 2e-2)
     worst, wcos = 0.0, 1.0
     for k in keys:
         g = eng.params.view(k, "grad")
@@ -93,7 +93,7 @@ def test_tiny_step_vs_oracle_and_golden(golden_dir, tag, mcfg, bs, init, dtype):
             assert rel(g, gold[f"{tag}.grad.{k}"]) < 2e-3, k
         else:
             # bf16: per-element errors of cancellation-heavy sums say little; direction and size do
-            assert cos(g, ref) > 0.99 and e < 0.15, (k, cos(g, ref), e)
+            assert cos(g, ref) > (0.999 if f16 else 0.99) and e < (0.03 if f16 else 0.15), (k, cos(g, ref), e)
     print(tag, dtype, "worst grad err", worst, "worst cosine", wcos)
     # inference path returns the same logits
     assert rel(eng.forward(img, attr), out["logits"]) < 1e-6
@@ -142,7 +142,7 @@ def test_no_attr_uniform_mix():
 
 
 @pytest.mark.parametrize("tag,bs", [("vitb_r8", 8), ("vitb_r8_bs32", 32)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
     """Full ViT-B/16 r=8 G=3 step against the imported reference's logits, loss, gradients and loss trajectory: bs 8,
     and bs 32 = the bench workload, whose 6304 token rows select the bf16 panel GEMMs on fragment-packed weights."""
@@ -154,26 +154,26 @@ def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
     batch = synth.make_batch(mcfg, bs, seed=1234)
     eng = make_engine(mcfg, sd, dtype, bs)
     assert eng.params.numel == 741952
-    f32 = dtype == torch.float32
+    f32, f16 = dtype == torch.float32, dtype == torch.float16
     if bs == 32 and not f32:
         from fairfedmed_amd import ops
         w = mcfg.vision.width
         assert eng.vis.blocks[0].packed is not None
-        assert ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, torch.bfloat16, True) != \
-            ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, torch.bfloat16, False), "panel kernel not selected"
+        assert ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, dtype, True) != \
+            ops.gemm_tiles_m(32 * 197, 4 * w, w, 2 | 4 | 32 | 64, 8, dtype, False), "panel kernel not selected"
     img, attr, label = to_dev(batch)
     out = eng.forward_backward(img, attr, label)
     torch.cuda.synchronize()
     l0 = meta[f"{tag}.loss0"]
     print(tag, dtype, "loss", float(out["loss"]), "ref", l0, "logit err", rel(out["logits"], gold[f"{tag}.logits"]))
-    assert abs(float(out["loss"]) - l0) <= (1e-4 if f32 else 1e-2) * abs(l0)
-    assert rel(out["logits"], gold[f"{tag}.logits"]) < (1e-4 if f32 else 5e-2)
+    assert abs(float(out["loss"]) - l0) <= (1e-4 if f32 else 2e-3 if f16 else 1e-2) * abs(l0)
+    assert rel(out["logits"], gold[f"{tag}.logits"]) < (1e-4 if f32 else 1e-2 if f16 else 5e-2)
     from tests.golden.make_golden import sub
     worst, wcos = 0.0, 1.0
     for k in synth.trainable_keys(mcfg):
         g = eng.params.view(k, "grad").cpu()
         n, ref_n = float(g.norm()), meta[f"{tag}.grad_norms"][k]
-        assert abs(n - ref_n) <= (2e-3 if f32 else 8e-2) * ref_n + 1e-12, (k, n, ref_n)
+        assert abs(n - ref_n) <= (2e-3 if f32 else 2e-2 if f16 else 8e-2) * ref_n + 1e-12, (k, n, ref_n)
         key = f"{tag}.grad.{k}" if f"{tag}.grad.{k}" in gold else f"{tag}.gradsub.{k}"
         ref = gold[key]
         got = g.numpy() if key.startswith(f"{tag}.grad.") else sub(g, 1024)
@@ -183,7 +183,7 @@ def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
         if f32:
             assert e < 5e-3, (k, e)
         else:
-            assert cos(got, ref) > 0.97, (k, cos(got, ref), e)
+            assert cos(got, ref) > (0.995 if f16 else 0.97), (k, cos(got, ref), e)
     print(tag, dtype, "worst grad err", worst, "worst cosine", wcos)
     # the reference's forward_backward trajectory (two optimizer steps per batch: quirk 9)
     for i, ref in enumerate(meta[f"{tag}.traj"]):

@@ -49,7 +49,7 @@ def to_dev(batch):
 
 
 @pytest.mark.parametrize("TAG", list(GEOMS))
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_rn_step_vs_oracle_and_golden(golden_dir, dtype, TAG):
     from oracle import fairlora_oracle as O
     gold = np.load(os.path.join(golden_dir, "rn_tiny.npz"))

@@ -36,7 +36,7 @@ def to_dev(batch):
     return batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_full_rn50_step_vs_oracle(dtype):
     from fairfedmed_amd.engine_rn import create_engine, RN50Engine
     from oracle import fairlora_oracle as O
@@ -87,7 +87,7 @@ def test_full_rn50_step_vs_oracle(dtype):
                 assert rel(bufs[k], ref_sd[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_full_size_3d_oct_step_vs_oracle(dtype):
     from fairfedmed_amd.engine import FairLoRAEngine
     from oracle import fairlora_oracle as O

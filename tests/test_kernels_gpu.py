@@ -13,12 +13,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
-IDS = ["f32", "bf16"]
+DT = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ["f32", "bf16", "f16"]
+# the two 16-bit storage types run the same sources (csrc/common.h, FFM_TWIN_F16): every 16-bit-only test takes both
+H16 = pytest.mark.parametrize("h16", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 
 
 def tol(dt):
-    return 2e-5 if dt == torch.float32 else 1.2e-2
+    # max error / tensor scale: bf16 rounds to 2^-9, IEEE half to 2^-12 (held 6x tighter: a half path that quietly ran
+    # in bfloat16 fails it)
+    return 2e-5 if dt == torch.float32 else 1.2e-2 if dt == torch.bfloat16 else 2e-3
 
 
 def rel_err(got, ref):
@@ -117,10 +121,11 @@ def test_gemm_rankop_fused_lora(ops, dt, r, G, kr, use_attr):
 # ------------------------------------------------- panel GEMM (packed B) ---
 @pytest.mark.parametrize("M,N,K,mode", [(6304, 2048, 1536, "b"), (6304, 768, 768, "br"), (6304, 768, 2304, ""),
                                          (6000, 768, 3072, "br"), (4100, 1024, 512, "b")])
-def test_gemm_panel_plain(ops, M, N, K, mode):
+@H16
+def test_gemm_panel_plain(ops, M, N, K, mode, h16):
     """Frozen weights packed in MFMA-fragment order -> panel kernel (csrc/gemm_panel_impl.h); same contract as
     ffm_gemm_nt on the row-major operand."""
-    dt = torch.bfloat16
+    dt = h16
     flags = (1 if "b" in mode else 0) | (8 if "r" in mode else 0)
     assert ops.gemm_tiles_m(M, N, K, flags, 0, dt, True) != ops.gemm_tiles_m(M, N, K, flags, 0, dt, False), \
         "shape does not select the panel kernel"
@@ -143,9 +148,10 @@ def test_gemm_panel_plain(ops, M, N, K, mode):
 
 @pytest.mark.parametrize("case", ["fc_fwd", "proj_fwd", "proj_dx", "fc_dx"])
 @pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (5500, 16, 2, False), (6304, 4, 3, True)])
-def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr):
+@H16
+def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr, h16):
     """The four FairLoRA GEMMs of a block on the panel kernel: t / ts / dS partials / fused rank-r update / GELU."""
-    dt = torch.bfloat16
+    dt = h16
     width, rps = 768, 197
     N, K = (4 * width, width) if case in ("fc_fwd", "proj_dx") else (width, 4 * width)
     kr = case in ("proj_dx", "fc_dx")
@@ -611,19 +617,20 @@ def test_x3_gemm_rejects_large_products():
 
 
 # ------------------------------------------------ LayerNorm folded into the GEMMs around it ---
-def test_gemm_rowstats_partials():
+@H16
+def test_gemm_rowstats_partials(h16):
     """FFM_EPI_ROWSTATS (out-proj forward shape): the partial {sum, sum of squares} of every STORED output row, one
     partial per column tile, add up to the row sums of the bf16 output."""
     from fairfedmed_amd import ops, _lib as L
     M, N, K = 6304, 768, 768
     g = torch.Generator(device="cuda").manual_seed(5)
-    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    a = torch.randn(M, K, device="cuda", generator=g).to(h16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(h16)
     bias = torch.randn(N, device="cuda", generator=g)
-    res = (3 + torch.randn(M, N, device="cuda", generator=g)).to(torch.bfloat16)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    res = (3 + torch.randn(M, N, device="cuda", generator=g)).to(h16)
+    out = torch.empty(M, N, device="cuda", dtype=h16)
     bp = ops.pack_b(w)
-    tn = ops.gemm_tiles_n(M, N, K, L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_ROWSTATS, 0, torch.bfloat16, True)
+    tn = ops.gemm_tiles_n(M, N, K, L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_ROWSTATS, 0, h16, True)
     assert tn > 0
     part = torch.full((tn, M, 2), float("nan"), device="cuda")
     ops.gemm_nt(a, w, out, bias=bias, res=res, b_packed=bp, rowstats=part)
@@ -640,25 +647,26 @@ def test_gemm_rowstats_partials():
 
 
 @pytest.mark.parametrize("np_", [1, 6])
-def test_gemm_layernorm_folded_in(np_):
+@H16
+def test_gemm_layernorm_folded_in(np_, h16):
     """FFM_EPI_LNIN (qkv forward shape): raw rows x gamma-scaled weight, corrected in the epilogue with the row statistics
     assembled from np partial sums, equals LayerNorm(x) W^T + b; mean / rstd come out for the LayerNorm backward."""
     from fairfedmed_amd import ops
     M, N, K = 6304, 2304, 768
     g = torch.Generator(device="cuda").manual_seed(6)
-    x = (1.5 + 2.0 * torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)     # a row mean far from 0
+    x = (1.5 + 2.0 * torch.randn(M, K, device="cuda", generator=g)).to(h16)     # a row mean far from 0
     x[:, 5] += 40.0                                                                          # one outlier channel
     w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
     gamma = 1 + 0.2 * torch.randn(K, device="cuda", generator=g)
     beta = 0.3 * torch.randn(K, device="cuda", generator=g)
     bias = torch.randn(N, device="cuda", generator=g)
-    wg = (w * gamma).to(torch.bfloat16)
+    wg = (w * gamma).to(h16)
     c = wg.float().sum(1).contiguous()
     d = (w @ beta + bias).contiguous()
     xf = x.float()
     cols = torch.tensor_split(torch.arange(K, device="cuda"), np_)
     part = torch.stack([torch.stack([xf[:, ix].sum(1), (xf[:, ix] ** 2).sum(1)], 1) for ix in cols]).contiguous()
-    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=h16)
     mean = torch.empty(M, device="cuda")
     rstd = torch.empty(M, device="cuda")
     ops.gemm_nt(x, wg, out, bias=d, b_packed=ops.pack_b(wg), ln_in=ops.LnIn(part, np_, c, mean, rstd))
@@ -671,7 +679,7 @@ def test_gemm_layernorm_folded_in(np_):
     # against the unfolded bf16 path (LayerNorm kernel, then the product): the folded form is no less accurate
     h = torch.empty_like(x)
     ops.layernorm_fwd(x, h, gamma, beta, torch.empty(M, device="cuda"), torch.empty(M, device="cuda"))
-    wb = w.to(torch.bfloat16)
+    wb = w.to(h16)
     out2 = torch.empty_like(out)
     ops.gemm_nt(h, wb, out2, bias=bias, b_packed=ops.pack_b(wb))
     e_fold = float((out.double() - ref).abs().mean())
@@ -680,13 +688,14 @@ def test_gemm_layernorm_folded_in(np_):
     assert e_fold < 1.5 * e_plain
 
 
-def test_lora_grad_partial_through_a_folded_layernorm():
+@H16
+def test_lora_grad_partial_through_a_folded_layernorm(h16):
     """ffm_lora_grad_partial_ln: dA = LayerNorm(x)^T v from the RAW rows (the normalised copy is never written when ln_2
     rides inside the c_fc product) equals the plain reduction on a materialised LayerNorm output."""
     from fairfedmed_amd import ops
     M, K, r = 6304, 768, 8
     g = torch.Generator(device="cuda").manual_seed(9)
-    x = (0.7 + 1.5 * torch.randn(M, K, device="cuda", generator=g)).to(torch.bfloat16)
+    x = (0.7 + 1.5 * torch.randn(M, K, device="cuda", generator=g)).to(h16)
     v = torch.randn(M, r, device="cuda", generator=g)
     gamma = 1 + 0.2 * torch.randn(K, device="cuda", generator=g)
     beta = 0.3 * torch.randn(K, device="cuda", generator=g)
@@ -802,3 +811,84 @@ def test_attention_quarter_head_blocks_switch():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+# --------------------------------------- attention, third generation (csrc/attention3.hip) ---
+# Every 32-token tile count the fat-wave kernels take (3..8 tiles: 65..256 tokens), tile edges (L = 32 k, 32 k + 1,
+# 32 k - 1), the vision tower's lengths (197; 113..224 in steps), one and several (batch, head) pairs per XCD group, in
+# both 16-bit storage types, against float64.
+A3_LENGTHS = [65, 96, 97, 113, 128, 129, 144, 160, 161, 176, 192, 193, 197, 200, 208, 209, 224, 225, 240, 255, 256]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("L", A3_LENGTHS)
+def test_attention3_lengths(ops, dt, L):
+    B, heads = (3, 5) if L % 2 else (2, 12)
+    E = heads * 64
+    qkv = rnd(B * L, 3 * E, dt=dt, seed=230 + L)
+    out = torch.full((B * L, E), float("nan"), device="cuda", dtype=dt)
+    lse = torch.full((B, heads, L), float("nan"), device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+    qd = qkv.double().requires_grad_(True)
+    ref, ref_lse = ref_attention(qd, B, L, heads, False)
+    t16 = 1.2e-2 if dt == torch.bfloat16 else 2e-3
+    check(out, ref.detach(), t16, "attn out")
+    check(lse, ref_lse.detach(), 2e-3 if dt == torch.bfloat16 else 3e-4, "lse")
+    dout = rnd(B * L, E, dt=dt, seed=240 + L)
+    ref.backward(dout.double())
+    dqkv = torch.full((B * L, 3 * E), float("nan"), device="cuda", dtype=dt)
+    delta = torch.full((B, heads, L), float("nan"), device="cuda")
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, False)
+    check(delta, (dout.double() * out.double()).reshape(B, L, heads, 64).sum(-1).permute(0, 2, 1), 1e-5, "delta")
+    check(dqkv[:, :E], qd.grad[:, :E], 2 * t16, "dq")
+    check(dqkv[:, E:2 * E], qd.grad[:, E:2 * E], 2 * t16, "dk")
+    check(dqkv[:, 2 * E:], qd.grad[:, 2 * E:], 2 * t16, "dv")
+
+
+@pytest.mark.parametrize("L", [197, 130])
+def test_attention3_running_maximum_and_rows(ops, L):
+    """The second DMA half can raise a row's maximum (the rescale path): one key of the second half is made to dominate
+    chosen queries, another row peaks in the first half; per-row comparison so that one wrong row cannot hide."""
+    dt, B, heads = torch.bfloat16, 2, 3
+    E = heads * 64
+    qkv = rnd(B * L, 3 * E, dt=dt, seed=77, scale=0.5)
+    v = qkv.view(B, L, 3, heads, 64)
+    v[0, 5, 0, 1] = 2.0                                    # query 5 of head 1 ...
+    v[0, L - 2, 1, 1] = 3.0                                # ... against a key of the last tile: score 384 / 8
+    v[1, 40, 0, 2] = -2.0
+    v[1, 3, 1, 2] = -3.0                                   # query 40 of head 2 peaks at key 3 (first half)
+    out = torch.empty(B * L, E, device="cuda", dtype=dt)
+    lse = torch.empty(B, heads, L, device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+    ref, ref_lse = ref_attention(qkv.double(), B, L, heads, False)
+    err = (out.double() - ref).abs().reshape(B, L, heads, 64).amax(-1)
+    assert float(err.max()) <= 1.2e-2 * float(ref.abs().max()), (float(err.max()), err.argmax())
+    assert float((lse.double() - ref_lse).abs().max()) <= 2e-3 * float(ref_lse.abs().max())
+    assert float(lse[0, 1, 5]) > 40.0                      # the spike really is the row maximum
+
+
+def test_attention3_is_the_kernel_that_runs_and_matches_the_second_generation():
+    """attn3_* must be what the vision tower's shape launches (no silent fallback), and it agrees with attn2_* run in a
+    child process under FFM_ATTN=v2 to 16-bit rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, %r); from fairfedmed_amd import ops\n"
+            "g = torch.Generator(device='cuda').manual_seed(5)\n"
+            "qkv = torch.randn(2 * 197, 2304, device='cuda', generator=g).bfloat16()\n"
+            "out = torch.empty(2 * 197, 768, device='cuda', dtype=torch.bfloat16); lse = torch.empty(2, 12, 197, device='cuda')\n"
+            "ops.attention_fwd(qkv, out, lse, 2, 197, 12, False); torch.cuda.synchronize()\n"
+            "torch.save({'out': out.cpu(), 'lse': lse.cpu()}, sys.argv[1])\n" % root)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for gen in ("v2", "v3"):
+            f = os.path.join(d, gen + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, FFM_ATTN=gen), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[gen] = torch.load(f)
+    a, b = res["v2"], res["v3"]
+    assert not torch.equal(a["out"], b["out"]), "FFM_ATTN=v2 / v3 ran the same kernel"
+    assert float((a["out"].double() - b["out"].double()).abs().max()) <= 2e-2 * float(a["out"].double().abs().max())
+    assert float((a["lse"] - b["lse"]).abs().max()) <= 2e-3 * float(a["lse"].abs().max())

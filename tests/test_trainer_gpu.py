@@ -44,7 +44,7 @@ def test_state_dict_keys_shapes_and_sharing():
 
 
 @pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: c[0])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fairlora_linear_vs_reference_golden(golden_dir, case, dtype):
     """FairLoRALinear.forward/backward (HIP) vs the imported reference layer, nn.Linear and 1x1-conv (RN50) forms."""
     from fairfedmed_amd.model import FairLoRALinear
@@ -82,7 +82,7 @@ def test_fairlora_linear_vs_reference_golden(golden_dir, case, dtype):
     assert rel(layer.lora_B.weight.grad, unit[f"layer.{name}.dB"]) < t2
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_fairlora_linear_global_s_vs_reference_golden(golden_dir, dtype):
     """FairLoRALinear(global_s=True): lora_S_global [r] is added to every sample's singular values
     (trainers/GLP_OT_SVLoRA.py:359-363, 418-422, 467-468); forward, all five gradients and weight() vs the reference."""
@@ -111,7 +111,7 @@ def test_fairlora_linear_global_s_vs_reference_golden(golden_dir, dtype):
     assert rel(layer.weight(xin.detach().float(), attr.cuda()).detach(), unit[f"layer.{name}.gs.weight_attr"]) < 1e-5
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_lora_linear_vs_reference_golden(golden_dir, dtype):
     """LoRALinear (plain LoRA of the RN50 attention pool) on the HIP kernels vs the imported reference layer."""
     from fairfedmed_amd.model import LoRALinear
@@ -496,7 +496,7 @@ def test_cli_runs_the_fairlora_script_on_files(tmp_path):
     assert any(ln.startswith("client 2: acc") for ln in lines)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_svlora_linear_vs_reference_golden(golden_dir, dtype):
     """SVLoRALinear (--lora_type SVLoRA; trainers/GLP_OT_SVLoRA.py:255-330) on the HIP kernels vs the imported
     reference layer: initial singular values (1-D, linspace(1, 0.1, r)), forward, all gradients."""
