@@ -66,13 +66,16 @@ def parse():
                          "r=16, c5 = configs[4] RN50 r=8 G=2")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="storage type: bf16 (BASELINE.json configs[1]), f16 (IEEE half, the reference's PREC=fp16), f32")
     ap.add_argument("--rank", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trainer", action="store_true", help="skip the GLP_OT_SVLoRA.train() throughput entries")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[3] (3D OCT) / configs[4] (RN50) step times (child processes after the timed region)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--engine-step", action="store_true",
+                    help="configs[1]: time the bare engine loop (forward_backward + sgd_step) instead of the trainer's per-batch path")
     ap.add_argument("--serial", action="store_true",
                     help="fold the side streams into the main stream for the timed steps (one kernel at a time): the "
                          "mode the roofline pass measures in; use it under rocprofv3 to get per-kernel durations "
@@ -234,7 +237,7 @@ def build_bench_trainer(mcfg, sd, args, dev, rank):
                         DIM_PER_3D_SLICE=0, USERS=1),
              MODEL=NS(BACKBONE=NS(NAME="ViT-B/16"), STATE_DICT=sd),
              TRAINER=NS(NAME="GLP_OT_SVLoRA", LAMBDA_FAIRNESS=0.0,
-                        GLP_OT=NS(N=2, N_CTX=4, PREC="bf16" if args.dtype == "bf16" else "fp32", OT="None"),
+                        GLP_OT=NS(N=2, N_CTX=4, PREC={"bf16": "bf16", "f16": "fp16", "f32": "fp32"}[args.dtype], OT="None"),
                         GLP_OT_LORA=NS(RANK=args.rank, ALPHA=2.0, TYPE="FairLoRA", GLOBAL_S=False, DISABLE_ATTR=False,
                                        UNFREEZE_IMAGE_ENCODER=True)),
              OPTIM=NS(NAME="sgd", LR=1e-3, MOMENTUM=0.9, WEIGHT_DECAY=5e-4, LR_SCHEDULER="single_step", STEPSIZE=200,
@@ -314,7 +317,7 @@ class Workload:
         from fairfedmed_amd import config as C
         from fairfedmed_amd import synth
         from fairfedmed_amd.engine import FairLoRAEngine
-        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
         self.key, self.tr, self.vit_images = args.config, None, None
         if args.config == "c2":
             self.mcfg = C.vit_b16(rank=args.rank)
@@ -357,6 +360,7 @@ class Workload:
         self.dtype = dtype
         self.img = batch["img"].to(dev)
         self.attr = batch["attrs"].t()[0].contiguous().to(dev)
+        self.attrs = batch["attrs"].to(dev)                    # [B, n_attr]: the trainer's batch format
         self.label = batch["label"].to(dev)
         self.has_buf = hasattr(self.eng, "buffers_flat")       # RN50: BatchNorm running statistics
 
@@ -421,8 +425,20 @@ def main():
         raise SystemExit("--launch graph: the captured step exists for --config c2 only")
     graphed = eng.capture_train_step(BATCH, opt.lr, opt.momentum, opt.weight_decay) if args.launch == "graph" else None
 
+    # SURVEY.md section 8(d) defines the metric on the wall time of the client's train(): for configs[1] a timed step is
+    # therefore what GLP_OT_SVLoRA.run_epoch does per batch - parse_batch_train, forward_backward (engine step + the
+    # reference's double optimizer step), the per-step summary left on the device - on a batch resident in HBM; the bare
+    # engine loop of earlier rounds is reported beside it as `engine_only`.
+    trainer_step = tr is not None and graphed is None and not args.engine_step
+    if trainer_step:
+        tr.set_model_mode("train")
+        tr.batch_idx, tr.num_batches = 0, 1 << 30             # never an epoch's last batch: no StepLR move while timing
+        tbatch = {"img": img, "label": label, "attrs": wl.attrs}
+
     def step():
-        if graphed is None:
+        if trainer_step:
+            tr.forward_backward(tbatch)
+        elif graphed is None:
             eager_step()
         else:
             graphed.run(img, attr, label)          # copies the (resident) batch into the graph's inputs, replays
@@ -463,6 +479,24 @@ def main():
         dt = float(t)
     finite = int(eng.finite)
     loss = float(eng.loss)
+    engine_only = None
+    if trainer_step:
+        # the bare engine loop on the same engine (earlier rounds' headline): K steps, same bracket, max over ranks
+        tr.check_finite()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        de = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([de], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            de = float(t)
+        engine_only = {"value": wl.units * args.steps * world / de, "ms_per_step": de / args.steps * 1e3,
+                       "what": "eng.forward_backward + eng.sgd_step(repeats=2) in a bare loop: no parse_batch, no per-step summary"}
     # round-boundary exchange on its own: pre-scale, ONE all-reduce of the flat trainable buffer,
     # shared_half_s + EMA (RN50: + the BatchNorm-buffer all-reduce); median of 5 after the timed region, max over ranks
     fedavg_us = None
@@ -498,7 +532,7 @@ def main():
             n_all, ms_all, fl_all = gt.summary()
             floor_us = gt.pair_floor_us()
         eng.set_overlap(True)
-        peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+        peak = MFMA_BF16_PEAK_TFLOPS if dtype != torch.float32 else MFMA_F32_PEAK_TFLOPS     # (the f16 MFMA forms run at the bf16 rate)
         ach = fl / (ms * 1e-3) / 1e12
         # HBM-side bytes per launch of the same kernels come from the committed PMC passes (rocprofv3 cannot be
         # driven from inside the timed process): tools/pmc_traffic.py -> profiles/rNN_traffic.json
@@ -506,7 +540,7 @@ def main():
         try:
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
             cand = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json"))
-            if cand and dtype == torch.bfloat16 and args.rank == 8 and args.config == "c2":
+            if cand and dtype != torch.float32 and args.rank == 8 and args.config == "c2":
                 traffic = json.load(open(os.path.join(pdir, cand[-1])))["traffic_bytes_per_launch"]
                 tsrc = "profiles/" + cand[-1]
         except (OSError, KeyError, ValueError):
@@ -556,6 +590,8 @@ def main():
                        "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite,
                        "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
                        "launch": args.launch,
+                       "timed_step": ("GLP_OT_SVLoRA.forward_backward(batch) - the per-batch body of run_epoch / train() "
+                                      "(SURVEY.md section 8(d))" if trainer_step else "engine.forward_backward + sgd_step"),
                        "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None},
         }
@@ -566,6 +602,8 @@ def main():
             res["config"]["fedavg_payload_bytes"] = eng.params.numel * 4
             if wl.has_buf:
                 res["config"]["fedavg_buffer_payload_bytes"] = buf_bytes
+        if engine_only:
+            res["engine_only"] = engine_only
         if roof:
             res["roofline"] = roof
         if trainer_res:
