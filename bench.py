@@ -539,8 +539,10 @@ def main():
         traffic, tsrc = None, None
         try:
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            cand = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json"))
-            if cand and dtype != torch.float32 and args.rank == 8 and args.config == "c2":
+            # configs[1]: profiles/rNN_traffic.json; configs[3] / [4]: profiles/rNN_traffic_c4.json / _c5.json (tools/pmc.sh <name> --config c4)
+            suffix = "_traffic.json" if args.config == "c2" else f"_traffic_{args.config}.json"
+            cand = sorted(f for f in os.listdir(pdir) if f.endswith(suffix))
+            if cand and dtype != torch.float32 and (args.rank == 8 or args.config != "c2"):
                 traffic = json.load(open(os.path.join(pdir, cand[-1])))["traffic_bytes_per_launch"]
                 tsrc = "profiles/" + cand[-1]
         except (OSError, KeyError, ValueError):

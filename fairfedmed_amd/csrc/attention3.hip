@@ -178,10 +178,13 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); 
 // token row of register r of a 32 x 32 accumulator for lane half h
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }   // + 4 h
 
-// (b, h) pair and half of a block id: ids b and b + 8 are the two halves of one pair
+// (b, h) pair and half of a block id: ids b and b + 8 are the two halves of one pair (one XCD under round-robin placement:
+// the second fetch of the tiles is an L2 hit).  Which id is the larger half flips every 256 ids: a CU hosts ids b, b + 256,
+// b + 512 under the placement observed, and three larger halves (12 tiles) beside three smaller ones (9) on the next CU
+// cost the launch its balance (speed only: any placement computes the same).
 __device__ __forceinline__ void unit_of_block(int bid, int& bh, int& part) {
     bh = (bid >> 4) * 8 + (bid & 7);
-    part = (bid >> 3) & 1;
+    part = ((bid >> 3) ^ (bid >> 8)) & 1;
 }
 
 // 16-byte operand fragments straight from global memory, hidden from hipcc's s_waitcnt bookkeeping: beside LDS-DMA in
@@ -232,13 +235,31 @@ __device__ __forceinline__ void store_rows(T* __restrict__ row_ptr, const f32x16
 
 template <int NT> struct Geo {
     static constexpr int NW = (NT + 1) / 2;                     // waves per block = 32-token tiles of the larger half
-    static constexpr int PPW = (4 * NT + NW - 1) / NW;          // DMA pieces per wave and tile (the waves that run out repeat their last)
-    static constexpr int CA = NT < 4 ? NT : 4, CB = NT - CA;    // swept tiles of the two DMA halves
-    static constexpr int IA = (4 * CA + NW - 1) / NW;           // piece rounds that cover the first half
+    static constexpr int NCH = (NT + 1) / 2;                    // DMA chunks of two swept tiles (64 rows = 8 pieces per operand)
+    static constexpr int RC = (8 + NW - 1) / NW;                // piece rounds per chunk and operand (waves that run out repeat a piece)
+    static constexpr int CA = NT < 4 ? NT : 4, CB = NT - CA;    // swept tiles of the forward's two softmax halves
 };
 
+// Pieces of DMA chunk c (rows 64 c .. 64 c + 63 of the two operand tiles), dealt round-robin to the NW waves.  The chunks are
+// issued ONE AHEAD of the compute ([issue c + 1][wait c][barrier][compute c]): with every piece of a block issued up front,
+// the waves sat in the ISSUE of their DMA for the whole load (in-kernel stamps: 6 400 of a wave's 17 700 cycles; the CU's
+// memory path holds ~70 KB in flight, three blocks ask for 153 KB) and the first MFMA waited for the last byte.
+template <typename T, int NT>
+__device__ __forceinline__ void dma_chunk(int c, const T* __restrict__ s0, int ld0, char* t0, const T* __restrict__ s1, int ld1, char* t1,
+                                          int L, int NP, int wave, int lane) {
+    typedef Geo<NT> GE;
+#pragma unroll
+    for (int i = 0; i < GE::RC; ++i) {
+        int pc = 8 * c + wave + GE::NW * i;
+        pc = pc < 8 * c + 7 ? pc : 8 * c + 7;
+        pc = pc < NP ? pc : NP - 1;
+        dma_piece<T>(s0, ld0, L, pc, t0, lane);
+        dma_piece<T>(s1, ld1, L, pc, t1, lane);
+    }
+}
+
 // ---------------------------------------------------------------------------
-// forward: a wave owns 32 queries; S^T = K Q^T per 32-key tile, running maximum over the two DMA halves, O^T = V^T P^T
+// forward: a wave owns 32 queries; S^T = K Q^T per 32-key tile, running maximum over two halves of the keys, O^T = V^T P^T
 // ---------------------------------------------------------------------------
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
@@ -274,17 +295,13 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
         asm_load16<64>(qv[2], qp);
         asm_load16<96>(qv[3], qp);
     }
-    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+    dma_chunk<T, NT>(0, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+    if constexpr ((FFM_ATTN3_ABL & 1) != 0) {
 #pragma unroll
-    for (int i = 0; i < GE::IA; ++i) dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
-#pragma unroll
-    for (int i = 0; i < GE::IA; ++i) dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
-#pragma unroll
-    for (int i = GE::IA; i < GE::PPW; ++i) dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
-#pragma unroll
-    for (int i = GE::IA; i < GE::PPW; ++i) dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
-    constexpr int REST = GE::PPW - GE::IA;
-    if constexpr ((FFM_ATTN3_ABL & 1) != 0) { wait_frags<0>(qv); return; }
+        for (int c = 1; c < GE::NCH; ++c) dma_chunk<T, NT>(c, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+        wait_frags<0>(qv);
+        return;
+    }
     A3_STAMP(1);
 
     const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
@@ -297,95 +314,101 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
         for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     frag qf[4];
 
-    auto chunk = [&](auto F0_, auto CF_, auto FIRST_) {
-        constexpr int F0 = decltype(F0_)::value, CF = decltype(CF_)::value;
-        constexpr bool FIRST = decltype(FIRST_)::value;
-        // K tiles of this half have landed (all waves' pieces: barrier)
-        if constexpr (FIRST) {
-            wait_frags<GE::IA + 2 * REST>(qv);
+    // chunk c has landed in every wave's view: issue the next one first (its issue stalls on the memory path about as long
+    // as this wait would anyway), then the counted wait for c, then the barrier
+    auto chunk_ready = [&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        if constexpr (c + 1 < GE::NCH) dma_chunk<T, NT>(c + 1, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+        constexpr int pend = c + 1 < GE::NCH ? 2 * GE::RC : 0;
+        if constexpr (c == 0) {
+            wait_frags<pend>(qv);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(frag, qv[ks]);
         } else {
-            wait_vm<REST>();
+            wait_vm<pend>();
         }
         block_sync();
-        A3_STAMP(FIRST ? 2 : 7);
-        if (active) {
-            f32x16 s[CF];
-            float mx = m;
+    };
+
+    auto half = [&](auto F0_, auto CF_, auto FIRST_) {
+        constexpr int F0 = decltype(F0_)::value, CF = decltype(CF_)::value;
+        constexpr bool FIRST = decltype(FIRST_)::value;
+        f32x16 s[CF];
+        float mx = m;
 #pragma unroll
-            for (int f = 0; f < CF; ++f) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int t = F0 + f;
-                f32x16 acc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = A3<T>::mma(row_frag<T>(Ks, ra, t, ks), qf[ks], acc);
-                if (F0 + f == NT - 1) {                         // only the last key tile can straddle L
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (32 * (NT - 1) + acc_row(e) + 4 * h >= L) acc[e] = -INFINITY;
-                }
-                s[f] = acc;
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+        for (int f = 0; f < CF; ++f) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            if ((F0 + f) % 2 == 0) {                            // tile F0 + f opens DMA chunk (F0 + f) / 2
+                if ((F0 + f) / 2 == 0) chunk_ready(std::integral_constant<int, 0>{});
+                if ((F0 + f) / 2 == 1) chunk_ready(std::integral_constant<int, (GE::NCH > 1 ? 1 : 0)>{});
+                if ((F0 + f) / 2 == 2) chunk_ready(std::integral_constant<int, (GE::NCH > 2 ? 2 : 0)>{});
+                if ((F0 + f) / 2 == 3) chunk_ready(std::integral_constant<int, (GE::NCH > 3 ? 3 : 0)>{});
+                if (F0 + f == 0) A3_STAMP(2);
             }
-            A3_STAMP(FIRST ? 3 : 8);
-            mx = fmaxf(mx, xhalf(mx));
-            const float mc = mx * A3_C;
-            if constexpr (!FIRST) {
-                // running maximum: everything accumulated so far is rescaled by 2^(c (m - mx))
-                const float alpha = __builtin_amdgcn_exp2f((m - mx) * A3_C);
-                l *= alpha;
+            if (!active) continue;
+            const int t = F0 + f;
+            f32x16 acc;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            for (int ks = 0; ks < 4; ++ks) acc = A3<T>::mma(row_frag<T>(Ks, ra, t, ks), qf[ks], acc);
+            if (F0 + f == NT - 1) {                             // only the last key tile can straddle L
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (32 * (NT - 1) + acc_row(e) + 4 * h >= L) acc[e] = -INFINITY;
             }
-            m = mx;
+            s[f] = acc;
 #pragma unroll
-            for (int f = 0; f < CF; ++f)
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(mx, fmaxf(acc[e], acc[e + 1]));
+        }
+        if (!active) return;
+        mx = fmaxf(mx, xhalf(mx));
+        const float mc = mx * A3_C;
+        if constexpr (!FIRST) {
+            // running maximum: everything accumulated so far is rescaled by 2^(c (m - mx))
+            const float alpha = __builtin_amdgcn_exp2f((m - mx) * A3_C);
+            l *= alpha;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[f][e], A3_C, -mc));
-                    s[f][e] = p;
-                    l += p;
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+        }
+        m = mx;
+        float l4[4] = {0.f, 0.f, 0.f, 0.f};                     // four partial sums: no 64-deep chain of dependent adds
+#pragma unroll
+        for (int f = 0; f < CF; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[f][e], A3_C, -mc));
+                s[f][e] = p;
+                l4[e & 3] += p;
+            }
+        l += (l4[0] + l4[1]) + (l4[2] + l4[3]);
+#pragma unroll
+        for (int f = 0; f < CF; ++f) {
+            const int t = F0 + f;
+            if (F0 + f == NT - 1) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    if (st == 1 && skip_last_step) break;
+                    const frag pf = pack8<T>(s[f], st);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag_clamped<T>(Vs, lane, t, st, dt, rmax), pf, o[dt]);
                 }
-            A3_STAMP(FIRST ? 4 : 9);
-            // V tiles of this half have landed
-            if constexpr (FIRST) wait_vm<2 * REST>(); else wait_vm<0>();
-            block_sync();
-            A3_STAMP(FIRST ? 5 : 10);
+            } else {
 #pragma unroll
-            for (int f = 0; f < CF; ++f) {
-                const int t = F0 + f;
-                if (F0 + f == NT - 1) {
+                for (int st = 0; st < 2; ++st) {
+                    const frag pf = pack8<T>(s[f], st);
 #pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        if (st == 1 && skip_last_step) break;
-                        const frag pf = pack8<T>(s[f], st);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag_clamped<T>(Vs, lane, t, st, dt, rmax), pf, o[dt]);
-                    }
-                } else {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        const frag pf = pack8<T>(s[f], st);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag<T>(Vs, ta, t, st, dt), pf, o[dt]);
-                    }
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = A3<T>::mma(tr_frag<T>(Vs, ta, t, st, dt), pf, o[dt]);
                 }
             }
-            A3_STAMP(FIRST ? 6 : 11);
-        } else {
-            if constexpr (FIRST) wait_vm<2 * REST>(); else wait_vm<0>();
-            block_sync();
         }
     };
-    chunk(std::integral_constant<int, 0>{}, std::integral_constant<int, GE::CA>{}, std::true_type{});
-    if constexpr (GE::CB > 0) chunk(std::integral_constant<int, GE::CA>{}, std::integral_constant<int, GE::CB>{}, std::false_type{});
+    half(std::integral_constant<int, 0>{}, std::integral_constant<int, GE::CA>{}, std::true_type{});
+    if constexpr (GE::CB > 0) half(std::integral_constant<int, GE::CA>{}, std::integral_constant<int, GE::CB>{}, std::false_type{});
+    A3_STAMP(3);
     if (!active) return;
 
     l += xhalf(l);
@@ -393,7 +416,7 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
         store_rows<T>(out + ((size_t)b * L + q) * E + hd * HD, o, 1.0f / l, lane);
         if (h == 0 && lse) lse[((size_t)b * heads + hd) * L + q] = m * 0.125f + __logf(l);
     }
-    A3_STAMP(12);
+    A3_STAMP(4);
     A3_RSTAMP(15);
 }
 
@@ -437,28 +460,22 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
         asm_load16<0>(ov[0], op); asm_load16<32>(ov[1], op); asm_load16<64>(ov[2], op); asm_load16<96>(ov[3], op);
         asm_load4(lq, lse + ((size_t)b * heads + hd) * L + qr);
     }
-    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+    dma_chunk<T, NT>(0, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+    constexpr bool LOADS_ONLY = (FFM_ATTN3_ABL & 1) != 0;
+    if constexpr (LOADS_ONLY || GE::NCH > 1) {
 #pragma unroll
-    for (int i = 0; i < GE::IA; ++i) {
-        dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
-        dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
+        for (int c = 1; c < (LOADS_ONLY ? GE::NCH : 2); ++c) dma_chunk<T, NT>(c, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
     }
-#pragma unroll
-    for (int i = GE::IA; i < GE::PPW; ++i) {
-        dma_piece<T>(base + E, ld, L, piece(i), Ks, lane);
-        dma_piece<T>(base + 2 * E, ld, L, piece(i), Vs, lane);
-    }
-    constexpr int REST = GE::PPW - GE::IA;
     const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
     const bool skip_last_step = L - 32 * (NT - 1) <= 16;
 
-    // the 13 fragment loads are older than every DMA piece: they are back when the first half's pieces are
+    // the 13 fragment loads are older than every DMA piece: they are back when chunk 0's pieces are
     asm volatile("s_waitcnt vmcnt(%13)"
                  : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(dov[0]), "+v"(dov[1]), "+v"(dov[2]), "+v"(dov[3]),
                    "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(lq)
-                 : "n"((FFM_ATTN3_ABL & 1) ? 0 : 2 * REST)
+                 : "n"(LOADS_ONLY ? 0 : GE::NCH > 1 ? 2 * GE::RC : 0)
                  : "memory");
-    if constexpr ((FFM_ATTN3_ABL & 1) != 0) return;
+    if constexpr (LOADS_ONLY) return;
     frag qf[4], dof[4];
     float dl = 0.f;
 #pragma unroll
@@ -509,23 +526,23 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
             }
         }
     };
-    block_sync();                                                               // first half of K and V landed
-    if (active) {
-        if constexpr (GE::CA > 0) tile(std::integral_constant<int, 0>{});
-        if constexpr (GE::CA > 1) tile(std::integral_constant<int, 1>{});
-        if constexpr (GE::CA > 2) tile(std::integral_constant<int, 2>{});
-        if constexpr (GE::CA > 3) tile(std::integral_constant<int, 3>{});
-    }
-    if constexpr (GE::CB > 0) {
-        wait_vm<0>();
+    // chunk c: [issue c + 2 ... no: c + 1 was issued one step ago][wait c][barrier][tiles 2c, 2c + 1]
+    auto chunk = [&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        if constexpr (c > 0) {                                                  // (chunk 1 rode with the prologue)
+            if constexpr (c + 1 < GE::NCH) dma_chunk<T, NT>(c + 1, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+            wait_vm<(c + 1 < GE::NCH ? 2 * GE::RC : 0)>();
+        }
         block_sync();
         if (active) {
-            if constexpr (GE::CB > 0) tile(std::integral_constant<int, GE::CA + 0>{});
-            if constexpr (GE::CB > 1) tile(std::integral_constant<int, GE::CA + 1>{});
-            if constexpr (GE::CB > 2) tile(std::integral_constant<int, GE::CA + 2>{});
-            if constexpr (GE::CB > 3) tile(std::integral_constant<int, GE::CA + 3>{});
+            tile(std::integral_constant<int, 2 * c>{});
+            if constexpr (2 * c + 1 < NT) tile(std::integral_constant<int, 2 * c + 1>{});
         }
-    }
+    };
+    chunk(std::integral_constant<int, 0>{});
+    if constexpr (GE::NCH > 1) chunk(std::integral_constant<int, 1>{});
+    if constexpr (GE::NCH > 2) chunk(std::integral_constant<int, 2>{});
+    if constexpr (GE::NCH > 3) chunk(std::integral_constant<int, 3>{});
     if (active && q < L) store_rows<T>(dqkv + ((size_t)b * L + q) * ld + hd * HD, dq, 0.125f, lane);
 }
 
@@ -582,27 +599,22 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
             asm_load4(dv_[j], delta + o);
         }
     }
-    auto piece = [&](int i) { const int pc = wave + GE::NW * i; return pc < NP ? pc : NP - 1; };
+    dma_chunk<T, NT>(0, base, ld, Qs, dob, E, dOs, L, NP, wave, lane);
+    constexpr bool LOADS_ONLY = (FFM_ATTN3_ABL & 1) != 0;
+    if constexpr (LOADS_ONLY || GE::NCH > 1) {
 #pragma unroll
-    for (int i = 0; i < GE::IA; ++i) {
-        dma_piece<T>(base, ld, L, piece(i), Qs, lane);
-        dma_piece<T>(dob, E, L, piece(i), dOs, lane);
+        for (int c = 1; c < (LOADS_ONLY ? GE::NCH : 2); ++c) dma_chunk<T, NT>(c, base, ld, Qs, dob, E, dOs, L, NP, wave, lane);
     }
-#pragma unroll
-    for (int i = GE::IA; i < GE::PPW; ++i) {
-        dma_piece<T>(base, ld, L, piece(i), Qs, lane);
-        dma_piece<T>(dob, E, L, piece(i), dOs, lane);
-    }
-    constexpr int REST = GE::PPW - GE::IA;
     const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
     const bool skip_last_step = L - 32 * (NT - 1) <= 16;
 
     asm volatile("s_waitcnt vmcnt(%12)"
                  : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]),
                    "+v"(lv[0]), "+v"(lv[1]), "+v"(dv_[0]), "+v"(dv_[1])
-                 : "n"((FFM_ATTN3_ABL & 1) ? 0 : 2 * REST)
+                 : "n"(LOADS_ONLY ? 0 : GE::NCH > 1 ? 2 * GE::RC : 0)
                  : "memory");
-    if constexpr ((FFM_ATTN3_ABL & 1) != 0) return;
+    if constexpr (LOADS_ONLY) return;
+    A3_STAMP(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = tid + j * NTH;
@@ -665,34 +677,30 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
             }
         }
     };
-    A3_STAMP(1);
-    block_sync();                                                               // first half of Q and dO, lse_s, del_s
-    A3_STAMP(2);
-    if (active) {
-        if constexpr (GE::CA > 0) tile(std::integral_constant<int, 0>{});
-        if constexpr (GE::CA > 1) tile(std::integral_constant<int, 1>{});
-        if constexpr (GE::CA > 2) tile(std::integral_constant<int, 2>{});
-        if constexpr (GE::CA > 3) tile(std::integral_constant<int, 3>{});
-    }
-    A3_STAMP(3);
-    if constexpr (GE::CB > 0) {
-        wait_vm<0>();
-        block_sync();
-        A3_STAMP(4);
-        if (active) {
-            if constexpr (GE::CB > 0) tile(std::integral_constant<int, GE::CA + 0>{});
-            if constexpr (GE::CB > 1) tile(std::integral_constant<int, GE::CA + 1>{});
-            if constexpr (GE::CB > 2) tile(std::integral_constant<int, GE::CA + 2>{});
-            if constexpr (GE::CB > 3) tile(std::integral_constant<int, GE::CA + 3>{});
+    auto chunk = [&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        if constexpr (c > 0) {                                                  // (chunk 1 rode with the prologue)
+            if constexpr (c + 1 < GE::NCH) dma_chunk<T, NT>(c + 1, base, ld, Qs, dob, E, dOs, L, NP, wave, lane);
+            wait_vm<(c + 1 < GE::NCH ? 2 * GE::RC : 0)>();
         }
-    }
-    A3_STAMP(5);
+        block_sync();                                                           // (chunk 0: also lse_s, del_s)
+        if constexpr (c == 0) A3_STAMP(2);
+        if (active) {
+            tile(std::integral_constant<int, 2 * c>{});
+            if constexpr (2 * c + 1 < NT) tile(std::integral_constant<int, 2 * c + 1>{});
+        }
+    };
+    chunk(std::integral_constant<int, 0>{});
+    if constexpr (GE::NCH > 1) chunk(std::integral_constant<int, 1>{});
+    if constexpr (GE::NCH > 2) chunk(std::integral_constant<int, 2>{});
+    if constexpr (GE::NCH > 3) chunk(std::integral_constant<int, 3>{});
+    A3_STAMP(3);
     if (active && key < L) {
         T* drow = dqkv + ((size_t)b * L + key) * ld + hd * HD;
         store_rows<T>(drow + E, dk, 0.125f, lane);
         store_rows<T>(drow + 2 * E, dv, 1.0f, lane);
     }
-    A3_STAMP(6);
+    A3_STAMP(4);
     A3_RSTAMP(15);
 }
 

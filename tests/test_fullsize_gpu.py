@@ -238,3 +238,44 @@ def test_full_rn50_bf16_step_against_the_bf16_storage_control():
     assert le <= 2.0 * lc + 0.01, (le, lc)
     assert e_med >= c_med - 0.03 and e_p5 >= c_p5 - 0.05 and e_min >= min(c_min - 0.1, 0.7), ((e_min, e_p5, e_med), (c_min, c_p5, c_med))
     assert e_min > 0.5                                                # no tensor on the wrong side
+
+
+def test_zz_3d_oct_at_bench_size_f32_and_16bit_vs_oracle():
+    """configs[3] at the size `bench.py --config c4` TIMES (4 volumes of 200 x 224 x 224 -> 100 ViT images, 19 700 token
+    rows, rank 16, four different attribute values) against the ORACLE: the fp32 engine to fp32 tolerances, and the two
+    16-bit engines (whose FairLoRA products run on the 208 x 384 panel at three rounds of tiles) directly against the
+    oracle as well, so the timed shape no longer leans on the repo's own fp32 engine as its reference.  One ~40 s CPU
+    step; kept last in the file (pytest runs a file's tests in definition order)."""
+    from fairfedmed_amd.engine import FairLoRAEngine
+    from oracle import fairlora_oracle as O
+    mcfg = dataclasses.replace(C.vit_b16(rank=16), dim_per_3d_slice=8)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    B, S = 4, 25
+    batch = synth.make_batch(mcfg, B, seed=3, slices=S, signal=0.2)
+    batch["attrs"][:, 0] = torch.tensor([2, 0, 1, 0])
+    keys = synth.trainable_keys(mcfg)
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    loss, logits, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
+        eng = FairLoRAEngine(mcfg, sd, dtype=dtype, max_images=B * S)
+        out = eng.forward_backward(*to_dev(batch))
+        torch.cuda.synchronize()
+        f32 = dtype == torch.float32
+        assert int(out["finite"]) == 1 and tuple(out["logits"].shape) == (B, 2)
+        assert abs(float(out["loss"]) - float(loss)) <= (1e-4 if f32 else 1e-2) * abs(float(loss)), (dtype, float(out["loss"]), float(loss))
+        assert rel(out["logits"], logits) < (1e-4 if f32 else 5e-2), (dtype, rel(out["logits"], logits))
+        worst, werr = 1.0, 0.0
+        for k in keys:
+            g, ref = eng.params.view(k, "grad"), grads[k]
+            if float(ref.abs().max()) == 0.0:
+                assert float(g.abs().max()) < 1e-12, k
+                continue
+            worst, werr = min(worst, cos(g, ref)), max(werr, rel(g, ref))
+            if f32:
+                assert rel(g, ref) < 5e-3, (k, rel(g, ref))
+            else:
+                assert cos(g, ref) > 0.97, (dtype, k, cos(g, ref))
+        print("oct3d B=4 r=16", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits),
+              "worst gradient cosine", worst, "worst rel err", werr)
+        del eng
+        torch.cuda.empty_cache()

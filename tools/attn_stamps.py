@@ -29,10 +29,10 @@ for _ in range(20):                              # warm clocks
 torch.cuda.synchronize()
 if which == "fwd":
     ops.attention_fwd(qkv, out, lse, B, L, H, False)
-    names = ["entry", "DMA issued", "K_A landed", "S_A + max", "exp_A", "V_A landed", "PV_A", "K_B landed", "S_B + max", "exp_B", "V_B landed", "PV_B", "stored"]
+    names = ["entry", "prologue issued", "chunk 0 landed", "all tiles done", "stored"]
 else:
     ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, H, False)      # the dq kernel carries no stamps: dkv's remain
-    names = ["entry", "loads issued + frags back", "first half landed", "tiles 0-3", "second half landed", "tiles 4-6", "stored"]
+    names = ["entry", "prologue issued + frags back", "chunk 0 landed", "all tiles done", "stored"]
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 768 * 4 * 16

@@ -1,12 +1,13 @@
 #!/bin/bash
 # PMC passes of bench.py on the GPU box (separate passes, --kernel-trace only, as the guide prescribes):
-#   tools/pmc.sh <name>  ->  gpurun_out/<name>_fetch.csv, _write.csv, _sq.csv
+#   tools/pmc.sh <name> [extra bench.py flags, e.g. --config c4]  ->  gpurun_out/<name>_fetch.csv, _write.csv, _sq.csv
+#   PMC_PASSES="fetch write" limits the passes
 set -e
-name=$1
+name=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 2 --serial --no-cpu-baseline --no-trainer --no-secondary --no-roofline"
-for pass in fetch write sq; do
+B="python3 $R/bench.py --steps 3 --warmup 2 --serial --no-cpu-baseline --no-trainer --no-secondary --no-roofline --engine-step $@"
+for pass in ${PMC_PASSES:-fetch write sq}; do
     case $pass in
         fetch) C="FETCH_SIZE";;
         write) C="WRITE_SIZE";;

@@ -16,16 +16,19 @@ import sys
 from collections import defaultdict
 
 
+MIN_WGS = int(sys.argv[3]) if len(sys.argv) > 3 else 200      # (RN50, --config c5: 40 - its layer3 / layer4 products launch 52-208 tiles)
+
+
 def load(path, counter):
     per = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r.get("Counter_Name") != counter:
             continue
         name = r["Kernel_Name"]
-        if "gemm_panel_kernel" not in name and "gemm_nt_kernel" not in name:
+        if "gemm_panel_kernel" not in name and "gemm_nt_kernel" not in name and "conv_narrow_kernel" not in name:
             continue
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1) if r.get("Grid_Size") else 0
-        if wgs < 200:
+        if wgs < MIN_WGS:
             continue
         short = re.sub(r"\(anonymous namespace\)::|ffm_panel::|void |\(ffm_gemm_args\)", "", name)[:60]
         per[short][0] += 1
