@@ -565,6 +565,17 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
         }
     };
+    // Two waves per SIMD: the second-dispatched half (waves 4-7) loses every issue arbitration to its older partner (priority,
+    // then age: MI355X_MICROARCH.md, "Two waves per SIMD", item 4).  ONE static s_setprio 1 for that half in front of the
+    // loop, no per-segment flips; back to 0 for the epilogue.  Measured (round 4, A/B in one gpurun call, three alternating pairs of
+    // 40-step runs): 4.9376 / 4.9423 / 4.9213 ms per step with it, 4.9328 / 4.9497 / 4.9245 without - nothing; off by default
+    // (-DFFM_PANEL_PRIO=1 builds it).
+#ifndef FFM_PANEL_PRIO
+#define FFM_PANEL_PRIO 0
+#endif
+    if constexpr (PW == 8 && !KS && FFM_PANEL_PRIO) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
     if constexpr (WSPEC) {                                       // one copy of the loop per column slab (see half())
         static_for<CW>([&](auto WW_) {
             if (colw == decltype(WW_)::value) main_loop(WW_);
@@ -572,6 +583,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     } else {
         main_loop(I0{});
     }
+    if constexpr (PW == 8 && !KS && FFM_PANEL_PRIO) __builtin_amdgcn_s_setprio(0);
     // the asm MFMAs are invisible to the hazard recogniser: let the last ones retire before the accumulators are read
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();                                                  // the ring is free from here on

@@ -29,6 +29,30 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ffm_abi_version() == _lib.ABI_VERSION
 
 
+def test_every_dtype_entry_point_has_a_half_twin_behind_one_dispatcher():
+    """fairfedmed_amd/build.py: every prototype with a `dtype` parameter is defined once by the generated dispatcher
+    (public name) and twice below it - `<name>_m` (float32 / bfloat16 / FFM_F32_X3) and `<name>_f16` (FFM_F16, the same
+    source compiled with -DFFM_TWIN_F16); FFM_F16 reaches the twin, everything else the main object."""
+    from fairfedmed_amd import build as B
+    protos = B.api_prototypes()
+    typed = [n for _, n, params in protos if any(a == "dtype" for _, a in params)]
+    assert len(protos) >= 60 and len(typed) >= 37
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in typed:
+        assert hasattr(lib, n) and hasattr(lib, n + "_m") and hasattr(lib, n + "_f16"), n
+    disp = open(B.GEN_DISPATCH).read()
+    for n in typed:
+        assert f"dtype == FFM_F16 ? {n}_f16(" in disp and f": {n}_m(" in disp, n
+    # argument validation of both twins without a GPU: null pointers are rejected on every path, never dereferenced
+    l = _lib.load()
+    for code in (_lib.F32, _lib.BF16, _lib.F16):
+        assert l.ffm_layernorm_fwd(None, None, None, None, None, None, 4, 768, code, None) == -1
+        assert l.ffm_attention_fwd(None, None, None, 2, 197, 12, 0, code, None) == -1
+    assert l.ffm_lora_down_blocks(6304, 768, 8, _lib.F16) == l.ffm_lora_down_blocks(6304, 768, 8, _lib.BF16) > 0
+    assert l.ffm_gemm_tiles_m(6304, 3072, 768, 0, 0, _lib.F16, 1) == l.ffm_gemm_tiles_m(6304, 3072, 768, 0, 0, _lib.BF16, 1) > 0
+    assert l.ffm_scale_check(None, 1.0, 4, None, None) == -1
+
+
 def test_argument_validation_needs_no_gpu():
     lib = _lib.load()
     args = _lib.GemmArgs()                          # null pointers
