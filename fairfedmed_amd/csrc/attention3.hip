@@ -178,13 +178,24 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); 
 // token row of register r of a 32 x 32 accumulator for lane half h
 __device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }   // + 4 h
 
-// (b, h) pair and half of a block id: ids b and b + 8 are the two halves of one pair (one XCD under round-robin placement:
-// the second fetch of the tiles is an L2 hit).  Which id is the larger half flips every 256 ids: a CU hosts ids b, b + 256,
-// b + 512 under the placement observed, and three larger halves (12 tiles) beside three smaller ones (9) on the next CU
-// cost the launch its balance (speed only: any placement computes the same).
-__device__ __forceinline__ void unit_of_block(int bid, int& bh, int& part) {
-    bh = (bid >> 4) * 8 + (bid & 7);
-    part = ((bid >> 3) ^ (bid >> 8)) & 1;
+// (batch, head) pair and half of a block id.  Block ids b, b + 8, b + 16, ... share an XCD under the round-robin placement
+// observed (speed only: any placement computes the same), so XCD label x = b & 7 takes the CONTIGUOUS range of units
+// [x U/8, (x + 1) U/8): the two halves of a pair sit on one XCD (the second fetch of the tiles is an L2 hit), and so do all
+// heads of an image - the images whose qkv rows (and dO rows in the backward) the panel GEMM in front of this kernel produced
+// on the same XCD (its xcd_remap gives XCD x whole row bands: ~4 images of 197 rows at batch 32).  FFM_ATTN3_MAP=0 (A/B
+// runs) spreads an image's heads over the XCDs as rounds 2-3 did.  Which unit of a pair is the larger half flips every 32
+// units of an XCD: a CU hosts units j, j + 32, j + 64 of its XCD's range, and three larger halves (12 tiles) beside three
+// smaller ones (9) on the next CU cost the launch its balance.
+__device__ __forceinline__ void unit_of_block(int bid, int& bh, int& part, int map) {
+    if (map) {
+        const int per = gridDim.x >> 3, j = bid >> 3;
+        const int u = (bid & 7) * per + j;
+        bh = u >> 1;
+        part = (u ^ (j >> 5)) & 1;
+    } else {
+        bh = (bid >> 4) * 8 + (bid & 7);
+        part = ((bid >> 3) ^ (bid >> 8)) & 1;
+    }
 }
 
 // 16-byte operand fragments straight from global memory, hidden from hipcc's s_waitcnt bookkeeping: beside LDS-DMA in
@@ -263,7 +274,7 @@ __device__ __forceinline__ void dma_chunk(int c, const T* __restrict__ s0, int l
 // ---------------------------------------------------------------------------
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse, int L, int heads, int BH) {
+void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse, int L, int heads, int BH, int map) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -271,7 +282,7 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
     char* Ks = smem;                                            // [R8][128 B]; reads past it land in Vs
     char* Vs = smem + R8 * 128;
     int bh, part;
-    unit_of_block(blockIdx.x, bh, part);
+    unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
     const int b = bh / heads, hd = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -427,7 +438,7 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
-                         const T* __restrict__ o_fwd, T* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, int BH) {
+                         const T* __restrict__ o_fwd, T* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, int BH, int map) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -435,7 +446,7 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
     char* Ks = smem;
     char* Vs = smem + R8 * 128;
     int bh, part;
-    unit_of_block(blockIdx.x, bh, part);
+    unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
     const int b = bh / heads, hd = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -555,7 +566,7 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
-                          const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH) {
+                          const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH, int map) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -565,7 +576,7 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);              // [32 NT]: -8 lse (-inf beyond L)
     float* del_s = lse_s + 32 * NT;                                             // [32 NT]: -delta (0 beyond L)
     int bh, part;
-    unit_of_block(blockIdx.x, bh, part);
+    unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
     const int b = bh / heads, hd = bh % heads;
     const int E = heads * HD, ld = 3 * E;
@@ -704,6 +715,11 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     A3_RSTAMP(15);
 }
 
+inline int a3_map() {
+    static const int m = (getenv("FFM_ATTN3_MAP") && getenv("FFM_ATTN3_MAP")[0] == '0') ? 0 : 1;
+    return m;
+}
+
 template <typename F> int set_lds3(F fn, int bytes) {
     if (bytes > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -718,7 +734,7 @@ int run_fwd3(const void* qkv, void* out, float* lse, int B, int L, int heads, hi
     int e = set_lds3(attn3_fwd_kernel<T, NT>, lds);
     if (e) return e;
     hipLaunchKernelGGL((attn3_fwd_kernel<T, NT>), dim3(((BH + 7) / 8) * 16), dim3(64 * Geo<NT>::NW), lds, s, (const T*)qkv, (T*)out, lse, L,
-                       heads, BH);
+                       heads, BH, a3_map());
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -732,10 +748,10 @@ int run_bwd3(const void* qkv, const void* out, const void* dout, const float* ls
     if (e) return e;
     const dim3 grid(((BH + 7) / 8) * 16), block(64 * Geo<NT>::NW);
     hipLaunchKernelGGL((attn3_bwd_dq_kernel<T, NT>), grid, block, lds_dq, s, (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv,
-                       delta, L, heads, BH);
+                       delta, L, heads, BH, a3_map());
     FFM_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn3_bwd_dkv_kernel<T, NT>), grid, block, lds_dkv, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta,
-                       (T*)dqkv, L, heads, BH);
+                       (T*)dqkv, L, heads, BH, a3_map());
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

@@ -5,6 +5,11 @@
 // up to 8 K32 steps before the first MFMA, and the partial accumulators meet in LDS: N/16 = 32..128 blocks.
 // Operand types: see SkOps; epilogues: none, bias, bias+residual, bias+GELU, dGELU.
 #include "gemm_panel.h"
+#include <cstdlib>
+
+#ifndef FFM_SKINNY_CAP_DEFAULT
+#define FFM_SKINNY_CAP_DEFAULT 0
+#endif
 
 namespace {
 
@@ -76,10 +81,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * SK_COLS;
     const int nmf = (p.M + 15) >> 4;                               // 1..4 row fragments (uniform)
     const int kw = p.K / NW, k0 = wave * kw;                       // this wave's K range, a multiple of KS
     const TA* A = reinterpret_cast<const TA*>(p.a);
+    // A block walks the 16-column tiles blockIdx.x, blockIdx.x + gridDim.x, ...: with the grid capped (sk_grid below) the
+    // launch holds a handful of CUs instead of N / 16 of them for about as long - a tile is one memory round trip.
+    for (int tile = blockIdx.x; tile < p.N / SK_COLS; tile += gridDim.x) {
+    const int n0 = tile * SK_COLS;
     const TB* bp = reinterpret_cast<const TB*>(p.b) + (size_t)(n0 + col) * p.ldb + k0 + kg * KG;
     const TA* ap[SK_MF];
 #pragma unroll
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
             if (mf < nmf) red[wave - 1][mf][lane] = acc[mf];
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
     const int n = n0 + col;
     const float bias = (FL & FFM_EPI_BIAS) ? p.bias[n] : 0.f;
     TA* C = reinterpret_cast<TA*>(p.c);
@@ -144,11 +152,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
             if (FL & FFM_EPI_GELU) reinterpret_cast<TA*>(p.c2)[o] = (TA)Act<TA>::gelu(x);
         }
     }
+    }
+    if (tile + (int)gridDim.x < p.N / SK_COLS) __syncthreads();   // `red` is rewritten by the next tile
+    }
+}
+
+// Blocks per launch.  Every block of the vision tower's single-round panel GEMMs needs a whole CU, and a panel launch leaves
+// 8-16 of the 256 idle: a side-stream launch that holds more CUs than that when a panel starts keeps some of its blocks
+// waiting (the side streams cost the chain ~0.4 ms per step).  FFM_SKINNY_CAP=<n> caps the grid at n
+// blocks (0 = one block per tile).
+inline int sk_grid(int tiles) {
+    static const int cap = getenv("FFM_SKINNY_CAP") ? atoi(getenv("FFM_SKINNY_CAP")) : FFM_SKINNY_CAP_DEFAULT;
+    return cap > 0 && tiles > cap ? cap : tiles;
 }
 
 template <typename TA, typename TB, bool X3, int NW, int FL>
 int launch(const ffm_gemm_args& a, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB, X3, NW, FL>), dim3(a.N / SK_COLS), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB, X3, NW, FL>), dim3(sk_grid(a.N / SK_COLS)), dim3(NW * 64), 0, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
