@@ -237,3 +237,44 @@ def test_prec_amp_trains_without_the_attribute():
     with_attr, _, _ = O.loss_and_grads(sd, batch, mcfg, synth.trainable_keys(mcfg))
     assert abs(s["loss"] - float(ref_loss)) <= 2e-5 * abs(float(ref_loss))
     assert abs(float(ref_loss) - float(with_attr)) > 1e-6             # the two mixes do differ on this batch
+
+
+def test_fp16_gradient_scale_and_overflow_guard():
+    """IEEE-half mode: the backward pass runs scaled (x 2^12 on dloss/dlogits, out again on the fp32 gradient buffer:
+    ffm_scale_check).  (1) the scale leaves no trace in the result: 2^12 and 2^8 give the same gradients to rounding, and no
+    scale at all is visibly worse against the oracle on the smallest gradients (half's subnormals) - never better;
+    (2) an absurd scale overflows half, the unscaled buffer holds inf / nan, and the device-side finite flag is cleared, which
+    the trainer raises as the reference's FloatingPointError (Dassl/dassl/engine/trainer.py:260-262)."""
+    from fairfedmed_amd.engine import FairLoRAEngine
+    from oracle import fairlora_oracle as O
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 8, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    img, attr, label = batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
+    _, _, grads = O.loss_and_grads(sd, batch, mcfg, keys)
+
+    def run(scale):
+        eng = FairLoRAEngine(mcfg, sd, dtype=torch.float16, max_images=8)
+        eng.grad_scale = float(scale)
+        out = eng.forward_backward(img, attr, label)
+        torch.cuda.synchronize()
+        return int(out["finite"]), {k: eng.params.view(k, "grad").clone() for k in keys}
+
+    f12, g12 = run(4096.0)
+    f8, g8 = run(256.0)
+    f0, g0 = run(1.0)
+    assert f12 == 1 and f8 == 1 and f0 == 1
+    worst = {1.0: 0.0, 256.0: 0.0, 4096.0: 0.0}
+    for k in keys:
+        ref = grads[k]
+        if float(ref.abs().max()) == 0.0:
+            continue
+        assert rel(g12[k], g8[k]) < 2e-3, (k, rel(g12[k], g8[k]))
+        for s, g in ((1.0, g0), (256.0, g8), (4096.0, g12)):
+            worst[s] = max(worst[s], rel(g[k], ref))
+    print("fp16 worst gradient error vs the oracle by scale:", worst)
+    assert worst[4096.0] <= worst[1.0] * 1.05 + 1e-6 and worst[4096.0] < 1e-2
+    fbad, gbad = run(2.0 ** 40)
+    assert fbad == 0, "an overflowing gradient scale must clear the finite flag"
+    assert not all(bool(torch.isfinite(g).all()) for g in gbad.values())

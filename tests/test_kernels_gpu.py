@@ -892,3 +892,36 @@ def test_attention3_is_the_kernel_that_runs_and_matches_the_second_generation():
     assert not torch.equal(a["out"], b["out"]), "FFM_ATTN=v2 / v3 ran the same kernel"
     assert float((a["out"].double() - b["out"].double()).abs().max()) <= 2e-2 * float(a["out"].double().abs().max())
     assert float((a["lse"] - b["lse"]).abs().max()) <= 2e-3 * float(a["lse"].abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_attention3_race_screen_bitwise_repeatable(ops, dt):
+    """attn3_* order their LDS-DMA by hand-counted s_waitcnt vmcnt(N) + raw s_barrier (no compiler-inserted waits): a read
+    placed one phase early passes a reference check whenever the DMA happens to land first.  Screen: the bench shape (768
+    blocks, three per CU) 30 times back to back, with a cache-flushing write between launches on every third run (the DMA then
+    comes from HBM instead of the Infinity Cache: different landing order), every output bit-identical to the first run's -
+    the kernels have no atomics and no run-dependent summation order."""
+    B, L, heads = 32, 197, 12
+    E = heads * 64
+    qkv = rnd(B * L, 3 * E, dt=dt, seed=901)
+    dout = rnd(B * L, E, dt=dt, seed=902)
+    flush = torch.empty(320 << 20, device="cuda", dtype=torch.uint8)
+    first = None
+    for it in range(30):
+        out = torch.full((B * L, E), float("nan"), device="cuda", dtype=dt)
+        lse = torch.full((B, heads, L), float("nan"), device="cuda")
+        dqkv = torch.full((B * L, 3 * E), float("nan"), device="cuda", dtype=dt)
+        delta = torch.full((B, heads, L), float("nan"), device="cuda")
+        if it % 3 == 1:
+            flush.fill_(it)
+        ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+        if it % 3 == 2:
+            flush.fill_(it)
+        ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, False)
+        cur = (out, lse, dqkv, delta)
+        if first is None:
+            first = cur
+            assert all(bool(torch.isfinite(t.float()).all()) for t in cur)
+        else:
+            for a, b, nm in zip(cur, first, ("out", "lse", "dqkv", "delta")):
+                assert torch.equal(a, b), f"run {it}: {nm} differs from run 0 in {int((a != b).sum())} elements"
