@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("rk", _vp), ("S", _vp), ("attr", _vp), ("t_out", _vp), ("ts_out", _vp), ("t_fwd", _vp), ("ds_part", _vp),
         ("G", _i32), ("rows_per_sample", _i32), ("scaling", _f32), ("lambda_group", _f32),
         ("b_packed", _vp), ("lw_wide", _vp),
-        ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("pad1_", _i32),
+        ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("gelu_deriv", _i32),
         ("ln_rk", _vp), ("colstat_part", _vp),
     ]
 

@@ -169,6 +169,8 @@ template <typename T> struct Act;
 template <> struct Act<float> {
     static __device__ __forceinline__ float gelu(float x) { return quick_gelu_f(x); }
     static __device__ __forceinline__ float gelu_grad(float x) { return quick_gelu_grad_f(x); }
+    // both from one call (ffm_gemm_args.gelu_deriv): the same two expressions as above, so fp32 results do not move
+    static __device__ __forceinline__ void gelu_both(float x, float& g, float& d) { g = quick_gelu_f(x); d = quick_gelu_grad_f(x); }
 };
 template <> struct Act<bf16_t> {
     // raw v_exp_f32 / v_rcp_f32 (1 ulp): __expf / __frcp_rn expand to range checks and a full IEEE division
@@ -180,6 +182,11 @@ template <> struct Act<bf16_t> {
     static __device__ __forceinline__ float gelu_grad(float x) {
         const float s = sigmoid1702(x);
         return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    static __device__ __forceinline__ void gelu_both(float x, float& g, float& d) {      // one sigmoid for both
+        const float s = sigmoid1702(x);
+        g = x * s;
+        d = s * (1.0f + 1.702f * x * (1.0f - s));
     }
 };
 

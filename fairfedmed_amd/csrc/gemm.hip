@@ -673,10 +673,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                     for (int c = 0; c < 8; ++c) v[i][c] += Elem<T>::to_f(rres[i][c / EPC][c % EPC]);
                 }
                 if (flags & FFM_EPI_DGELU) {
+                    if (p.gelu_deriv) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(Elem<T>::to_f(raux[i][c / EPC][c % EPC]));
+                        for (int c = 0; c < 8; ++c) v[i][c] *= Elem<T>::to_f(raux[i][c / EPC][c % EPC]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[i][c] *= Act<T>::gelu_grad(Elem<T>::to_f(raux[i][c / EPC][c % EPC]));
+                    }
                 }
-                Vec8<T>::store(C + off, v[i]);
+                float gd[8];
+                const bool deriv = (flags & FFM_EPI_GELU) && p.gelu_deriv;
+                if (deriv) {
+                    float ga[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) Act<T>::gelu_both(Elem<T>::to_f(Elem<T>::from_f(v[i][c])), ga[c], gd[c]);
+                    Vec8<T>::store(C + off, gd);
+                    Vec8<T>::store(reinterpret_cast<T*>(p.c2) + off, ga);
+                } else {
+                    Vec8<T>::store(C + off, v[i]);
+                }
                 if (cst) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                         cq[c] += st * st;
                     }
                 }
-                if (flags & FFM_EPI_GELU) {
+                if ((flags & FFM_EPI_GELU) && !deriv) {
                     float a[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) a[c] = Act<T>::gelu(Elem<T>::to_f(Elem<T>::from_f(v[i][c])));

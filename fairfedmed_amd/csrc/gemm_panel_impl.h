@@ -902,8 +902,13 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];
             }
             if constexpr ((flags & FFM_EPI_DGELU) != 0) {
+                if (p.gelu_deriv) {                              // (kernel argument: a scalar branch) aux holds gelu'(pre)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] *= Act<bf16_t>::gelu_grad((float)rpre[rg % PF][i][c]);
+                    for (int c = 0; c < 8; ++c) v[c] *= (float)rpre[rg % PF][i][c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] *= Act<bf16_t>::gelu_grad((float)rpre[rg % PF][i][c]);
+                }
             }
             if constexpr (ROWST) {
                 // partial LayerNorm sums of the row AS STORED (bf16): the lanes of a row are adjacent (CPR of them)
@@ -926,12 +931,21 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
             if (ok) {
                 const size_t off = (size_t)gm * p.ldc + n0w + ch * 8;
-                Vec8<bf16_t>::store(C + off, v);
                 if constexpr ((flags & FFM_EPI_GELU) != 0) {
                     float a[8];
+                    if (p.gelu_deriv) {                          // c = gelu'(x), c2 = gelu(x), x as it would have been stored
+                        float d[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) a[c] = Act<bf16_t>::gelu((float)(bf16_t)v[c]);
+                        for (int c = 0; c < 8; ++c) Act<bf16_t>::gelu_both((float)(bf16_t)v[c], a[c], d[c]);
+                        Vec8<bf16_t>::store(C + off, d);
+                    } else {
+                        Vec8<bf16_t>::store(C + off, v);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) a[c] = Act<bf16_t>::gelu((float)(bf16_t)v[c]);
+                    }
                     Vec8<bf16_t>::store(reinterpret_cast<bf16_t*>(p.c2) + off, a);
+                } else {
+                    Vec8<bf16_t>::store(C + off, v);
                 }
             }
         }

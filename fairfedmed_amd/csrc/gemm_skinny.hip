@@ -147,9 +147,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
             const size_t o = (size_t)row * p.ldc + n;
             float x = v[e] + bias;
             if (FL & FFM_EPI_RESIDUAL) x += (float)reinterpret_cast<const TA*>(p.res)[o];
-            if (FL & FFM_EPI_DGELU) x *= Act<TA>::gelu_grad((float)reinterpret_cast<const TA*>(p.aux)[o]);
-            C[o] = (TA)x;
-            if (FL & FFM_EPI_GELU) reinterpret_cast<TA*>(p.c2)[o] = (TA)Act<TA>::gelu(x);
+            if (FL & FFM_EPI_DGELU) {
+                const float ax = (float)reinterpret_cast<const TA*>(p.aux)[o];
+                x *= p.gelu_deriv ? ax : Act<TA>::gelu_grad(ax);
+            }
+            if ((FL & FFM_EPI_GELU) && p.gelu_deriv) {
+                float ga, gd;
+                Act<TA>::gelu_both(x, ga, gd);
+                C[o] = (TA)gd;
+                reinterpret_cast<TA*>(p.c2)[o] = (TA)ga;
+            } else {
+                C[o] = (TA)x;
+                if (FL & FFM_EPI_GELU) reinterpret_cast<TA*>(p.c2)[o] = (TA)Act<TA>::gelu(x);
+            }
         }
     }
     }

@@ -196,7 +196,18 @@ class _Stack:
         self.causal, self.rank, self.dtype = causal, rank, dtype
         # x3: float32 tower whose products run on the bf16 matrix cores as hi/lo pairs (FFM_F32_X3)
         # (ops.gemm_nt is looked up per call: bench.py wraps it to time the launches)
-        self.gemm = (lambda *a, **k: ops.gemm_nt(*a, x3=True, **k)) if x3 else (lambda *a, **k: ops.gemm_nt(*a, **k))
+        # FFM_GELU_DERIV=1: the MLP's saved tensor is quick_gelu'(pre) instead of pre (ffm_gemm_args.gelu_deriv): the forward's
+        # epilogue has the sigmoid in hand and nothing but the dX product of c_proj reads the pre-activation.  Measured
+        # (round 4, serial rocprofv3 of one call each): dX(c_proj) 48.86 -> 48.48 us, c_fc forward 47.18 -> 48.43 us, the step
+        # 4.869 -> 4.874 ms (three alternating pairs): the backward epilogue is not bound by the derivative's exp + rcp, and
+        # the forward pays for the extra arithmetic.  Off by default; bit-identical in fp32 either way.
+        deriv = os.environ.get("FFM_GELU_DERIV", "0") == "1"
+
+        def _gemm(*a, **k):
+            if deriv and (k.get("gelu_out") is not None or k.get("dgelu_aux") is not None):
+                k["gelu_deriv"] = True
+            return ops.gemm_nt(*a, x3=x3, **k)
+        self.gemm = _gemm
         self.blocks: List[_Block] = []
         T = max_images * tokens
         self.max_rows = T

@@ -144,9 +144,11 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
             x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
-            colstats: Optional[Tensor] = None) -> Tensor:
+            colstats: Optional[Tensor] = None, gelu_deriv: bool = False) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
-    x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores."""
+    x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores.
+    gelu_deriv (with gelu_out / dgelu_aux): `out` receives / `dgelu_aux` holds quick_gelu'(pre) instead of pre
+    (ffm_gemm_args.gelu_deriv)."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
     assert a.dtype == b.dtype == out.dtype and (not x3 or a.dtype == torch.float32)
     M, K = a.shape
@@ -185,7 +187,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
                  L.ptr(ro.ds_part), ro.S.shape[0], ro.rps, ro.scaling, ro.lam)
     else:
         extra = (None, None, None, None, None, None, None, 0, 0, 0.0, 0.0)
-    lnx = (None, None, None, None, 0, 0, None)
+    lnx = (None, None, None, None, 0, int(gelu_deriv), None)
     if rowstats is not None:                       # [tiles_n, M, 2] fp32 partial row sums of the stored output
         _dev(rowstats)
         flags |= L.EPI_ROWSTATS
@@ -196,7 +198,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         assert _f32(ln_in.part).numel() >= 2 * M * ln_in.np and _f32(ln_in.c).numel() == N and bias is not None
         _dev(ln_in.rk)
         assert (ro is None) == (ln_in.rk is None) and (ln_in.rk is None or _f32(ln_in.rk).numel() == 32)
-        lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, 0,
+        lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, int(gelu_deriv),
                L.ptr(ln_in.rk))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,

@@ -108,7 +108,14 @@ typedef struct ffm_gemm_args {
     const float* ln_c;
     float*       ln_mean;
     float*       ln_rstd;
-    int32_t      ln_np, pad1_;
+    int32_t      ln_np;
+    /* FFM_EPI_GELU / FFM_EPI_DGELU, 0 or 1.  0: `c` (GELU) receives the pre-activation and `aux` (DGELU) holds it -
+     * c *= quick_gelu'(aux).  1: the forward stores the DERIVATIVE instead, c = quick_gelu'(x) beside c2 = quick_gelu(x)
+     * (the sigmoid is shared), and the backward multiplies by what `aux` holds, c *= aux.  Nothing else reads the
+     * pre-activation of QuickGELU on this path (clip/model.py:313-332: the reference's autograd saves it for exactly this
+     * product).  Same bytes, one more rounding of the derivative in 16-bit storage, bit-identical results in fp32.
+     * Measured on MI355X: no gain - the engines leave it 0. */
+    int32_t      gelu_deriv;
     /* FFM_EPI_LNIN with FFM_EPI_RANKOP: rk holds (gamma (.) lora_A)^T and ln_rk [2][16] its corrections
      * {c_j = sum_k rk[j][k], d_j = sum_k beta_k lora_A[k][j]} (ffm_lora_pack_multi writes both):
      * t = rstd (x rk^T - mu c) + d = LayerNorm(x) lora_A */

@@ -146,13 +146,15 @@ def test_gemm_panel_plain(ops, M, N, K, mode, h16):
     check(out, out2.double(), 1e-2, "panel vs 128x128")
 
 
-@pytest.mark.parametrize("case", ["fc_fwd", "proj_fwd", "proj_dx", "fc_dx"])
+@pytest.mark.parametrize("case", ["fc_fwd", "proj_fwd", "proj_dx", "fc_dx", "proj_dx_deriv"])
 @pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (5500, 16, 2, False), (6304, 4, 3, True)])
 @H16
 def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr, h16):
     """The four FairLoRA GEMMs of a block on the panel kernel: t / ts / dS partials / fused rank-r update / GELU."""
     dt = h16
     width, rps = 768, 197
+    deriv = case == "proj_dx_deriv"               # dX(c_proj) with the saved tensor = quick_gelu'(pre) (gelu_deriv)
+    case = "proj_dx" if deriv else case
     N, K = (4 * width, width) if case in ("fc_fwd", "proj_dx") else (width, 4 * width)
     kr = case in ("proj_dx", "fc_dx")
     flags = {"fc_fwd": 1 | 2 | 16, "proj_fwd": 1 | 2 | 8, "proj_dx": 2 | 4 | 32, "fc_dx": 2 | 4}[case] | 64
@@ -193,7 +195,9 @@ def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr, h16):
         kw["dgelu_aux"] = rnd(M, N, dt=dt, seed=78)
         x = kw["dgelu_aux"].double()
         sg = torch.sigmoid(1.702 * x)
-        ref = ref * (sg * (1 + 1.702 * x * (1 - sg)))
+        ref = ref * (x if deriv else sg * (1 + 1.702 * x * (1 - sg)))
+        if deriv:
+            kw["gelu_deriv"] = True
     ops.gemm_nt(a, b, out, lw=lw, lw_is_kr=kr, rankop=ro, b_packed=ops.pack_b(b), **kw)
     check(t, ref_t, 2e-5, "t")
     check(ts, ref_ts, 2e-5, "ts")
@@ -925,3 +929,61 @@ def test_attention3_race_screen_bitwise_repeatable(ops, dt):
         else:
             for a, b, nm in zip(cur, first, ("out", "lse", "dqkv", "delta")):
                 assert torch.equal(a, b), f"run {it}: {nm} differs from run 0 in {int((a != b).sum())} elements"
+
+
+# ------------------------------- QuickGELU with the derivative as the saved tensor (ffm_gemm_args.gelu_deriv) ---
+def _qgelu64(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def _qgelu_grad64(x):
+    s = torch.sigmoid(1.702 * x)
+    return s * (1 + 1.702 * x * (1 - s))
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,N,K,packed", [(333, 384, 256, False),        # 128 x 128 kernel
+                                          (40, 512, 512, False),         # skinny kernel (text tower rows)
+                                          (6304, 3072, 768, True)])      # panel kernel (16-bit: fragment-packed weights)
+def test_gemm_gelu_derivative_form(ops, dt, M, N, K, packed):
+    """FFM_EPI_GELU with gelu_deriv: `out` = quick_gelu'(x), `gelu_out` = quick_gelu(x), x the product as it would have been
+    stored; FFM_EPI_DGELU with gelu_deriv: out = (a b^T) * aux.  Chained, the two launches give the classic pair's result:
+    g W^T * quick_gelu'(pre) - bit-identical in fp32, to one 16-bit rounding of the derivative otherwise."""
+    if packed and dt == torch.float32:
+        pytest.skip("packed weights are a 16-bit layout")
+    a, w = rnd(M, K, dt=dt, seed=71), rnd(N, K, dt=dt, scale=K ** -0.5, seed=72)
+    bias = rnd(N, seed=73)
+    bp = ops.pack_b(w) if packed else None
+    d = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    act = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    pre = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    act0 = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
+    kw = dict(bias=bias, b_packed=bp)
+    if packed:                                   # the panel kernel's GELU epilogues are the FairLoRA ones: rank operand needed
+        P = rnd(K, 8, scale=0.1, seed=74)
+        rk = torch.zeros(16, K, device="cuda", dtype=dt)
+        ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+        attr = torch.randint(0, 3, ((M + 196) // 197,), device="cuda", dtype=torch.int32)
+        mk = lambda: ops.RankOp(rk, rnd(3, 8, seed=75), attr, 197, 0.25, 0.7, t_out=torch.empty(M, 8, device="cuda"),
+                                ts_out=torch.empty(M, 8, device="cuda"))
+        kw.update(lw=rnd(8, N, scale=0.1, seed=76))
+        ops.gemm_nt(a, w, pre, gelu_out=act0, rankop=mk(), **kw)
+        ops.gemm_nt(a, w, d, gelu_out=act, rankop=mk(), gelu_deriv=True, **kw)
+        assert ops.gemm_tiles_m(M, N, K, 1 | 2 | 16 | 64, 8, dt, True) != ops.gemm_tiles_m(M, N, K, 1 | 2 | 16 | 64, 8, dt, False)
+    else:
+        ops.gemm_nt(a, w, pre, gelu_out=act0, **kw)
+        ops.gemm_nt(a, w, d, gelu_out=act, gelu_deriv=True, **kw)
+    assert torch.equal(act, act0), "the activation must not depend on which tensor is saved"
+    x = pre.double()                             # the stored (rounded) pre-activation of the classic launch
+    check(d, _qgelu_grad64(x), 1e-6 if dt == torch.float32 else tol(dt), "saved derivative")
+    check(act, _qgelu64(x), 1e-6 if dt == torch.float32 else tol(dt), "activation")
+    # backward: g W * saved tensor, both forms
+    g, wt = rnd(M, 64, dt=dt, seed=77), rnd(N, 64, dt=dt, scale=0.125, seed=78)
+    o0 = torch.empty(M, N, device="cuda", dtype=dt)
+    o1 = torch.empty(M, N, device="cuda", dtype=dt)
+    ops.gemm_nt(g, wt, o0, dgelu_aux=pre)
+    ops.gemm_nt(g, wt, o1, dgelu_aux=d, gelu_deriv=True)
+    if dt == torch.float32:
+        assert torch.equal(o0, o1), "fp32: the derivative form is the same arithmetic"
+    check(o1, (g.double() @ wt.double().t()) * _qgelu_grad64(x), tol(dt) * 2, "dX with the saved derivative")
+    check(o1, o0.double(), tol(dt) * 2, "derivative form vs classic form")
