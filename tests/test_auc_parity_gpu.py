@@ -101,7 +101,8 @@ def _oracle_run(name, mcfg, data, sd, args, cfg):
     return _ORACLE_RUNS[name]
 
 
-# "fp16": the reference's own 16-bit format (FFM_F16), held to north_star's plain 0.002 on every tower - no control widening
+# "fp16": the reference's own 16-bit format (FFM_F16), held to north_star's plain 0.002 on every tower: the ViT towers
+# against the fp32-weights oracle, the RN tower against the oracle on the half-rounded frozen weights the mode runs on
 @pytest.mark.parametrize("prec,tol", [("fp32", 0.0005), ("bf16", 0.002), ("fp16", 0.002)])
 @pytest.mark.parametrize("tower", list(CASES))
 def test_auc_after_equal_rounds(tower, prec, tol):
@@ -150,6 +151,23 @@ def test_auc_after_equal_rounds(tower, prec, tol):
         # capped: a control run that wandered far from the fp32 oracle must not make the bound below vacuous
         extra = [min(abs(c - r), 0.003) for c, r in zip(ctl_auc, ref_auc)]
         print(tower, "oracle with bf16-stored activations", [round(a, 5) for a in ctl_auc], " its own distance", [round(e, 5) for e in extra])
+    if tower.startswith("rn") and prec == "fp16":
+        # The fp16 mode's model IS the reference's model with its frozen weights rounded to half (convert_weights,
+        # clip/model.py:609-630).  On this fixture that rounding ALONE moves the fp32 oracle's AUC by 0.0007 / 0.0022 /
+        # 0.0019 (a random-weight ReLU / BatchNorm trunk: the same run with bf16-rounded weights moves by 0.010), so a
+        # half-precision engine is held to the oracle ON THE HALF WEIGHTS - plain 0.002, measured 1.4e-4 - and must not be
+        # farther from the fp32-weights oracle than that oracle is (+ 0.0005): the engine adds nothing to what the
+        # format costs.  Both distances are printed.  (ViT towers: plain 0.002 against the fp32-weights oracle.)
+        train = set(synth.trainable_keys(mcfg))
+        sd_h = {k: (v if (k in train or not v.is_floating_point() or "running_" in k) else v.half().float()) for k, v in sd.items()}
+        half = _oracle_run(tower + "+half-weights", mcfg, data, sd_h, args, cfg)
+        half_auc = [a / 100.0 for a in half["auc"]]
+        print(tower, "oracle on half-rounded frozen weights", [round(a, 5) for a in half_auc], " its distance from the fp32-weights oracle",
+              [round(abs(a - b), 5) for a, b in zip(half_auc, ref_auc)], " engine's distance from it", [round(abs(a - b), 5) for a, b in zip(hip_auc, half_auc)])
+        for r in range(rounds):
+            assert abs(hip_auc[r] - half_auc[r]) <= tol, (r, hip_auc, half_auc)
+            assert abs(hip_auc[r] - ref_auc[r]) <= abs(half_auc[r] - ref_auc[r]) + 0.0005, (r, hip_auc, half_auc, ref_auc)
+        ref_auc = half_auc
     for r in range(rounds):
         assert abs(hip_auc[r] - ref_auc[r]) <= tol + extra[r], (r, hip_auc, ref_auc, extra)
         # accuracy (percent, mean over the clients): fp32 may differ by one test sample of one client, 16-bit modes by 5 points
