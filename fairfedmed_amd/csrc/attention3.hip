@@ -348,8 +348,6 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
         float mx = m;
 #pragma unroll
         for (int f = 0; f < CF; ++f) {
-            constexpr int dummy = 0;
-            (void)dummy;
             if ((F0 + f) % 2 == 0) {                            // tile F0 + f opens DMA chunk (F0 + f) / 2
                 if ((F0 + f) / 2 == 0) chunk_ready(std::integral_constant<int, 0>{});
                 if ((F0 + f) / 2 == 1) chunk_ready(std::integral_constant<int, (GE::NCH > 1 ? 1 : 0)>{});
