@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step time of the bench workload with the side streams on / folded into the main stream."""
+"""Step time of the bench workload with the side streams on / folded into the main stream / the two side streams merged."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -28,3 +28,10 @@ eng.set_overlap(False)
 print("overlap off: %.3f ms/step" % run())
 eng.set_overlap(True)
 print("overlap on : %.3f ms/step" % run())
+# the LoRA-gradient reductions on the TEXT tower's stream (two side kernels never run at once; both still beside the chain)
+for rep in range(2):
+    eng.grad_stream = eng.side
+    eng.step_plans.clear()
+    print("grad reductions on the text stream: %.3f ms/step" % run())
+    eng.set_overlap(True)
+    print("three streams                     : %.3f ms/step" % run())
