@@ -10,6 +10,17 @@
 #ifndef FFM_SKINNY_CAP_DEFAULT
 #define FFM_SKINNY_CAP_DEFAULT 0
 #endif
+// Diagnostic twins only (tools/side_abl.sh): 1 = no weight loads, 2 = no activation loads (results are garbage) - which of
+// the text tower's two operand streams is it that slows the vision chain's kernels down?
+#ifndef FFM_SKINNY_ABL
+#define FFM_SKINNY_ABL 0
+#endif
+#ifndef FFM_SKINNY_NT_DEFAULT
+#define FFM_SKINNY_NT_DEFAULT 2
+#endif
+#ifndef FFM_SKINNY_MINB_DEFAULT
+#define FFM_SKINNY_MINB_DEFAULT 1
+#endif
 
 namespace {
 
@@ -64,12 +75,12 @@ template <> struct SkOps<float, float, true> {
         }
         return r;
     }
-    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) {
-        const bprep x = prep(a);
+    static __device__ __forceinline__ void mma_split(f32x4& acc, const bprep& x, const bprep& b) {
         Mma16<bf16_t>::mma(acc, x.l, b.h);                  // small terms first
         Mma16<bf16_t>::mma(acc, x.h, b.l);
         Mma16<bf16_t>::mma(acc, x.h, b.h);
     }
+    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) { mma_split(acc, prep(a), b); }
 };
 
 template <typename TA, typename TB, bool X3, int NW, int FL>
@@ -105,10 +116,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (ks + KS * u < kw) {
+                if constexpr (FFM_SKINNY_ABL & 1) bf[u] = {}; else
                 O::loadB(bf[u], bp + ks + KS * u);
 #pragma unroll
-                for (int mf = 0; mf < SK_MF; ++mf)
+                for (int mf = 0; mf < SK_MF; ++mf) {
+                    if constexpr (FFM_SKINNY_ABL & 2) af[u][mf] = {}; else
                     if (mf < nmf) O::loadA(af[u][mf], ap[mf] + ks + KS * u);
+                }
             }
         }
 #pragma unroll
@@ -167,6 +181,118 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
     }
 }
 
+// The X3 product with NT 16-column tiles per block.  Every block reads ALL rows of A (40 x K floats through the L2 -> CU
+// path: 2.5x the bytes of its 16 weight rows), so with one tile per block the activations are most of a launch's traffic - and
+// that traffic, not the CUs a launch occupies, is what the vision chain's kernels feel beside it (tools/side_proxy.py,
+// tools/side_abl.sh).  The NT tiles of a block share the A fragments AND their hi / lo split; wave
+// t < NT finishes tile t, and the partial sums meet in the one-tile kernel's order (wave 0, 1, ...): bit-identical results.
+// MFC: row fragments (3 for M <= 48: the text tower's 40 rows), UN: K32 steps of loads in flight (2 when a wave's K slice is
+// two steps, K = 512 on 8 waves).
+template <int NW, int FL, int NT, int MFC, int UN>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p) {
+    typedef SkOps<float, float, true> O;
+    constexpr int KS = O::KS, KG = KS / 4;
+    static_assert(NT <= NW, "one finishing wave per tile");
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);                // [NW][NT][MFC][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int nmf = (p.M + 15) >> 4;
+    const int kw = p.K / NW, k0 = wave * kw;
+    const float* A = reinterpret_cast<const float*>(p.a);
+    const int groups = p.N / (SK_COLS * NT);
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int n0 = grp * SK_COLS * NT;
+    const float* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bp[t] = reinterpret_cast<const float*>(p.b) + (size_t)(n0 + t * SK_COLS + col) * p.ldb + k0 + kg * KG;
+    const float* ap[MFC];
+#pragma unroll
+    for (int mf = 0; mf < MFC; ++mf) {
+        int row = mf * 16 + col;
+        row = row < p.M ? row : p.M - 1;                           // clamped rows are never stored
+        ap[mf] = A + (size_t)row * p.lda + k0 + kg * KG;
+    }
+    f32x4 acc[NT][MFC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MFC; ++mf) acc[t][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < kw; ks += KS * UN) {
+        O::braw bf[UN][NT];
+        O::afrag af[UN][MFC];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ks + KS * u < kw) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) O::loadB(bf[u][t], bp[t] + ks + KS * u);
+#pragma unroll
+                for (int mf = 0; mf < MFC; ++mf)
+                    if (mf < nmf) O::loadA(af[u][mf], ap[mf] + ks + KS * u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (ks + KS * u < kw) {
+                O::bprep b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = O::prep(bf[u][t]);
+#pragma unroll
+                for (int mf = 0; mf < MFC; ++mf)
+                    if (mf < nmf) {
+                        const O::bprep a = O::prep(af[u][mf]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) O::mma_split(acc[t][mf], a, b[t]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MFC; ++mf)
+            if (mf < nmf) red[((wave * NT + t) * MFC + mf) * 64 + lane] = acc[t][mf];
+    __syncthreads();
+    if (wave < NT) {
+        const int t = wave;
+        const int n = n0 + t * SK_COLS + col;
+        const float bias = (FL & FFM_EPI_BIAS) ? p.bias[n] : 0.f;
+        float* C = reinterpret_cast<float*>(p.c);
+        for (int mf = 0; mf < nmf; ++mf) {
+            f32x4 v = red[((0 * NT + t) * MFC + mf) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const f32x4 o = red[((w * NT + t) * MFC + mf) * 64 + lane];
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mf * 16 + 4 * kg + e;
+                if (row >= p.M) continue;
+                const size_t o = (size_t)row * p.ldc + n;
+                float x = v[e] + bias;
+                if (FL & FFM_EPI_RESIDUAL) x += reinterpret_cast<const float*>(p.res)[o];
+                if (FL & FFM_EPI_DGELU) {
+                    const float ax = reinterpret_cast<const float*>(p.aux)[o];
+                    x *= p.gelu_deriv ? ax : Act<float>::gelu_grad(ax);
+                }
+                if ((FL & FFM_EPI_GELU) && p.gelu_deriv) {
+                    float ga, gd;
+                    Act<float>::gelu_both(x, ga, gd);
+                    C[o] = gd;
+                    reinterpret_cast<float*>(p.c2)[o] = ga;
+                } else {
+                    C[o] = x;
+                    if (FL & FFM_EPI_GELU) reinterpret_cast<float*>(p.c2)[o] = Act<float>::gelu(x);
+                }
+            }
+        }
+    }
+    if (grp + (int)gridDim.x < groups) __syncthreads();           // `red` is rewritten by the next tile group
+    }
+}
+
 // Blocks per launch.  Every block of the vision tower's single-round panel GEMMs needs a whole CU, and a panel launch leaves
 // 8-16 of the 256 idle: a side-stream launch that holds more CUs than that when a panel starts keeps some of its blocks
 // waiting (the side streams cost the chain ~0.4 ms per step).  FFM_SKINNY_CAP=<n> caps the grid at n
@@ -176,8 +302,41 @@ inline int sk_grid(int tiles) {
     return cap > 0 && tiles > cap ? cap : tiles;
 }
 
+// Tiles per block of the X3 product: FFM_SKINNY_NT = 1 | 2 | 4; a product whose N does not divide takes fewer.
+inline int sk_nt(int N) {
+    static const int want = getenv("FFM_SKINNY_NT") ? atoi(getenv("FFM_SKINNY_NT")) : FFM_SKINNY_NT_DEFAULT;
+    static const int minb = getenv("FFM_SKINNY_MINB") ? atoi(getenv("FFM_SKINNY_MINB")) : FFM_SKINNY_MINB_DEFAULT;
+    static const int want_n = getenv("FFM_SKINNY_NT_NARROW") ? atoi(getenv("FFM_SKINNY_NT_NARROW")) : want;   // N <= 512
+    const int w = N <= 512 ? want_n : want;
+    int nt = w >= 4 ? 4 : (w >= 2 ? 2 : 1);
+    while (nt > 1 && (N % (SK_COLS * nt) || N / (SK_COLS * nt) < minb)) nt >>= 1;     // never fewer than minb blocks
+    return nt;
+}
+
+template <int NW, int FL, int NT, int MFC, int UN>
+int launch_nt(const ffm_gemm_args& a, hipStream_t s) {
+    constexpr int lds = NW * NT * MFC * 64 * 16;
+    static bool done = false;                         // one per instantiation
+    if (!done && lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_nt_kernel<NW, FL, NT, MFC, UN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    done = true;
+    hipLaunchKernelGGL((gemm_skinny_nt_kernel<NW, FL, NT, MFC, UN>), dim3(sk_grid(a.N / (SK_COLS * NT))), dim3(NW * 64), lds, s, a);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
 template <typename TA, typename TB, bool X3, int NW, int FL>
 int launch(const ffm_gemm_args& a, hipStream_t s) {
+    if constexpr (X3 && NW == 8) {
+        // (the text tower's shapes: 40 rows, K = 512 or 2048 on 8 waves -> 2 or 8 K32 steps per wave)
+        const int nt = a.M <= 48 ? sk_nt(a.N) : 1, steps = a.K / NW / 32;
+        if (nt == 4 && steps <= 2) return launch_nt<NW, FL, 4, 3, 2>(a, s);
+        if (nt >= 2 && steps <= 2) return launch_nt<NW, FL, 2, 3, 2>(a, s);
+        if (nt >= 2) return launch_nt<NW, FL, 2, 3, 4>(a, s);
+    }
     hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB, X3, NW, FL>), dim3(sk_grid(a.N / SK_COLS)), dim3(NW * 64), 0, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;

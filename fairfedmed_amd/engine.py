@@ -393,6 +393,7 @@ class FairLoRAEngine:
         cfg, v, dtype, dev = self.cfg, self.cfg.vision, self.dtype, self.device
         # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
         self.fused_rank = 0 < cfg.lora.rank <= 16
+        self.red_at = int(os.environ.get("FFM_RED_AT", "0"))       # where a block's LoRA-gradient reductions start (_stack_backward)
         ie = "image_encoder.transformer.resblocks."
         self.sops = SOperands(self.params, [f"{ie}{i}.mlp.c_{n}." for i in range(v.layers) for n in ("fc", "proj")],
                               cfg, dev)
@@ -677,21 +678,29 @@ class FairLoRAEngine:
                     ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._S(i, "fc"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
-                self._ev_record(self.ev_layer[i], main)
-                self._ev_wait(self.grad_stream, self.ev_layer[i])
-                with self._on(self.grad_stream):
-                    if not last:
-                        ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
-                        ops.lora_grad_partial(act, us2, r, pt["proj_A"])
-                        ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
-                    if self._fold_ln2(st, rows):
-                        ops.lora_grad_partial_ln(xm, us1, st.st2[i][0], st.st2[i][1], blk.ln2_w, blk.ln2_b, r, pt["fc_A"])
-                    else:
-                        ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
-                    # this block's six gradient tensors are complete: sum their partials now, behind the four reductions
-                    # on the same side stream (one launch per block; only block 0's is left when the dX chain ends -
-                    # ONE launch for all 72 tensors at the end sat in the step's tail for ~50 us)
-                    self._reduce_plan(st, rows, need_input_grad, i).run()
+                def reductions(i=i, blk=blk, gi=gi, act=act, dpre=dpre, us2=us2, us1=us1, pt=pt, xm=xm, h2=h2, last=last):
+                    self._ev_record(self.ev_layer[i], main)
+                    self._ev_wait(self.grad_stream, self.ev_layer[i])
+                    with self._on(self.grad_stream):
+                        if not last:
+                            ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
+                            ops.lora_grad_partial(act, us2, r, pt["proj_A"])
+                            ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
+                        if self._fold_ln2(st, rows):
+                            ops.lora_grad_partial_ln(xm, us1, st.st2[i][0], st.st2[i][1], blk.ln2_w, blk.ln2_b, r, pt["fc_A"])
+                        else:
+                            ops.lora_grad_partial(h2, us1, r, pt["fc_A"])
+                        # this block's six gradient tensors are complete: sum their partials now, behind the four reductions
+                        # on the same side stream (one launch per block; only block 0's is left when the dX chain ends -
+                        # ONE launch for all 72 tensors at the end sat in the step's tail for ~50 us)
+                        self._reduce_plan(st, rows, need_input_grad, i).run()
+                # red_at: where the side stream may start them (everything they read is kept per layer).  0: behind this
+                # block's dX(c_fc) - beside its LayerNorm / out-proj / attention backward; 1: behind its attention backward;
+                # 2: behind the whole block - beside the NEXT block's two FairLoRA products, whose main loops live on
+                # LDS / L2 operands (the last block's have nothing behind them and always start at once)
+                red_at = 0 if last or i == 0 else self.red_at
+                if red_at == 0:
+                    reductions()
                 if last:
                     break
                 if not fused:
@@ -706,8 +715,12 @@ class FairLoRAEngine:
             gemm(g1, blk.w_out_t, st.do[:rows], b_packed=blk.pk("w_out_t"))
             ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
                               images, st.L, st.heads, st.causal)
+            if r and red_at == 1:
+                reductions()
             gemm(st.dqkv[:rows], blk.w_in_t, st.dh[:rows], b_packed=blk.pk("w_in_t"))
             ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
+            if r and red_at == 2:
+                reductions()
         if r:
             if self.sops.glob:
                 self._glue(self.sops.finish, self.grad_stream)     # dS_eff -> dS, dS_global

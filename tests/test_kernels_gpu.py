@@ -611,6 +611,47 @@ def test_skinny_gemm_f32(M, N, K, x3, mode):
     assert rel(out, ref) < tol, rel(out, ref)
 
 
+def test_skinny_x3_tiles_per_block_switch():
+    """FFM_SKINNY_NT (read once per process): the text tower's X3 product with 1 / 2 / 4 column tiles per block
+    (csrc/gemm_skinny.hip, gemm_skinny_nt_kernel: the tiles of a block share the activation fragments).  The partial sums
+    meet in the one-tile kernel's order, so the three settings are BIT-identical on the text tower's shapes; the float64
+    test runs again under each setting in a child process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, sys; sys.path.insert(0, %r); from fairfedmed_amd import ops\n"
+            "g = torch.Generator(device='cuda').manual_seed(11)\n"
+            "res = {}\n"
+            "for (M, N, K) in ((40, 1536, 512), (40, 512, 512), (40, 2048, 512), (40, 512, 2048), (33, 48, 640), (40, 96, 512)):\n"
+            "    a = torch.randn(M, K, device='cuda', generator=g); w = torch.randn(N, K, device='cuda', generator=g) * K ** -0.5\n"
+            "    bias = torch.randn(N, device='cuda', generator=g); r = torch.randn(M, N, device='cuda', generator=g)\n"
+            "    out = torch.full((M, N), float('nan'), device='cuda'); act = torch.full((M, N), float('nan'), device='cuda')\n"
+            "    ops.gemm_nt(a, w, out, bias=bias, res=r, x3=True); res[(M, N, K, 'res')] = out.cpu().clone()\n"
+            "    ops.gemm_nt(a, w, out, bias=bias, gelu_out=act, x3=True); res[(M, N, K, 'gelu')] = (out.cpu().clone(), act.cpu().clone())\n"
+            "    ops.gemm_nt(a, w, out, dgelu_aux=r, x3=True); res[(M, N, K, 'dgelu')] = out.cpu().clone()\n"
+            "torch.cuda.synchronize(); torch.save(res, sys.argv[1])\n" % root)
+    with tempfile.TemporaryDirectory() as d:
+        got = {}
+        for nt in ("1", "2", "4"):
+            f = os.path.join(d, nt + ".pt")
+            env = dict(os.environ, FFM_SKINNY_NT=nt)
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            got[nt] = torch.load(f)
+            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_kernels_gpu.py"), "-k",
+                                "test_skinny_gemm_f32 and x3"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for key, ref in got["1"].items():
+        for nt in ("2", "4"):
+            other = got[nt][key]
+            if isinstance(ref, tuple):
+                assert all(torch.equal(x, y) for x, y in zip(ref, other)), (key, nt)
+            else:
+                assert not torch.isnan(other).any() and torch.equal(ref, other), (key, nt)
+
+
 def test_x3_gemm_rejects_large_products():
     """FFM_F32_X3 exists for skinny products only: anything else is refused, never computed some other way."""
     from fairfedmed_amd import ops
