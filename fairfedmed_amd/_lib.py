@@ -17,8 +17,8 @@ LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm
 
 F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the reference's PREC="fp16")
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-EPI_ROWSTATS, EPI_LNIN = 128, 256
-ABI_VERSION = 8
+EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD = 128, 256, 512
+ABI_VERSION = 9
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("b_packed", _vp), ("lw_wide", _vp),
         ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("gelu_deriv", _i32),
         ("ln_rk", _vp), ("colstat_part", _vp),
+        ("lg_v", _vp), ("lg_part_c", _vp), ("lg_part_a", _vp),
     ]
 
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
     "ffm_gemm_tiles_m": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_gemm_tiles_n": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "ffm_gemm_lgrad_rows": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_gemm_tile_shape": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)],
     "ffm_pack_b": [_vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_lora_pack_multi": [_vp, _i32, _i32, _i32, _vp],

@@ -835,6 +835,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         if (!off || dtype == FFM_F32_X3) return ffm_skinny_launch(a, dtype, s);
     }
     if (dtype == FFM_F32_X3) return FFM_EUNSUP;                           // split-operand products: skinny shapes only
+    if (a.flags & FFM_EPI_LGRAD) {                                        // gradient partial products: one panel tile only
+        const int cfgg = (a.b_packed && !a.colstat_part) ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
+        return cfgg >= 0 ? ffm_panel_launch(a, cfgg, s) : FFM_EUNSUP;
+    }
     if (a.flags & (FFM_EPI_ROWSTATS | FFM_EPI_LNIN)) {                    // LayerNorm folding: the panel kernel only
         if (a.colstat_part) return FFM_EUNSUP;                            // ... which has no column-sum epilogue
         const int cfgl = a.b_packed ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
@@ -1109,6 +1113,11 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
 extern "C" int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed) {
     const int cfg = ffm_panel_select(M, N, K, flags, rank, dtype, packed != 0);
     return cfg >= 0 ? ffm_panel_ds_rows(M, N, cfg) : (M + BM - 1) / BM;
+}
+
+extern "C" int ffm_gemm_lgrad_rows(int M, int N, int K, int flags, int rank, int dtype, int packed) {
+    const int cfg = ffm_panel_select(M, N, K, flags | FFM_EPI_LGRAD, rank, dtype, packed != 0);
+    return cfg >= 0 ? (M + 16 * FFM_PANEL_CFGS[cfg].mf - 1) / (16 * FFM_PANEL_CFGS[cfg].mf) : FFM_EUNSUP;
 }
 
 extern "C" int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dtype, int packed) {

@@ -46,6 +46,10 @@ bool plain_flags_ok(int flags) {
 
 bool rk_flags_ok(int flags, int rank) {
     if (rank <= 0 || rank > 16) return false;
+    if (flags & FFM_EPI_LGRAD) {                               // the gradient partial products: the dX epilogue of c_proj only
+        if ((flags & ~FFM_EPI_RANKOP) != (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD) || rank % 4) return false;
+        return true;
+    }
     if ((flags & FFM_EPI_LNIN) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_LNIN)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU))
         return false;                                          // ln_2 folded in: the c_fc forward epilogue only
     if ((flags & FFM_EPI_ROWSTATS) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL))
@@ -90,6 +94,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         if (c >= 5 && !((exp_mask >> c) & 1)) continue;
         if (c == 5 || c == 6 || c == 9) continue;              // measured in round 3, lost, no longer instantiated
         if (cf.ks && K % 256) continue;                       // the K-split loop is unrolled by four K64 steps
+        if ((flags & FFM_EPI_LGRAD) && c != 7) continue;      // instantiated for the 8-wave 208x384 tile only
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)

@@ -72,6 +72,18 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LGRAD: the 2 NF transposed reads of one [32][16 NF] image (rows 8 g + q / + 4 of the lane's group, 16 columns each; the
+// two images are interleaved row by row: row stride 2 TROWX, the second image TROWX behind the first), all on
+// ONE address register with immediate offsets (as computed addresses the compiler kept all of them live across the row
+// groups and spilled them - with a vmcnt(0) in front of every reload)
+typedef __attribute__((ext_vector_type(2))) uint32_t panel_u32x2;
+template <int NFX, int TROWX, int TEN, int T = 0> __device__ __forceinline__ void lg_tr_reads(panel_u32x2 (&xr)[NFX][2], uint32_t a) {
+    if constexpr (T < NFX * 2) {
+        constexpr int cf = T / 2, h = T % 2;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xr[cf][h]) : "v"(a), "n"(TEN * TROWX + h * 4 * 2 * TROWX + cf * 32) : "memory");
+        lg_tr_reads<NFX, TROWX, TEN, T + 1>(xr, a);
+    }
+}
 __device__ __forceinline__ void fence() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -92,8 +104,10 @@ __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }   
 // persistent LDS behind the ring: bias [BN] f32 | (RANKOP) LoRA tile [BN][32] bf16 | lora_S [256] + its column sums [16]
 // f32 | row groups [BM]
 // | (LNIN) c [BN] f32, row mean / rstd [BM] f32 each
-__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4) {
-    return pw * 16 * nf * 4 + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0);
+// | (LGRAD) the forward ts rows of the other adapter [BM][r] f32 (room for r = 16)
+__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4, bool lgrad = false) {
+    return pw * 16 * nf * 4 + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0) +
+           (lgrad ? 16 * mf * 64 : 0);
 }
 
 // Two blocks per CU (two waves per SIMD) for the 128 x 256 plain tile: 128 accumulator registers and a 64 KiB ring
@@ -118,6 +132,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int BMp = 16 * MF, BNp = CW * 16 * NF, WN = 16 * NF;
     constexpr int flags = FL;
     static_assert(!RK || (flags & FFM_EPI_LORA), "RANKOP rides on the LoRA epilogue");
+    // LGRAD (dX of c_proj): the two rank-r gradient reductions whose [rows x N] operand this launch holds in registers -
+    // dB of the other adapter from the rows it stores (c = dL/d pre) and dA of its own from quick_gelu(aux) - are formed
+    // per row tile in the output epilogue (see there) instead of by two kernels that read 2 x M x N elements once more
+    constexpr bool LGRAD = (FL & FFM_EPI_LGRAD) != 0;
+    static_assert(!LGRAD || (RK && (FL & FFM_EPI_DGELU) && !KS), "LGRAD rides on the DGELU + RANKOP epilogue");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -297,6 +316,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     float* Cv = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, false, CW));     // LNIN: c [BN]
     float* Mu = Cv + BNp;                                     // row means [BM]
     float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
+    float* V1F = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, LNIN, CW));      // LGRAD: lg_v rows [BM][r]
     const int r = RK ? p.rank : 0;
     // bias, c (LNIN), lora_S and the rows' group ids: inline-asm loads with clamped indices, consumed behind the ONE
     // vmcnt(0) below.  As compiler-visible loads each of them (a conditional load followed by its LDS store) was answered
@@ -366,6 +386,18 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     row[0] = lo8; row[1] = hi8; row[2] = z8; row[3] = z8;
                 }
             }
+        }
+    }
+    if constexpr (LGRAD) {
+        // the tile's BM * r floats of lg_v ([M][r] fp32) are contiguous: 1 KiB pieces dealt over the waves, chunks beyond
+        // the last row clamped (their rows are masked where they are used)
+        const long lim = (long)p.M * r - 4;
+        for (int q = wave; q * 256 < BMp * r; q += PW) {
+            long e0 = (long)m0 * r + q * 256 + lane * 4;
+            e0 = e0 < lim ? e0 : lim;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.lg_v + e0),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(V1F) + q * 1024),
+                                             16, 0, 0);
         }
     }
     FFM_STAMP(6);
@@ -639,6 +671,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PF = NRG < PFMAX ? NRG : PFMAX;
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
+    float* V2F = reinterpret_cast<float*>(smem + BMp * 128);          // LGRAD: the same rows in fp32, [BM][16]
     float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + colw * (32 * PITCH);
     // ROWSTATS: per-wave partial row sums [PW][BM][2] behind the four waves' output stages
     float* RowP = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + CW * (32 * PITCH);
@@ -740,6 +773,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     else
                     TsA[(row0 + e) * 32 + j] = (bf16_t)tsv[e];
                     TsA[(row0 + e) * 32 + 16 + j] = (bf16_t)0.f;
+                    if constexpr (LGRAD) V2F[(row0 + e) * 16 + j] = tsv[e];      // fp32 ts rows (zero beyond M and beyond r)
                 }
                 if (mine && jok) {
 #pragma unroll
@@ -830,6 +864,25 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // per wave: 32-row groups of the accumulator slab through a private LDS stage, then 16-byte row segments out.
     // accumulator fragment -> stage: explicit ds_write_b32 (data straight from the AGPR / VGPR the MFMAs left it in)
     const uint32_t cw_lane = (uint32_t)(uintptr_t)(Cw + fgrp * 4 * PITCH + frow);
+    // LGRAD.  part_c[tm][n][j] = sum_rows c[row][n] lg_v[row][j], part_a[tm][n][j] = sum_rows quick_gelu(aux)[row][n] ts[row][j]
+    // over the block's rows: products V^T [16 x 32 rows] . X [32 rows x 16 columns] per row group, with the ROW index
+    // contracted.  X is needed with 8 consecutive rows of one column per lane, and the epilogue has 8 consecutive columns
+    // of one row per lane: every lane drops its 16-bit chunk (the rows as stored / the activation recomputed from the
+    // pre-activation chunk it holds anyway) into a [32][WN] image over the part of the wave's stage that has been read
+    // already, and ds_read_b64_tr_b16 hands the image back transposed (the reduction kernel's own recipe, lora.hip).
+    // V enters as a bf16 hi + lo pair (fp32-level accuracy in v, as there).  No VMEM in here: the counted waits stand.
+    // Both images are written INSIDE the chunk loop (the activation shares the sigmoid of the derivative there: recomputed
+    // behind the loop its exp + rcp cost 12 us per launch), interleaved row by row - image row R of both at 2 TROW R, 16
+    // bytes short of the stage's row pitch - so that what iteration i writes (rows it has just read) ends below the first
+    // stage row a LATER iteration still reads, except in a row the two iterations share: there it covers the row's first
+    // 4 PITCH - 16 (R + 1) bytes, chunks the earlier iteration has consumed (NF = 3: row 10, its chunk 0; row 21: nothing).
+    constexpr int TROW = WN * 2;                                      // bytes per image row
+    static_assert(!LGRAD || (NF == 3 && 2 * 32 * TROW <= 32 * PITCH * 4), "both images fit the wave's stage; shared rows checked for NF = 3");
+    // (the accumulators are born in the first row group, behind its stage writes: the AGPRs of the main accumulator's
+    // first two fragment rows are free from there on, and the epilogue has no VGPRs to spare on the 8-wave tile)
+    f32x4 lgc[NF], lga[NF];
+    const uint32_t t_img = (uint32_t)(uintptr_t)Cw;
+    const uint32_t t_rd = t_img + (8 * fgrp + (frow >> 2)) * 2 * TROW + 8 * (lane & 3);     // lane 4q + p of a group: row q, columns 4p..
     static_for<NRG>([&](auto RG_) {
         constexpr int rg = decltype(RG_)::value;
         static_for<2 * NF * 4>([&](auto T_) {
@@ -901,7 +954,31 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];
             }
-            if constexpr ((flags & FFM_EPI_DGELU) != 0) {
+            if constexpr (LGRAD) {
+                // (gelu_deriv == 0 here: the launcher checks) derivative and activation from one sigmoid; both chunks into
+                // their images (asm: ordered behind this iteration's reads of the stage, whatever the compiler thinks of
+                // the types)
+                bf16x8 d8, a8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float ga, gd;
+                    Act<bf16_t>::gelu_both((float)rpre[rg % PF][i][c], ga, gd);
+                    v[c] *= gd;
+                    d8[c] = (bf16_t)v[c];
+                    a8[c] = (bf16_t)ga;
+                }
+                if constexpr (rg == NRG - 1 && (MF & 1)) {
+                    // the last group of an odd MF has 16 rows; the other 16 stage rows hold what the previous group's images
+                    // left there - any bit pattern, NaN included, and 0 x NaN is what a masked V row would make of it
+                    if (row >= 16) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) d8[c] = a8[c] = (bf16_t)0.f;
+                    }
+                }
+                const uint32_t ta = t_img + row * (2 * TROW) + ch * 16;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ta), "v"(d8) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ta), "v"(a8), "n"(TROW) : "memory");
+            } else if constexpr ((flags & FFM_EPI_DGELU) != 0) {
                 if (p.gelu_deriv) {                              // (kernel argument: a scalar branch) aux holds gelu'(pre)
 #pragma unroll
                     for (int c = 0; c < 8; ++c) v[c] *= (float)rpre[rg % PF][i][c];
@@ -949,11 +1026,75 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 }
             }
         }
+        if constexpr (LGRAD) {
+            // one operand after the other (registers): V fragment (rank slot frow, rows 8 fgrp .. + 7 of the group) as a
+            // bf16 hi + lo pair, the NF column fragments of its image by two transposed reads each, 2 NF MFMAs
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            if constexpr (rg == 0) {
+#pragma unroll
+                for (int cf = 0; cf < NF; ++cf) {
+                    lgc[cf] = lga[cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(lgc[cf]), "+a"(lga[cf]));
+                }
+            }
+#pragma unroll
+            for (int ten = 0; ten < 2; ++ten) {
+                frag_t vh, vl;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int R = rg * 32 + 8 * fgrp + t;
+                    const bool ok = R < BMp && m0 + R < p.M && frow < r;
+                    const int Rc = R < BMp ? R : BMp - 1;
+                    float vv = ten ? V2F[Rc * 16 + frow] : V1F[Rc * r + (frow < r ? frow : 0)];      // (unconditional: no exec-masked branch per read)
+                    vv = ok ? vv : 0.f;
+                    vh[t] = (bf16_t)vv;
+                    vl[t] = (bf16_t)(vv - (float)vh[t]);
+                }
+                panel_u32x2 xr[NF][2];
+                if (ten == 0) lg_tr_reads<NF, TROW, 0>(xr, t_rd); else lg_tr_reads<NF, TROW, 1>(xr, t_rd);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int cf = 0; cf < NF; ++cf) {
+                    asm volatile("" : "+v"(xr[cf][0]), "+v"(xr[cf][1]));
+                    const u32x4 pk = {xr[cf][0][0], xr[cf][0][1], xr[cf][1][0], xr[cf][1][1]};
+                    const frag_t xb = __builtin_bit_cast(frag_t, pk);
+                    f32x4& dst = ten ? lga[cf] : lgc[cf];
+                    // (s_nop 1: an operand the VALU has just written - vh / vl, the zeroed accumulator - needs two wait
+                    // states before an MFMA reads it, and hipcc pads nothing for an asm statement: measured, IEEE-half twin)
+                    asm volatile("s_nop 1\n\t" FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(dst) : "v"(vh), "v"(xb));
+                    asm volatile("s_nop 1\n\t" FFM_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+a"(dst) : "v"(vl), "v"(xb));
+                }
+            }
+        }
         if constexpr (PRE) {
             if constexpr (rg + PF < NRG) load_pre(rg + PF, rpre[rg % PF]);
         }
         fence();
     });
+    if constexpr (LGRAD) {
+        // (asm MFMAs: see behind the main loop.  The accumulators are operands of the wait, or the scheduler lifts their
+        // v_accvgpr_read above it, in between the last MFMAs - measured: element 0 of one fragment wrong in full tiles)
+        static_assert(NF <= 3 || !LGRAD, "operands of the wait below");
+        if constexpr (NF == 3)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+a"(lgc[0]), "+a"(lgc[1]), "+a"(lgc[2]), "+a"(lga[0]), "+a"(lga[1]), "+a"(lga[2])::"memory");
+        else if constexpr (NF == 2)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+a"(lgc[0]), "+a"(lgc[1]), "+a"(lga[0]), "+a"(lga[1])::"memory");
+        else
+            asm volatile("s_nop 15\n\ts_nop 15" : "+a"(lgc[0]), "+a"(lga[0])::"memory");
+        // D[rank slot 4 fgrp + e][column frow] -> part[tm][n0w + 16 cf + frow][slot]
+#pragma unroll
+        for (int cf = 0; cf < NF; ++cf) {
+            const size_t o = ((size_t)tm * p.N + n0w + cf * 16 + frow) * r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = 4 * fgrp + e;
+                if (jj < r) {
+                    p.lg_part_c[o + jj] = lgc[cf][e];
+                    p.lg_part_a[o + jj] = lga[cf][e];
+                }
+            }
+        }
+    }
     if constexpr (ROWST) {
         __syncthreads();
         for (int i = tid; i < BMp; i += ET) {
@@ -982,7 +1123,7 @@ int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
     using G = PanelGeom<MF, RK, PWV>;
     const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (CW * 16 * NF));
     constexpr int partb = KS ? CW * (MF * NF + (RK ? (MF + CW - 1) / CW : 0)) * 1024 : 0;      // K split: partial accumulators
-    constexpr int lds = (partb > G::RING ? partb : G::RING) + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, CW);
+    constexpr int lds = (partb > G::RING ? partb : G::RING) + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, CW, (FL & FFM_EPI_LGRAD) != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert((RK ? 16 * MF * 192 : 0) + CW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? CW * 16 * MF * 8 : 0) <= G::RING,
                   "epilogue tiles alias the ring");

@@ -32,6 +32,8 @@ static int ffm_panel_launch_rk1(const ffm_gemm_args& a, int cfg, hipStream_t s) 
 
 int ffm_panel_launch_rk(const ffm_gemm_args& a, int cfg, hipStream_t s) {
     if (!a.rk || ((uintptr_t)a.rk & 15) || !a.S || !a.lw || a.rank <= 0 || a.rank > 16) return FFM_EINVAL;
+    if ((a.flags & FFM_EPI_LGRAD) && (!a.lg_v || ((uintptr_t)a.lg_v & 15) || !a.lg_part_c || !a.lg_part_a || a.rank % 4 || a.gelu_deriv || cfg != 7))
+        return FFM_EINVAL;
     switch (cfg) {
         case 0: case 3: return ffm_panel_launch_rk1(a, cfg, s);
         case 8: case 11: return ffm_panel_launch_rk2(a, cfg, s);

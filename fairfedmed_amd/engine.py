@@ -261,6 +261,7 @@ class _Stack:
                           "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),
                           "fc_S": f(nb * 8 * rank), "proj_S": f(nb * 8 * rank)} for _ in range(layers)]
             self.plans = {}
+            self.lgrad = {}                                      # rows -> row tiles of the FFM_EPI_LGRAD partials (0: not served)
 
 
 class FairLoRAEngine:
@@ -394,6 +395,7 @@ class FairLoRAEngine:
         # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
         self.fused_rank = 0 < cfg.lora.rank <= 16
         self.red_at = int(os.environ.get("FFM_RED_AT", "0"))       # where a block's LoRA-gradient reductions start (_stack_backward)
+        self.use_lgrad = os.environ.get("FFM_LGRAD", "1") != "0"    # the two large reductions inside the dX product of c_proj
         ie = "image_encoder.transformer.resblocks."
         self.sops = SOperands(self.params, [f"{ie}{i}.mlp.c_{n}." for i in range(v.layers) for n in ("fc", "proj")],
                               cfg, dev)
@@ -646,10 +648,15 @@ class FairLoRAEngine:
                     self._ev_wait(self.grad_stream, self.ev_tail0)
                     with self._on(self.grad_stream):
                         ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
+                # FFM_EPI_LGRAD: dB(c_fc) = dpre^T ts1 and dA(c_proj) = act^T us2 leave with the dX product of c_proj, which
+                # holds dpre and (through pre) act in registers - per row tile, into the buffers the two reduction launches
+                # they replace would have filled (77 MB per block that the side stream no longer reads beside the chain)
+                lg = self._lgrad_rows(st, rows, blk) if fused else 0
                 if fused:
                     ro = ops.RankOp(self.rk[i]["proj_B"], self._S(i, "proj"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"],
-                                    lw_wide=self.lw_wide[i].get("proj_A"))
+                                    lw_wide=self.lw_wide[i].get("proj_A"),
+                                    lgrad=(st.ts1[i][:rows], pt["fc_B"], pt["proj_A"]) if lg else None)
                     gemm(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                                 dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"))
                 else:
@@ -673,19 +680,21 @@ class FairLoRAEngine:
                         with self._on(self.grad_stream):
                             if not early:
                                 ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
-                            ops.lora_grad_partial(act, us2, r, pt["proj_A"])
-                            ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
+                            if not lg:
+                                ops.lora_grad_partial(act, us2, r, pt["proj_A"])
+                                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
                     ops.lora_down(dpre, self._lora_view(blk, "fc_B"), True, self._S(i, "fc"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
-                def reductions(i=i, blk=blk, gi=gi, act=act, dpre=dpre, us2=us2, us1=us1, pt=pt, xm=xm, h2=h2, last=last):
+                def reductions(i=i, blk=blk, gi=gi, act=act, dpre=dpre, us2=us2, us1=us1, pt=pt, xm=xm, h2=h2, last=last, lg=lg):
                     self._ev_record(self.ev_layer[i], main)
                     self._ev_wait(self.grad_stream, self.ev_layer[i])
                     with self._on(self.grad_stream):
                         if not last:
                             ops.lora_grad_partial(gi, st.ts2[i][:rows], r, pt["proj_B"])
-                            ops.lora_grad_partial(act, us2, r, pt["proj_A"])
-                            ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
+                            if not lg:
+                                ops.lora_grad_partial(act, us2, r, pt["proj_A"])
+                                ops.lora_grad_partial(dpre, st.ts1[i][:rows], r, pt["fc_B"])
                         if self._fold_ln2(st, rows):
                             ops.lora_grad_partial_ln(xm, us1, st.st2[i][0], st.st2[i][1], blk.ln2_w, blk.ln2_b, r, pt["fc_A"])
                         else:
@@ -728,6 +737,20 @@ class FairLoRAEngine:
             self._ev_wait(main, self.ev_grads)
         return g
 
+    def _lgrad_rows(self, st: _Stack, rows: int, blk: _Block) -> int:
+        """Row tiles of the FFM_EPI_LGRAD partial products for this row count, 0 when the kernel that serves the dX product
+        of c_proj has no such epilogue (then the two reduction launches run) or FFM_LGRAD=0 asks for the launches."""
+        key = (rows, blk.packed is not None)
+        if key not in st.lgrad:
+            n = 0
+            deriv = os.environ.get("FFM_GELU_DERIV", "0") == "1"   # (the saved tensor is then gelu'(pre): no activation to recompute)
+            if self.use_lgrad and not deriv and blk.packed is not None and _is16(self.dtype) and st.rank % 4 == 0:
+                n = max(0, ops.gemm_lgrad_rows(rows, 4 * st.width, st.width, st.rank, self.dtype, True))
+                if n > ops.lora_grad_splits(rows):            # (the partial buffers are sized for the reduction kernel's splits)
+                    n = 0
+            st.lgrad[key] = n
+        return st.lgrad[key]
+
     def _reduce_plan(self, st: _Stack, rows: int, full_bwd: bool, layer: int):
         """Descriptor table (built once per row count and block) that sums the block's partials into params.grad."""
         key = (rows, full_bwd, layer)
@@ -747,9 +770,11 @@ class FairLoRAEngine:
                     else ops.lora_down_blocks(rows, w, r, self.dtype)
                 nb_f = _ds_rows(rows, w, 4 * w, r, self.dtype, pk) if (self.fused_rank and (li > 0 or full_bwd)) \
                     else ops.lora_down_blocks(rows, 4 * w, r, self.dtype)
+                # (FFM_EPI_LGRAD: proj_A and fc_B hold one partial per row tile of the dX product of c_proj)
+                nlg = (self._lgrad_rows(st, rows, st.blocks[li]) if self.fused_rank else 0) or nsp
                 ent += [(pt["proj_S"], nb_p, G * r, self._dS(li, "proj"), 0, 0), (pt["fc_S"], nb_f, G * r, self._dS(li, "fc"), 0, 0),
-                        (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nsp, 4 * w * r, gv("proj_A"), 0, 0),
-                        (pt["fc_B"], nsp, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
+                        (pt["proj_B"], nsp, w * r, gv("proj_B"), w, r), (pt["proj_A"], nlg, 4 * w * r, gv("proj_A"), 0, 0),
+                        (pt["fc_B"], nlg, 4 * w * r, gv("fc_B"), 4 * w, r), (pt["fc_A"], nsp, w * r, gv("fc_A"), 0, 0)]
             st.plans[key] = ops.ReducePlan(ent, self.device)
         return st.plans[key]
 

@@ -91,17 +91,28 @@ class RankOp:
 
     def __init__(self, rk: Tensor, S: Tensor, attr: Optional[Tensor], rows_per_sample: int, scaling: float,
                  lambda_group: float, t_out: Optional[Tensor] = None, ts_out: Optional[Tensor] = None,
-                 t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None, lw_wide: Optional[Tensor] = None):
+                 t_fwd: Optional[Tensor] = None, ds_part: Optional[Tensor] = None, lw_wide: Optional[Tensor] = None,
+                 lgrad: Optional[tuple] = None):
         self.rk, self.S, self.attr, self.rps = rk, S, attr, rows_per_sample
         self.scaling, self.lam = scaling, lambda_group
         self.t_out, self.ts_out, self.t_fwd, self.ds_part = t_out, ts_out, t_fwd, ds_part
         self.lw_wide = lw_wide                    # `lw` as [N, 32] rows in the activation dtype (PackPlan's wide output)
+        # FFM_EPI_LGRAD (dX of c_proj): (lg_v [M, r], lg_part_c, lg_part_a) - the two large rank-r gradient partial
+        # products leave with this launch's epilogue (gemm_lgrad_rows says whether its kernel can, and how many tiles)
+        self.lgrad = lgrad
 
 
 def gemm_tiles_m(M: int, N: int = 128, K: int = 128, flags: int = 0, rank: int = 0, dtype=torch.float32,
                  packed: bool = False) -> int:
     """Row tiles (= dS partial rows) of the kernel ffm_gemm_nt picks for this call."""
     return L.load().ffm_gemm_tiles_m(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
+
+
+def gemm_lgrad_rows(M: int, N: int, K: int, rank: int, dtype, packed: bool = True) -> int:
+    """Row tiles of the FFM_EPI_LGRAD partial products of the dX product of c_proj, or a negative code when the kernel
+    ffm_gemm_nt picks for that call has no such epilogue."""
+    flags = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_DGELU | L.EPI_RANKOP
+    return L.load().ffm_gemm_lgrad_rows(M, N, K, flags, rank, L.dtype_code(dtype), int(packed))
 
 
 def gemm_tiles_n(M: int, N: int, K: int, flags: int = 0, rank: int = 0, dtype=torch.float32, packed: bool = False) -> int:
@@ -200,10 +211,20 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         assert (ro is None) == (ln_in.rk is None) and (ln_in.rk is None or _f32(ln_in.rk).numel() == 32)
         lnx = (L.ptr(ln_in.part), L.ptr(ln_in.c), L.ptr(_f32(ln_in.mean)), L.ptr(_f32(ln_in.rstd)), ln_in.np, int(gelu_deriv),
                L.ptr(ln_in.rk))
+    lgx = (None, None, None)
+    if ro is not None and ro.lgrad is not None:
+        lg_v, lg_c, lg_a = ro.lgrad
+        _dev(lg_v, lg_c, lg_a)
+        flags |= L.EPI_LGRAD
+        rows = gemm_lgrad_rows(M, N, K, rank, a.dtype, b_packed is not None)
+        assert rows > 0 and dgelu_aux is not None and not gelu_deriv, "FFM_EPI_LGRAD: ask gemm_lgrad_rows first"
+        assert _f32(lg_v).shape[0] >= M and lg_v.shape[1] == rank
+        assert min(_f32(lg_c).numel(), _f32(lg_a).numel()) >= rows * N * rank
+        lgx = (L.ptr(lg_v), L.ptr(lg_c), L.ptr(lg_a))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,
-                      L.ptr(_f32(colstats)))
+                      L.ptr(_f32(colstats)), *lgx)
     if colstats is not None:                       # [tiles_m, 2, N] fp32 column sums of the stored output (128x128 kernel)
         _dev(colstats)
         assert b_packed is None and colstats.numel() >= 2 * N * ((M + 127) // 128)

@@ -47,7 +47,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 8   /* 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 9   /* 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -66,6 +66,7 @@ int ffm_abi_version(void);
  * normalised copy of x in HBM. */
 #define FFM_EPI_ROWSTATS  128 /* producer: rowstat_part[tn][m] = {sum, sum of squares} of the stored row over this block's columns */
 #define FFM_EPI_LNIN      256 /* consumer: b / b_packed hold W', bias holds d, ln_c holds c; rows are normalised in the epilogue */
+#define FFM_EPI_LGRAD     512 /* with DGELU | RANKOP: also lg_part_c / lg_part_a, two rank-r gradient partial products (below) */
 
 typedef struct ffm_gemm_args {
     const void* a;      /* [M, K] dtype, row stride lda (elements) */
@@ -127,6 +128,18 @@ typedef struct ffm_gemm_args {
      * column-sum epilogue; ask ffm_gemm_tiles_m with packed = 0 for the row tiles); together with
      * FFM_EPI_ROWSTATS / FFM_EPI_LNIN: FFM_EUNSUP */
     float*       colstat_part;
+    /* FFM_EPI_LGRAD (16-bit panel kernel, with FFM_EPI_DGELU | FFM_EPI_RANKOP, rank % 4 == 0, gelu_deriv == 0; ask
+     * ffm_gemm_lgrad_rows first): the dX product of c_proj holds both [M, N] operands of the two LARGE rank-r gradient
+     * reductions of an MLP block in registers - the rows it stores (c = dL/d pre) and quick_gelu(aux) (the forward's
+     * activation) - so their per-row-tile partial products leave with its epilogue instead of being formed by two
+     * launches of ffm_lora_grad_partial that read 2 x M x N elements once more:
+     *   lg_part_c[tile][n][j] = sum over the tile's rows of c[m][n] * lg_v[m][j]              (dB of c_fc: lg_v = its forward ts)
+     *   lg_part_a[tile][n][j] = sum over the tile's rows of quick_gelu(aux[m][n]) * ts[m][j]  (dA of c_proj: ts = this launch's)
+     * both [ffm_gemm_lgrad_rows][N][rank] fp32, written once per call (sum them with ffm_reduce_partials_multi);
+     * trainers/GLP_OT_SVLoRA.py:450-482 (the autograd of lora_B / lora_A). */
+    const float* lg_v;      /* [M, rank] fp32 */
+    float*       lg_part_c;
+    float*       lg_part_a;
 } ffm_gemm_args;
 
 /*
@@ -141,6 +154,9 @@ typedef struct ffm_gemm_args {
 int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
 /* row tiles (= dS partial rows written under FFM_EPI_RANKOP) of the kernel ffm_gemm_nt picks for this call */
 int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed);
+/* row tiles of lg_part_c / lg_part_a under FFM_EPI_LGRAD for this call (flags with or without the bit), or FFM_EUNSUP when
+ * the kernel ffm_gemm_nt picks for it has no such epilogue (then leave the bit out and call ffm_lora_grad_partial) */
+int ffm_gemm_lgrad_rows(int M, int N, int K, int flags, int rank, int dtype, int packed);
 /* column tiles (= rows of rowstat_part under FFM_EPI_ROWSTATS) of that kernel; FFM_EUNSUP when no kernel serves the
  * flags for this shape (FFM_EPI_ROWSTATS / FFM_EPI_LNIN exist in the bf16 panel kernel only: ask before relying on them) */
 int ffm_gemm_tiles_n(int M, int N, int K, int flags, int rank, int dtype, int packed);

@@ -209,6 +209,59 @@ def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr, h16):
         check(dsp.double().sum(0), pi_rows.t() @ (0.25 * t_fwd.double() * ref_t), 5e-5, "dS")
 
 
+@pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (6250, 16, 2, False), (6304, 4, 3, True), (3000, 8, 3, True)])
+@H16
+def test_gemm_panel_lgrad_partials(ops, M, r, G, use_attr, h16):
+    """FFM_EPI_LGRAD: the dX product of c_proj also leaves the per-row-tile partial products of the two large rank-r
+    gradient reductions of the block - dB(c_fc) = dpre^T ts1 from the rows it stores and dA(c_proj) = act^T us from
+    quick_gelu(pre) and its own ts.  Held to float64 on the 16-bit tensors the kernel itself produced, and to the
+    reduction kernel it replaces (ffm_lora_grad_partial); everything else the launch writes must not move."""
+    dt = h16
+    width, rps = 768, 197
+    N, K = 4 * width, width
+    nlg = ops.gemm_lgrad_rows(M, N, K, r, dt, True)
+    if nlg <= 0:
+        pytest.skip("no FFM_EPI_LGRAD kernel for this shape (the engine then launches the reductions)")
+    flags = 2 | 4 | 32 | 64
+    nrows = ops.gemm_tiles_m(M, N, K, flags, r, dt, True)
+    a, b = rnd(M, K, dt=dt, seed=70), rnd(N, K, dt=dt, scale=K ** -0.5, seed=71)
+    P, S, lw = rnd(K, r, scale=0.1, seed=73), rnd(G, r, seed=74), rnd(N, r, seed=75)
+    nsamp = (M + rps - 1) // rps
+    attr = torch.randint(0, G, (nsamp,), device="cuda", dtype=torch.int32) if use_attr else None
+    rk = torch.zeros(16, K, device="cuda", dtype=dt)
+    ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+    pre = rnd(M, N, dt=dt, seed=78)
+    ts1 = rnd(M, r, seed=79)
+    t_fwd = rnd(M, r, seed=76)
+    bp = ops.pack_b(b)
+
+    def run(lgrad):
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        t, ts = torch.full((M, r), float("nan"), device="cuda"), torch.full((M, r), float("nan"), device="cuda")
+        dsp = torch.full((nrows, G, r), float("nan"), device="cuda")
+        ro = ops.RankOp(rk, S, attr, rps, 0.25, 0.7, t_out=t, ts_out=ts, t_fwd=t_fwd, ds_part=dsp, lgrad=lgrad)
+        ops.gemm_nt(a, b, out, lw=lw, lw_is_kr=True, rankop=ro, b_packed=bp, dgelu_aux=pre)
+        return out, t, ts, dsp
+
+    pc = torch.full((nlg, N, r), float("nan"), device="cuda")
+    pa = torch.full((nlg, N, r), float("nan"), device="cuda")
+    out, t, ts, dsp = run((ts1, pc, pa))
+    out0, t0, ts0, dsp0 = run(None)
+    assert torch.equal(out, out0) and torch.equal(t, t0) and torch.equal(ts, ts0) and torch.equal(dsp, dsp0)
+    assert not torch.isnan(pc).any() and not torch.isnan(pa).any()
+    x = pre.float()
+    act = (x * torch.sigmoid(1.702 * x)).to(dt)                       # the forward's stored activation, to 16-bit rounding
+    ref_c = out.double().t() @ ts1.double()
+    ref_a = act.double().t() @ ts.double()
+    check(pc.double().sum(0), ref_c, 2e-4, "dB(c_fc) partials")
+    # (quick_gelu by v_exp / v_rcp: a 16-bit rounding flips here and there against torch's sigmoid)
+    check(pa.double().sum(0), ref_a, 2e-3, "dA(c_proj) partials")
+    ns = ops.lora_grad_splits(M)
+    part = torch.empty(ns * N * r, device="cuda")
+    ops.lora_grad_partial(out, ts1, r, part)
+    check(pc.double().sum(0), part.view(ns, N, r).double().sum(0), 2e-5, "against ffm_lora_grad_partial")
+
+
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 def test_gemm_gelu_and_dgelu(ops, dt):
     M, N, K = 260, 256, 128
