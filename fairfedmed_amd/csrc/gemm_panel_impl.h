@@ -72,6 +72,11 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LGRAD: a V element as the 16-bit pair {hi, lo = v - hi} in one dword (split ONCE per block, not once per wave and row group)
+__device__ __forceinline__ uint32_t lg_split(float v) {
+    const bf16_t h = (bf16_t)v, l = (bf16_t)(v - (float)h);
+    return (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+}
 // LGRAD: the 2 NF transposed reads of one [32][16 NF] image (rows 8 g + q / + 4 of the lane's group, 16 columns each; the
 // two images are interleaved row by row: row stride 2 TROWX, the second image TROWX behind the first), all on
 // ONE address register with immediate offsets (as computed addresses the compiler kept all of them live across the row
@@ -491,6 +496,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         }
     }
     __syncthreads();
+    if constexpr (LGRAD) {
+        // lg_v tile -> hi | lo pairs in place, rows beyond M zeroed (read again in the epilogue, many barriers from here)
+        for (int e = tid; e < BMp * r; e += PT)
+            reinterpret_cast<uint32_t*>(V1F)[e] = (m0 + e / r < p.M) ? lg_split(V1F[e]) : 0u;
+    }
     FFM_STAMP(1);
 
     // VMEM issue order of step kt (nA = G::NI pieces, the same on every wave):
@@ -671,7 +681,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PF = NRG < PFMAX ? NRG : PFMAX;
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
-    float* V2F = reinterpret_cast<float*>(smem + BMp * 128);          // LGRAD: the same rows in fp32, [BM][16]
+    uint32_t* V2F = reinterpret_cast<uint32_t*>(smem + BMp * 128);    // LGRAD: the same rows as fp32-accurate hi | lo pairs, [BM][16]
     float* Cw = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + colw * (32 * PITCH);
     // ROWSTATS: per-wave partial row sums [PW][BM][2] behind the four waves' output stages
     float* RowP = reinterpret_cast<float*>(smem + (RK ? BMp * 192 : 0)) + CW * (32 * PITCH);
@@ -773,7 +783,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     else
                     TsA[(row0 + e) * 32 + j] = (bf16_t)tsv[e];
                     TsA[(row0 + e) * 32 + 16 + j] = (bf16_t)0.f;
-                    if constexpr (LGRAD) V2F[(row0 + e) * 16 + j] = tsv[e];      // fp32 ts rows (zero beyond M and beyond r)
+                    if constexpr (LGRAD) V2F[(row0 + e) * 16 + j] = lg_split(tsv[e]);      // ts rows as hi | lo pairs (zero beyond M and beyond r)
                 }
                 if (mine && jok) {
 #pragma unroll
@@ -1039,17 +1049,23 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
 #pragma unroll
             for (int ten = 0; ten < 2; ++ten) {
-                frag_t vh, vl;
+                // (rows beyond M are zero in both tables; the phantom rows of an odd MF's last group are clamped AND masked)
+                uint32_t pv[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int R = rg * 32 + 8 * fgrp + t;
-                    const bool ok = R < BMp && m0 + R < p.M && frow < r;
                     const int Rc = R < BMp ? R : BMp - 1;
-                    float vv = ten ? V2F[Rc * 16 + frow] : V1F[Rc * r + (frow < r ? frow : 0)];      // (unconditional: no exec-masked branch per read)
-                    vv = ok ? vv : 0.f;
-                    vh[t] = (bf16_t)vv;
-                    vl[t] = (bf16_t)(vv - (float)vh[t]);
+                    pv[t] = ten ? V2F[Rc * 16 + frow] : reinterpret_cast<const uint32_t*>(V1F)[Rc * r + (frow < r ? frow : 0)];
+                    if constexpr (rg == NRG - 1 && (MF & 1)) pv[t] = R < BMp ? pv[t] : 0u;
+                    if (!ten) pv[t] = frow < r ? pv[t] : 0u;             // (V2F holds zeros in the slots beyond r)
                 }
+                u32x4 ph, pl;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ph[k] = __builtin_amdgcn_perm(pv[2 * k + 1], pv[2 * k], 0x05040100u);
+                    pl[k] = __builtin_amdgcn_perm(pv[2 * k + 1], pv[2 * k], 0x07060302u);
+                }
+                const frag_t vh = __builtin_bit_cast(frag_t, ph), vl = __builtin_bit_cast(frag_t, pl);
                 panel_u32x2 xr[NF][2];
                 if (ten == 0) lg_tr_reads<NF, TROW, 0>(xr, t_rd); else lg_tr_reads<NF, TROW, 1>(xr, t_rd);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

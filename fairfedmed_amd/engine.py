@@ -687,6 +687,8 @@ class FairLoRAEngine:
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us1, st.t1[i][:rows], pt["fc_S"])
                 # ---- off the critical path: the four rank-r gradient reductions of this block
                 def reductions(i=i, blk=blk, gi=gi, act=act, dpre=dpre, us2=us2, us1=us1, pt=pt, xm=xm, h2=h2, last=last, lg=lg):
+                    # (the step's tail - block 0's last reduction and the sum of its partials - on the chain's own stream
+                    # instead of behind two cross-stream events: measured, 4.699 -> 4.692 ms per step, nothing; not kept)
                     self._ev_record(self.ev_layer[i], main)
                     self._ev_wait(self.grad_stream, self.ev_layer[i])
                     with self._on(self.grad_stream):
