@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""What the side-stream work costs the vision chain: step time with the text tower / the LoRA-gradient reductions
-removed (results are then wrong; timing experiment only)."""
+"""What the side-stream work costs the vision chain: step time with the text tower / the LoRA-gradient reduction launches
+removed (results are then wrong; timing experiment only).  ONE engine per process (a second engine's side
+stream can land on the main stream's hardware queue); run it under FFM_LGRAD=0 FFM_SKINNY_NT=1 for the round-3 arrangement."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -25,22 +26,20 @@ def run(eng, n=30):
 
 
 eng = FairLoRAEngine(mcfg, sd, dtype=torch.bfloat16, max_images=32)
-print("full step            : %.3f ms" % run(eng))
+real = (eng._text_forward, eng._text_backward, ops.lora_grad_partial, ops.lora_grad_partial_ln)
+none = lambda *a, **k: None
 
-eng2 = FairLoRAEngine(mcfg, sd, dtype=torch.bfloat16, max_images=32)
-eng2.forward_backward(img, attr, label)                      # one real step fills tbar_buf etc.
-eng2.step_plans.clear()
-eng2._text_forward = lambda *a, **k: None
-eng2._text_backward = lambda *a, **k: None
-print("no text tower        : %.3f ms" % run(eng2))
 
-eng3 = FairLoRAEngine(mcfg, sd, dtype=torch.bfloat16, max_images=32)
-real = ops.lora_grad_partial
-ops.lora_grad_partial = lambda *a, **k: None
-print("no LoRA-grad partials: %.3f ms" % run(eng3))
-eng3.step_plans.clear()
-eng3._text_forward = lambda *a, **k: None
-eng3._text_backward = lambda *a, **k: None
-eng3.tbar_buf.copy_(eng.tbar_buf)
-print("neither              : %.3f ms" % run(eng3))
-ops.lora_grad_partial = real
+def variant(name, text, red):
+    eng.step_plans.clear()
+    eng._text_forward, eng._text_backward = (real[0], real[1]) if text else (none, none)
+    ops.lora_grad_partial, ops.lora_grad_partial_ln = (real[2], real[3]) if red else (none, none)
+    print("%-28s: %.3f ms" % (name, run(eng)), flush=True)
+
+
+for rep in range(2):
+    variant("full step", True, True)
+    variant("no text tower", False, True)
+    variant("no LoRA-grad launches", True, False)
+    variant("neither", False, False)
+ops.lora_grad_partial, ops.lora_grad_partial_ln = real[2], real[3]
