@@ -811,8 +811,8 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if (!args || !args->a || !args->b || !args->c) return FFM_EINVAL;
     const ffm_gemm_args& a = *args;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
-    const size_t esb = es;
-    if (dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3) return FFM_EINVAL;
+    const size_t esb = dtype == FFM_F32_X3_W16 ? 2 : es;                  // (FFM_F32_X3_W16: f32 activations, half weights)
+    if (dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3 && dtype != FFM_F32_X3_W16) return FFM_EINVAL;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return FFM_EINVAL;
     if (((size_t)a.K * esb) % KT_BYTES != 0 || a.N % 8 != 0) return FFM_EINVAL;
     if (((size_t)a.lda * es) % 16 || ((size_t)a.ldb * esb) % 16 || ((size_t)a.ldc * es) % 16) return FFM_EINVAL;
@@ -832,9 +832,9 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (ffm_skinny_ok(a, dtype) && !a.colstat_part) {                    // (column sums: the 128x128 kernel's epilogue)
         static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
-        if (!off || dtype == FFM_F32_X3) return ffm_skinny_launch(a, dtype, s);
+        if (!off || dtype == FFM_F32_X3 || dtype == FFM_F32_X3_W16) return ffm_skinny_launch(a, dtype, s);
     }
-    if (dtype == FFM_F32_X3) return FFM_EUNSUP;                           // split-operand products: skinny shapes only
+    if (dtype == FFM_F32_X3 || dtype == FFM_F32_X3_W16) return FFM_EUNSUP;      // split-operand products: skinny shapes only
     if (a.flags & FFM_EPI_LGRAD) {                                        // gradient partial products: one panel tile only
         const int cfgg = (a.b_packed && !a.colstat_part) ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
         return cfgg >= 0 ? ffm_panel_launch(a, cfgg, s) : FFM_EUNSUP;

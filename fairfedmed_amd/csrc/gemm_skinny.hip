@@ -83,6 +83,32 @@ template <> struct SkOps<float, float, true> {
     static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) { mma_split(acc, prep(a), b); }
 };
 
+// <float, half, X3>: FFM_F32_X3_W16 - the weight rounded to IEEE half in memory (half the bytes), widened and split into the
+// same bf16 hi + lo pair in the kernel (exact: 11 significant bits = 8 + 3), the activations as under X3
+typedef _Float16 sk_half8 __attribute__((ext_vector_type(8)));
+template <> struct SkOps<float, _Float16, true> {
+    typedef SkOps<float, float, true> F;
+    static constexpr int KS = F::KS, UN = F::UN;
+    typedef F::afrag afrag;
+    typedef sk_half8 braw;
+    typedef F::bprep bprep;
+    static __device__ __forceinline__ void loadA(afrag& f, const float* p) { F::loadA(f, p); }
+    static __device__ __forceinline__ void loadB(braw& f, const _Float16* p) { f = *reinterpret_cast<const sk_half8*>(p); }
+    static __device__ __forceinline__ bprep prep(const afrag& a) { return F::prep(a); }
+    static __device__ __forceinline__ bprep prep(const braw& b) {
+        bprep r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = (float)b[i];
+            r.h[i] = (bf16_t)x;
+            r.l[i] = (bf16_t)(x - (float)r.h[i]);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ void mma_split(f32x4& acc, const bprep& x, const bprep& b) { F::mma_split(acc, x, b); }
+    static __device__ __forceinline__ void mma(f32x4& acc, const afrag& a, const bprep& b) { F::mma_split(acc, F::prep(a), b); }
+};
+
 template <typename TA, typename TB, bool X3, int NW, int FL>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
     typedef SkOps<TA, TB, X3> O;
@@ -188,9 +214,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(ffm_gemm_args p) {
 // t < NT finishes tile t, and the partial sums meet in the one-tile kernel's order (wave 0, 1, ...): bit-identical results.
 // MFC: row fragments (3 for M <= 48: the text tower's 40 rows), UN: K32 steps of loads in flight (2 when a wave's K slice is
 // two steps, K = 512 on 8 waves).
-template <int NW, int FL, int NT, int MFC, int UN>
+template <typename TB, int NW, int FL, int NT, int MFC, int UN>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p) {
-    typedef SkOps<float, float, true> O;
+    typedef SkOps<float, TB, true> O;
     constexpr int KS = O::KS, KG = KS / 4;
     static_assert(NT <= NW, "one finishing wave per tile");
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -204,9 +230,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
     const int groups = p.N / (SK_COLS * NT);
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     const int n0 = grp * SK_COLS * NT;
-    const float* bp[NT];
+    const TB* bp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = reinterpret_cast<const float*>(p.b) + (size_t)(n0 + t * SK_COLS + col) * p.ldb + k0 + kg * KG;
+    for (int t = 0; t < NT; ++t) bp[t] = reinterpret_cast<const TB*>(p.b) + (size_t)(n0 + t * SK_COLS + col) * p.ldb + k0 + kg * KG;
     const float* ap[MFC];
 #pragma unroll
     for (int mf = 0; mf < MFC; ++mf) {
@@ -220,8 +246,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
 #pragma unroll
         for (int mf = 0; mf < MFC; ++mf) acc[t][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < kw; ks += KS * UN) {
-        O::braw bf[UN][NT];
-        O::afrag af[UN][MFC];
+        typename O::braw bf[UN][NT];
+        typename O::afrag af[UN][MFC];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (ks + KS * u < kw) {
@@ -235,13 +261,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (ks + KS * u < kw) {
-                O::bprep b[NT];
+                typename O::bprep b[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b[t] = O::prep(bf[u][t]);
 #pragma unroll
                 for (int mf = 0; mf < MFC; ++mf)
                     if (mf < nmf) {
-                        const O::bprep a = O::prep(af[u][mf]);
+                        const typename O::bprep a = O::prep(af[u][mf]);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) O::mma_split(acc[t][mf], a, b[t]);
                     }
@@ -313,17 +339,17 @@ inline int sk_nt(int N) {
     return nt;
 }
 
-template <int NW, int FL, int NT, int MFC, int UN>
+template <typename TB, int NW, int FL, int NT, int MFC, int UN>
 int launch_nt(const ffm_gemm_args& a, hipStream_t s) {
     constexpr int lds = NW * NT * MFC * 64 * 16;
     static bool done = false;                         // one per instantiation
     if (!done && lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_nt_kernel<NW, FL, NT, MFC, UN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_nt_kernel<TB, NW, FL, NT, MFC, UN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
     }
     done = true;
-    hipLaunchKernelGGL((gemm_skinny_nt_kernel<NW, FL, NT, MFC, UN>), dim3(sk_grid(a.N / (SK_COLS * NT))), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((gemm_skinny_nt_kernel<TB, NW, FL, NT, MFC, UN>), dim3(sk_grid(a.N / (SK_COLS * NT))), dim3(NW * 64), lds, s, a);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -333,9 +359,9 @@ int launch(const ffm_gemm_args& a, hipStream_t s) {
     if constexpr (X3 && NW == 8) {
         // (the text tower's shapes: 40 rows, K = 512 or 2048 on 8 waves -> 2 or 8 K32 steps per wave)
         const int nt = a.M <= 48 ? sk_nt(a.N) : 1, steps = a.K / NW / 32;
-        if (nt == 4 && steps <= 2) return launch_nt<NW, FL, 4, 3, 2>(a, s);
-        if (nt >= 2 && steps <= 2) return launch_nt<NW, FL, 2, 3, 2>(a, s);
-        if (nt >= 2) return launch_nt<NW, FL, 2, 3, 4>(a, s);
+        if (nt == 4 && steps <= 2) return launch_nt<TB, NW, FL, 4, 3, 2>(a, s);
+        if (nt >= 2 && steps <= 2) return launch_nt<TB, NW, FL, 2, 3, 2>(a, s);
+        if (nt >= 2) return launch_nt<TB, NW, FL, 2, 3, 4>(a, s);
     }
     hipLaunchKernelGGL((gemm_skinny_kernel<TA, TB, X3, NW, FL>), dim3(sk_grid(a.N / SK_COLS)), dim3(NW * 64), 0, s, a);
     FFM_CHECK_LAUNCH();
@@ -363,7 +389,7 @@ int launch_waves(const ffm_gemm_args& a, hipStream_t s) {
 }  // namespace
 
 bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
-    if ((dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3) || a.M > 16 * SK_MF || a.N % SK_COLS || a.K % 128)
+    if ((dtype != FFM_BF16 && dtype != FFM_F32 && dtype != FFM_F32_X3 && dtype != FFM_F32_X3_W16) || a.M > 16 * SK_MF || a.N % SK_COLS || a.K % 128)
         return false;
     switch (a.flags) {
         case 0:
@@ -378,5 +404,6 @@ bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
 int ffm_skinny_launch(const ffm_gemm_args& a, int dtype, hipStream_t s) {
     if (dtype == FFM_F32) return launch_waves<float, float, false>(a, s);
     if (dtype == FFM_F32_X3) return launch_waves<float, float, true>(a, s);
+    if (dtype == FFM_F32_X3_W16) return launch_waves<float, _Float16, true>(a, s);
     return launch_waves<bf16_t, bf16_t, false>(a, s);
 }

@@ -194,6 +194,9 @@ class _Stack:
                  rank: int, dtype, device, x3: bool = False):
         self.width, self.heads, self.layers, self.L = width, heads, layers, tokens
         self.causal, self.rank, self.dtype = causal, rank, dtype
+        # FFM_TEXT_W16=1: the frozen weights of a float32 tower that runs beside a 16-bit vision tower (x3) as IEEE half in
+        # memory (FFM_F32_X3_W16) - see FairLoRAEngine.__init__; measured: no gain, off by default
+        self.wdtype = torch.float16 if (x3 and os.environ.get("FFM_TEXT_W16", "0") == "1") else dtype
         # x3: float32 tower whose products run on the bf16 matrix cores as hi/lo pairs (FFM_F32_X3)
         # (ops.gemm_nt is looked up per call: bench.py wraps it to time the launches)
         # FFM_GELU_DERIV=1: the MLP's saved tensor is quick_gelu'(pre) instead of pre (ffm_gemm_args.gelu_deriv): the forward's
@@ -298,6 +301,12 @@ class FairLoRAEngine:
         # the tiny model (tools/auc_diag.py, AUC after equal rounds against the reference): text tower in bf16 0.0026 off,
         # f32 activations on bf16 weights 0.0020, all f32 0.0005.  Beside a bf16 vision tower the 40-row products run on
         # the bf16 matrix cores as hi/lo pairs (FFM_F32_X3, csrc/gemm_skinny.hip) instead of the 16x slower f32 MFMA.
+        # Round 4, FFM_TEXT_W16=1: the FROZEN weights of the tower as IEEE half (FFM_F32_X3_W16: 11 significant bits, what
+        # the reference's own PREC="fp16" holds, clip/model.py:609-630; split exactly into the bf16 hi + lo pair in the
+        # kernel), 151 instead of 302 MB of text weights per step beside the vision chain; activations, gradients and
+        # accumulation stay float32.  Measured (three alternating pairs, one call): 4.590 against 4.592 ms per step -
+        # with two column tiles per block the weights are not what the chain feels any more.
+        # Off by default: float32 weights.
         self.txt = _Stack(t.width, t.heads, t.layers, self.txt_len, self.n_text, True, 0, torch.float32, self.device,
                           x3=(_is16(dtype)))
         dev, f32 = self.device, torch.float32
@@ -439,8 +448,8 @@ class FairLoRAEngine:
 
     def _load_stack(self, stack: _Stack, sd, prefix: str, lora: bool) -> None:
         old = stack.blocks if stack.blocks else None
-        W = lambda x: self._w(x, stack.dtype)
-        WT = lambda x: self._wt(x, stack.dtype)
+        W = lambda x: self._w(x, stack.wdtype)
+        WT = lambda x: self._wt(x, stack.wdtype)
         stack.blocks = []
         for i in range(stack.layers):
             p = f"{prefix}transformer.resblocks.{i}."

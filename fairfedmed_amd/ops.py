@@ -157,11 +157,13 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
             x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
             colstats: Optional[Tensor] = None, gelu_deriv: bool = False) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
-    x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores.
+    x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores; with
+    `b` in float16: FFM_F32_X3_W16, the same on a weight rounded to IEEE half in memory (half the bytes).
     gelu_deriv (with gelu_out / dgelu_aux): `out` receives / `dgelu_aux` holds quick_gelu'(pre) instead of pre
     (ffm_gemm_args.gelu_deriv)."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
-    assert a.dtype == b.dtype == out.dtype and (not x3 or a.dtype == torch.float32)
+    w16 = x3 and b.dtype == torch.float16            # FFM_F32_X3_W16: float32 activations on a weight stored as IEEE half
+    assert a.dtype == out.dtype and (b.dtype == a.dtype or w16) and (not x3 or a.dtype == torch.float32)
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and tuple(out.shape) == (M, N)
@@ -229,7 +231,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         _dev(colstats)
         assert b_packed is None and colstats.numel() >= 2 * N * ((M + 127) // 128)
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
-    _call("ffm_gemm_nt", C.byref(args), L.F32_X3 if x3 else L.dtype_code(a.dtype), L.stream_ptr())
+    _call("ffm_gemm_nt", C.byref(args), (L.F32_X3_W16 if w16 else L.F32_X3) if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
 
 

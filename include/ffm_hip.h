@@ -38,6 +38,11 @@ extern "C" {
 /* IEEE half storage (the reference's PREC="fp16", federated_main.py:85 / clip/model.py:609-630): activations and
  * frozen weights in fp16, fp32 accumulation and fp32 trainable tensors exactly as under FFM_BF16 */
 #define FFM_F16 3
+/* ffm_gemm_nt only: FFM_F32_X3 with the weight operand `b` stored as IEEE half [N, K] (ldb in half elements): a frozen
+ * weight rounded to 11 significant bits - what the reference's own PREC="fp16" holds (clip/model.py:609-630) - is split
+ * exactly into the bf16 hi + lo pair in the kernel, so the products are those of FFM_F32_X3 on the rounded weight at
+ * half its bytes (the text tower's weights are what its 40-row products move: DESIGN.md section 4.6) */
+#define FFM_F32_X3_W16 4
 
 #define FFM_OK 0
 #define FFM_EINVAL (-1)

@@ -622,16 +622,19 @@ def test_skinny_gemm_text_tower_shapes(M, N, K, mode):
 
 @pytest.mark.parametrize("M,N,K", [(40, 1536, 512), (40, 512, 2048), (40, 2048, 512), (1, 512, 128), (64, 128, 128),
                                    (33, 48, 640), (8, 512, 512)])
-@pytest.mark.parametrize("x3", [True, False], ids=["x3", "exact"])
+@pytest.mark.parametrize("x3", [True, False, "w16"], ids=["x3", "exact", "x3w16"])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_res", "bias_gelu", "dgelu"])
 def test_skinny_gemm_f32(M, N, K, x3, mode):
     """The text tower's products in float32 (engine.py: always, also beside a bf16 vision tower): FFM_F32_X3 (operands
-    split into bf16 hi + lo pairs, three MFMAs at the bf16 rate) and the exact f32 MFMA, 4 or 8 waves splitting K.
-    Reference: float64 on the same operands."""
+    split into bf16 hi + lo pairs, three MFMAs at the bf16 rate), the same on a weight stored as IEEE half
+    (FFM_F32_X3_W16: the half value is split exactly, so the reference is float64 on the ROUNDED weight at the same
+    tolerance) and the exact f32 MFMA, 4 or 8 waves splitting K.  Reference: float64 on the same operands."""
     from fairfedmed_amd import ops
     g = torch.Generator(device="cuda").manual_seed(M * 1000 + N + K)
     a = torch.randn(M, K, device="cuda", generator=g)
     w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    if x3 == "w16":
+        w, x3 = w.half(), True
     bias = torch.randn(N, device="cuda", generator=g)
     res = torch.randn(M, N, device="cuda", generator=g)
     aux = torch.randn(M, N, device="cuda", generator=g)
