@@ -218,9 +218,9 @@ template <typename TB, int NW, int FL, int NT, int MFC, int UN>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p) {
     typedef SkOps<float, TB, true> O;
     constexpr int KS = O::KS, KG = KS / 4;
-    static_assert(NT <= NW, "one finishing wave per tile");
+    static_assert(NT <= 8 && NW >= 4, "at most four tiles are finished at a time, one wave each");
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);                // [NW][NT][MFC][64]
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);                // [NW][min(NT, 4)][MFC][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, kg = lane >> 4;
@@ -274,22 +274,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
             }
         }
     }
+    // the partial sums meet in LDS, TG tiles at a time (8 tiles per block: two rounds through the same 96 KiB)
+    constexpr int TG = NT > 4 ? 4 : NT;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t0 = 0; t0 < NT; t0 += TG) {
+    if (t0) __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int mf = 0; mf < MFC; ++mf)
-            if (mf < nmf) red[((wave * NT + t) * MFC + mf) * 64 + lane] = acc[t][mf];
+            if (mf < nmf) red[((wave * TG + t) * MFC + mf) * 64 + lane] = acc[t0 + t][mf];
     __syncthreads();
-    if (wave < NT) {
+    if (wave < TG) {
         const int t = wave;
-        const int n = n0 + t * SK_COLS + col;
+        const int n = n0 + (t0 + t) * SK_COLS + col;
         const float bias = (FL & FFM_EPI_BIAS) ? p.bias[n] : 0.f;
         float* C = reinterpret_cast<float*>(p.c);
         for (int mf = 0; mf < nmf; ++mf) {
-            f32x4 v = red[((0 * NT + t) * MFC + mf) * 64 + lane];
+            f32x4 v = red[((0 * TG + t) * MFC + mf) * 64 + lane];
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
-                const f32x4 o = red[((w * NT + t) * MFC + mf) * 64 + lane];
+                const f32x4 o = red[((w * TG + t) * MFC + mf) * 64 + lane];
                 v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
             }
 #pragma unroll
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
                 }
             }
         }
+    }
     }
     if (grp + (int)gridDim.x < groups) __syncthreads();           // `red` is rewritten by the next tile group
     }
@@ -341,7 +347,7 @@ inline int sk_nt(int N) {
 
 template <typename TB, int NW, int FL, int NT, int MFC, int UN>
 int launch_nt(const ffm_gemm_args& a, hipStream_t s) {
-    constexpr int lds = NW * NT * MFC * 64 * 16;
+    constexpr int lds = NW * (NT > 4 ? 4 : NT) * MFC * 64 * 16;
     static bool done = false;                         // one per instantiation
     if (!done && lds > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_nt_kernel<TB, NW, FL, NT, MFC, UN>),
@@ -359,6 +365,8 @@ int launch(const ffm_gemm_args& a, hipStream_t s) {
     if constexpr (X3 && NW == 8) {
         // (the text tower's shapes: 40 rows, K = 512 or 2048 on 8 waves -> 2 or 8 K32 steps per wave)
         const int nt = a.M <= 48 ? sk_nt(a.N) : 1, steps = a.K / NW / 32;
+        // (eight tiles per block for the wide products - 16 blocks, two rounds through the meeting buffer - measured: 4.66
+        // against 4.57 ms per step; not instantiated)
         if (nt == 4 && steps <= 2) return launch_nt<TB, NW, FL, 4, 3, 2>(a, s);
         if (nt >= 2 && steps <= 2) return launch_nt<TB, NW, FL, 2, 3, 2>(a, s);
         if (nt >= 2) return launch_nt<TB, NW, FL, 2, 3, 4>(a, s);
