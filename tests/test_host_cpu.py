@@ -61,6 +61,35 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ffm_lora_grad_splits(6304) > 0 and lib.ffm_lora_down_blocks(6304, 768, 8, _lib.BF16) > 0
 
 
+def test_gemm_args_mirror_the_header_field_by_field():
+    """fairfedmed_amd/_lib.GemmArgs is the ctypes image of `ffm_gemm_args` (include/ffm_hip.h): same field names in the
+    same order, pointers / int32 / float where the header has them (a field appended to one and not the other shifts
+    every later pointer silently)."""
+    hdr = open(os.path.join(ROOT, "include", "ffm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct ffm_gemm_args {"):hdr.index("} ffm_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"^(const )?(void|float|int32_t)\s*(\*?)\s*(.+)$", decl)
+        assert m, decl
+        kind = ctypes.c_void_p if m.group(3) else {"float": ctypes.c_float, "int32_t": ctypes.c_int32}[m.group(2)]
+        for name in m.group(4).split(","):
+            name = name.strip()
+            star = name.startswith("*")
+            fields.append((name.lstrip("* "), ctypes.c_void_p if star else kind))
+    assert [(n, t) for n, t in _lib.GemmArgs._fields_] == fields
+    # FFM_EPI_LGRAD: the query answers without a GPU - the 8-wave 208 x 384 tile serves the bench shape (31 row tiles), no
+    # kernel serves a shape that tile does not take, and an odd rank is refused
+    l = _lib.load()
+    fl = _lib.EPI_LORA | _lib.EPI_LORA_KR | _lib.EPI_DGELU | _lib.EPI_RANKOP
+    assert l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.BF16, 1) == 31 == l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.F16, 1)
+    assert l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.BF16, 0) < 0 and l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 6, _lib.BF16, 1) < 0
+    assert l.ffm_gemm_lgrad_rows(6304, 768, 3072, fl, 8, _lib.BF16, 1) < 0
+
+
 def test_registry_semantics():
     r = Registry("T")
 
