@@ -331,6 +331,7 @@ class FairLoRAEngine:
         self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
+        self._counts_buf = None                       # enable_step_counts()
         self.tbar_buf = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.ot = cfg.ot if cfg.ot != "None" else None
         if self.ot:
@@ -1012,6 +1013,10 @@ class FairLoRAEngine:
         self._ev_record(self.ev_head_bwd, main)
         self._ev_wait(self.side, self.ev_head_bwd)
         with self._on(self.side):
+            if self._counts_buf is not None:
+                # the batch's evaluator counts for the trainer's per-step summary (enable_step_counts): prob is final, and
+                # beside the backward pass the 20 us launch costs the chain nothing (behind the SGD step it sat between steps)
+                ops.eval_counts(self.prob[:b], self.label_buf[:b], None, 0, method="pairs", out=self._counts_buf)
             self._text_backward(self.side)
         self._ev_record(self.ev_text_bwd, self.side)
         self._vision_backward(b, S, has_attr)
@@ -1049,7 +1054,10 @@ class FairLoRAEngine:
                 ops.reduce_partials(self.wpart, images * nblk, nw, self.params.grad[off:off + nw])
             if self.grad_scale != 1.0:
                 ops.scale_check(self.params.grad, 1.0 / self.grad_scale, self.finite)
-        return {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
+        out = {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
+        if self._counts_buf is not None:
+            out["counts"] = self._counts_buf          # ffm_eval_counts of (prob, label): rows {unknown, all}
+        return out
 
     @torch.no_grad()
     def sgd_step(self, lr: float, momentum: float, weight_decay: float, repeats: int = 1) -> None:
@@ -1057,6 +1065,15 @@ class FairLoRAEngine:
         p = self.params
         ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0, repeats)
         p.steps += repeats
+
+    def enable_step_counts(self, on: bool = True) -> None:
+        """Binary tasks: every training step also leaves ffm_eval_counts(prob, label) in out["counts"] (int64 [2, 10]: the
+        integers behind the reference's per-step accuracy / AUC summary, trainers/GLP_OT_SVLoRA.py:959-970), computed on the
+        side stream beside the backward pass."""
+        want = on and self.cfg.n_cls == 2
+        if want != (self._counts_buf is not None):
+            self._counts_buf = torch.zeros(2, ops.EVAL_SLOTS, device=self.device, dtype=torch.int64) if want else None
+            self.step_plans.clear()
 
     def set_overlap(self, on: bool) -> None:
         """on: text tower and LoRA-gradient reductions run on their own streams beside the vision chain

@@ -465,7 +465,8 @@ EVAL_SLOTS = 10
 EVAL_SORT_FROM = 32768      # samples from which the O(N log N) evaluator replaces the all-pairs kernel
 
 
-def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups: int, method: str = "auto") -> Tensor:
+def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups: int, method: str = "auto",
+                out: Optional[Tensor] = None) -> Tensor:
     """Integer counts behind every score of the binary-task evaluator: int64 [(G + 2), 10] on the device (rows: groups
     0..G-1, unknown, all).  method: 'pairs' (ffm_eval_counts, all pairs), 'sort' (ffm_eval_counts_sorted, for large test
     sets), 'auto' (by N); the two give identical integers."""
@@ -475,7 +476,9 @@ def eval_counts(prob: Tensor, label: Tensor, attr: Optional[Tensor], num_groups:
     assert label.dtype == torch.int64 and label.is_contiguous() and label.numel() == N
     assert attr is None or (attr.dtype == torch.int64 and attr.is_contiguous() and attr.numel() == N)
     assert method in ("auto", "pairs", "sort")
-    out = torch.empty(num_groups + 2, EVAL_SLOTS, device=prob.device, dtype=torch.int64)
+    if out is None:
+        out = torch.empty(num_groups + 2, EVAL_SLOTS, device=prob.device, dtype=torch.int64)
+    assert out.dtype == torch.int64 and out.is_contiguous() and tuple(out.shape) == (num_groups + 2, EVAL_SLOTS) and out.is_cuda
     if method == "sort" or (method == "auto" and N >= EVAL_SORT_FROM):
         if recording():
             # refused BEFORE anything is allocated or launched: a recorded launch would keep the raw pointer of the

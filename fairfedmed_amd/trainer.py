@@ -224,6 +224,11 @@ class GLP_OT_SVLoRA:
             bs *= first["img"].shape[1] // mcfg.dim_per_3d_slice
         self.model = CustomCLIP(mcfg, sd, dtype=dtype, max_images=bs, device=str(self.device))
         self.engine = self.model.engine
+        # the per-step summary's evaluator counts ride inside the step, beside the backward pass (binary tasks, device
+        # metrics: the default); TRAIN.HOST_METRICS / a fairness term keep the host path, which does not read them
+        tc = getattr(cfg, "TRAIN", NS())
+        if not getattr(tc, "HOST_METRICS", False) and getattr(cfg.TRAINER, "LAMBDA_FAIRNESS", 0.0) == 0.0:
+            self.engine.enable_step_counts()
         self._finite_acc = torch.ones(1, device=self.device, dtype=torch.int32)
         o = cfg.OPTIM
         self.optim = NS(lr0=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY,
@@ -332,8 +337,10 @@ class GLP_OT_SVLoRA:
             self.check_finite()
         if want and out["prob"].shape[1] == 2 and (lam == 0.0 or attr is None or amp) \
                 and not getattr(train_cfg, "HOST_METRICS", False):
-            summary = _DeviceSummary(self, out["loss"].clone(),
-                                     ops.eval_counts(out["prob"], label.contiguous(), None, 0))
+            # (the counts come with the step when the engine was asked for them - build_model - and are copied out of its
+            # static buffer like the loss; otherwise they are formed here, behind the SGD step)
+            counts = out["counts"].clone() if "counts" in out else ops.eval_counts(out["prob"], label.contiguous(), None, 0)
+            summary = _DeviceSummary(self, out["loss"].clone(), counts)
         elif want:
             self.check_finite()
             logits, prob = out["logits"], out["prob"]
