@@ -747,7 +747,7 @@ int run_bwd3(const void* qkv, const void* out, const void* dout, const float* ls
     const dim3 grid(((BH + 7) / 8) * 16), block(64 * Geo<NT>::NW);
     // (the dK/dV kernel on a second stream BESIDE the dQ kernel - a timing probe with a stale delta, to price ONE launch
     // holding both kernels' blocks with delta recomputed in the dK/dV blocks: 4.74 against 4.72 ms per step, three alternating
-    // pairs - nothing; the probe is in the history, commit "attention: dK/dV beside dQ probe")
+    // pairs - nothing)
     hipLaunchKernelGGL((attn3_bwd_dq_kernel<T, NT>), grid, block, lds_dq, s, (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv,
                        delta, L, heads, BH, a3_map());
     FFM_CHECK_LAUNCH();
