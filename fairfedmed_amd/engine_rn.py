@@ -173,6 +173,7 @@ class _Bneck:
         else:
             self.gid = e(Ro, out)
         self.ev = torch.cuda.Event()
+        self.rplans = {}                                          # images -> ReducePlan of this block's LoRA sites
         self.ev_d = [torch.cuda.Event() for _ in range(4)]        # downsample branch: fork / join, forward and backward
 
     def load(self, sd, putw) -> None:
@@ -280,7 +281,18 @@ class _Bneck:
             with e._on(e.grad_stream):
                 self.c3.grads(self.dz3[:ro], a)
                 self.c1.grads(self.dz1[:ri], x)
+                # ... and the sum of this block's partials behind them (round 4: ONE launch for every site of the trunk at the
+                # end of the backward pass sat in the step's tail for 92 us - layer1's sites alone have 784 partial rows)
+                self.reduce_plan(images).run()
         return self.dx[:ri]
+
+    def reduce_plan(self, images: int) -> "ops.ReducePlan":
+        if images not in self.rplans:
+            ent = []
+            for site, H in self.loras():
+                ent += site.reduce_entries(images * H * H)
+            self.rplans[images] = ops.ReducePlan(ent, self.eng.device)
+        return self.rplans[images]
 
     def _down_bwd(self, g: Tensor, images: int) -> None:
         e, p, W = self.eng, self.p, self.eng.rnw
@@ -543,6 +555,7 @@ class RN50Engine(FairLoRAEngine):
                 self.ap["c"].grads(self.dfeat[:rows], self.att_o[:rows])
                 for i, n in enumerate("qkv"):
                     self.ap[n].grads(dqkv[:, i * E:(i + 1) * E], tok)
+                self._reduce(b, "ap").run()
         g = self.dx4[:b * HW]
         ops.attnpool_tokens(acc, None, g, b, HW, backward=True)
         for i in range(len(self.blocks) - 1, -1, -1):
@@ -564,8 +577,7 @@ class RN50Engine(FairLoRAEngine):
             main = torch.cuda.current_stream(self.device)
             self._ev_record(self.ev_layer[0], main)
             self._ev_wait(self.grad_stream, self.ev_layer[0])
-            with self._on(self.grad_stream):
-                self._reduce(b).run()
+            # (every block and the attention pool have summed their partials behind their own reductions by now)
             if self.sops.glob:
                 self._glue(self.sops.finish, self.grad_stream)
             self._ev_record(self.ev_grads, self.grad_stream)
@@ -575,17 +587,19 @@ class RN50Engine(FairLoRAEngine):
             if self.sops.glob:
                 self._glue(self.sops.finish)
 
-    def _reduce(self, b: int) -> "ops.ReducePlan":
-        if b not in self.rn_plans:
+    def _reduce(self, b: int, what: str = "all") -> "ops.ReducePlan":
+        """what: 'all' (every site, one launch: the arrangement without a gradient stream) or 'ap' (the attention pool's)."""
+        if (b, what) not in self.rn_plans:
             v = self.cfg.vision
             ent = []
-            for blk in self.blocks:
-                for site, H in blk.loras():
-                    ent += site.reduce_entries(b * H * H)
+            if what == "all":
+                for blk in self.blocks:
+                    for site, H in blk.loras():
+                        ent += site.reduce_entries(b * H * H)
             for n in "qkvc":
                 ent += self.ap[n].reduce_entries(b * v.tokens)
-            self.rn_plans[b] = ops.ReducePlan(ent, self.device)
-        return self.rn_plans[b]
+            self.rn_plans[(b, what)] = ops.ReducePlan(ent, self.device)
+        return self.rn_plans[(b, what)]
 
     # -------------------------------------------------------------------- API --
     def _step_body(self, b: int, S: int, has_attr: bool) -> None:
