@@ -530,6 +530,14 @@ class FairLoRAEngine:
         put("lnpost", (self._f(sd[ie + "ln_post.weight"]), self._f(sd[ie + "ln_post.bias"])))
         put("proj", self._w(sd[ie + "proj"]))                     # [width, out]: B operand of dh = df proj^T
         put("proj_t", self._wt(sd[ie + "proj"]))                  # [out, width]: B operand of f = h proj
+        # the three frozen weights outside the blocks in MFMA-fragment order too (16-bit modes): patch embedding and the
+        # two products of the final projection take the panel kernel where their shape fills the chip
+        self.pk_out = getattr(self, "pk_out", {})
+        if _is16(self.dtype) and os.environ.get("FFM_PACK_OUT", "1") != "0":
+            for name in ("conv_w", "proj", "proj_t"):
+                w = getattr(self, name)
+                if w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0:
+                    self.pk_out[name] = ops.pack_b(w, self.pk_out.get(name))
 
     # -------------------------------------------------------------- tower --
     def _lora_view(self, blk: _Block, role: str) -> Tensor:
@@ -909,14 +917,14 @@ class FairLoRAEngine:
         a32 = self.attr_i32[:b] if has_attr else None
         if self.sops.glob:
             self._glue(self.sops.prepare)             # S_eff = S + S_global
-        ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P])
+        ops.gemm_nt(self.cols[:images * P], self.conv_w, self.patch_out[:images * P], b_packed=self.pk_out.get("conv_w"))
         ops.embed_lnpre(self.patch_out[:images * P], self.cls, self.pos, self.lnpre[0], self.lnpre[1],
                         self.vis.x[0][:rows], images, L, rowstat=self.vis.rowp[0] if self.vis.rowp is not None else None)
         self._rank_operands_ready()                   # LoRA matrices -> GEMM rank operands (they change every step)
         out = self._stack_forward(self.vis, rows, images, a32, L * S)
         ops.layernorm_fwd(out, self.hpost[:rows], self.lnpost[0], self.lnpost[1], self.post_stats[0],
                           self.post_stats[1])
-        ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows])
+        ops.gemm_nt(self.hpost[:rows], self.proj_t, self.feat[:rows], b_packed=self.pk_out.get("proj_t"))
         if wait is not None:
             self._ev_wait(torch.cuda.current_stream(self.device), wait)     # text features ready
         self._head_forward(rows, images, L)
@@ -963,7 +971,7 @@ class FairLoRAEngine:
         images, L = b * S, v.tokens
         rows = images * L
         a32 = self.attr_i32[:b] if has_attr else None
-        ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows])
+        ops.gemm_nt(self.dfeat[:rows], self.proj, self.vis.dh[:rows], b_packed=self.pk_out.get("proj"))
         # (straight into the buffer the last block's LoRA-gradient reductions read: no copy on the main stream)
         gl = self.vis.rank > 0
         ops.layernorm_bwd(self.vis.dh[:rows], self.vis.x[v.layers][:rows], self.lnpost[0], self.post_stats[0],
