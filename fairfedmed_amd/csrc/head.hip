@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64 * HD_NW) void head_fwd_kernel(const T* __restric
     f32x4 acc[HD_MAXV];
 #pragma unroll
     for (int i = 0; i < HD_MAXV; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (four rows in flight per wave instead of one: measured, 21.4 against 20.7 us - this kernel does not wait for its loads)
     for (int l = 1 + wave; l < L; l += HD_NW) {
         const T* fr = f + ((size_t)b * L + l) * D;
         f32x4 v[HD_MAXV];
@@ -195,7 +196,18 @@ __global__ __launch_bounds__(256) void head_dtbar_kernel(const float* __restrict
     if (i >= n_cls * D) return;
     const int c = i / D, d = i % D;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * n_cls + c] * fbar[(size_t)b * D + d];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {                             // eight images' loads in flight (a 32-deep chain: 10 us); same order
+        float dl[8], fb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            dl[u] = dlogits[(size_t)(b + u) * n_cls + c];
+            fb[u] = fbar[(size_t)(b + u) * D + d];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += dl[u] * fb[u];
+    }
+    for (; b < B; ++b) s += dlogits[(size_t)b * n_cls + c] * fbar[(size_t)b * D + d];
     dtbar[i] = s * expf(logit_scale[0]);
 }
 
