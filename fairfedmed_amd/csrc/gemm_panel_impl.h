@@ -1047,32 +1047,40 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     asm volatile("" : "+a"(lgc[cf]), "+a"(lga[cf]));
                 }
             }
+            // every LDS read of the phase is issued before the ONE wait (the V tables' packed pairs first, then both images'
+            // transposed reads): a wave sits in an LDS round trip once per row group instead of twice
+            uint32_t pv[2][8];
 #pragma unroll
-            for (int ten = 0; ten < 2; ++ten) {
-                // (rows beyond M are zero in both tables; the phantom rows of an odd MF's last group are clamped AND masked)
-                uint32_t pv[8];
+            for (int ten = 0; ten < 2; ++ten)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
+                    // (rows beyond M are zero in both tables; the phantom rows of an odd MF's last group are clamped AND masked)
                     const int R = rg * 32 + 8 * fgrp + t;
                     const int Rc = R < BMp ? R : BMp - 1;
-                    pv[t] = ten ? V2F[Rc * 16 + frow] : reinterpret_cast<const uint32_t*>(V1F)[Rc * r + (frow < r ? frow : 0)];
-                    if constexpr (rg == NRG - 1 && (MF & 1)) pv[t] = R < BMp ? pv[t] : 0u;
-                    if (!ten) pv[t] = frow < r ? pv[t] : 0u;             // (V2F holds zeros in the slots beyond r)
+                    pv[ten][t] = ten ? V2F[Rc * 16 + frow] : reinterpret_cast<const uint32_t*>(V1F)[Rc * r + (frow < r ? frow : 0)];
                 }
+            panel_u32x2 xr[2][NF][2];
+            lg_tr_reads<NF, TROW, 0>(xr[0], t_rd);
+            lg_tr_reads<NF, TROW, 1>(xr[1], t_rd);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ten = 0; ten < 2; ++ten) {
                 u32x4 ph, pl;
 #pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if constexpr (rg == NRG - 1 && (MF & 1)) pv[ten][t] = (rg * 32 + 8 * fgrp + t) < BMp ? pv[ten][t] : 0u;
+                    if (!ten) pv[ten][t] = frow < r ? pv[ten][t] : 0u;     // (V2F holds zeros in the slots beyond r)
+                }
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ph[k] = __builtin_amdgcn_perm(pv[2 * k + 1], pv[2 * k], 0x05040100u);
-                    pl[k] = __builtin_amdgcn_perm(pv[2 * k + 1], pv[2 * k], 0x07060302u);
+                    ph[k] = __builtin_amdgcn_perm(pv[ten][2 * k + 1], pv[ten][2 * k], 0x05040100u);
+                    pl[k] = __builtin_amdgcn_perm(pv[ten][2 * k + 1], pv[ten][2 * k], 0x07060302u);
                 }
                 const frag_t vh = __builtin_bit_cast(frag_t, ph), vl = __builtin_bit_cast(frag_t, pl);
-                panel_u32x2 xr[NF][2];
-                if (ten == 0) lg_tr_reads<NF, TROW, 0>(xr, t_rd); else lg_tr_reads<NF, TROW, 1>(xr, t_rd);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int cf = 0; cf < NF; ++cf) {
-                    asm volatile("" : "+v"(xr[cf][0]), "+v"(xr[cf][1]));
-                    const u32x4 pk = {xr[cf][0][0], xr[cf][0][1], xr[cf][1][0], xr[cf][1][1]};
+                    asm volatile("" : "+v"(xr[ten][cf][0]), "+v"(xr[ten][cf][1]));
+                    const u32x4 pk = {xr[ten][cf][0][0], xr[ten][cf][0][1], xr[ten][cf][1][0], xr[ten][cf][1][1]};
                     const frag_t xb = __builtin_bit_cast(frag_t, pk);
                     f32x4& dst = ten ? lga[cf] : lgc[cf];
                     // (s_nop 1: an operand the VALU has just written - vh / vl, the zeroed accumulator - needs two wait
