@@ -109,6 +109,8 @@ class GemmTimer:
                 fl += 2.0 * M * N * kw["ts"].shape[1]
             if rk is not None:                       # in-GEMM down projection (16 padded rank rows) + rank-r update
                 fl += 2.0 * M * K * 16 + 2.0 * M * N * rk.S.shape[1]
+                if getattr(rk, "lgrad", None) is not None:      # FFM_EPI_LGRAD: dB(c_fc) and dA(c_proj), 2 M N r each
+                    fl += 2 * 2.0 * M * N * rk.S.shape[1]
             self.rec.append((e0, e1, fl, M))
             return r
 
