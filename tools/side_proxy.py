@@ -16,6 +16,7 @@ from fairfedmed_amd.engine import FairLoRAEngine
 
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "proto", "libspin.so"))
 lib.spin_launch.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+lib.spin_fat_launch.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2 + [ctypes.c_int]
 mcfg = C.vit_b16(rank=8)
 sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
 b = synth.make_batch(mcfg, 32, seed=1234)
@@ -33,12 +34,16 @@ def run(eng, n=30):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-def spins(count, blocks, threads, lds, us):
+def spins(count, blocks, threads, lds, us, fat=0):
+    """fat: VGPRs per wave the stand-in allocates (0 / False: a handful; True: 128)"""
+    fat = 128 if fat is True else int(fat)
+    fn = (lambda *a: lib.spin_fat_launch(*a, fat)) if fat else lib.spin_launch
+
     def go(*a, **k):
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(count):
             def one(st=st):
-                rc = lib.spin_launch(blocks, threads, lds, us, sink.data_ptr(), st)
+                rc = fn(blocks, threads, lds, us, sink.data_ptr(), st)
                 assert rc == 0, rc
             one()
             ops.record_callable(one)
@@ -59,10 +64,20 @@ def variant(name, fwd, bwd):
 
 none = lambda *a, **k: None
 NF, NB = 87, 110
-for rep in range(2):
+for rep in range(1):
     variant("no text tower", none, none)
     for G, T, us in ((8, 512, 8), (8, 1024, 8), (16, 512, 8), (32, 512, 8), (128, 512, 8), (128, 512, 4)):
         variant("%d+%d spins of %d x %d, %d us" % (NF, NB, G, T, us), spins(NF, G, T, 0, us), spins(NB, G, T, 0, us))
+    # ... with a text GEMM's footprint: 128 VGPRs per wave and 48 KiB of LDS per block (such a block shares a CU with nothing large)
+    for G, T, us in ((16, 512, 8), (64, 512, 8), (128, 512, 8)):
+        variant("fat spins of %d x %d, %d us" % (G, T, us), spins(NF, G, T, 49152, us, True), spins(NB, G, T, 49152, us, True))
+    for vg in (32, 64, 96, 128, 168, 240):
+        for T in (512, 256):
+            variant("%d VGPRs, no LDS, 64 x %d, 8 us" % (vg, T), spins(NF, 64, T, 0, 8, vg), spins(NB, 64, T, 0, 8, vg))
+    variant("128 VGPRs, no LDS, 64 x 512, 8 us", spins(NF, 64, 512, 0, 8, True), spins(NB, 64, 512, 0, 8, True))
+    variant("few VGPRs, 48 KiB LDS, 64 x 512, 8 us", spins(NF, 64, 512, 49152, 8, False), spins(NB, 64, 512, 49152, 8, False))
+    variant("few VGPRs, 16 KiB LDS, 64 x 512, 8 us", spins(NF, 64, 512, 16384, 8, False), spins(NB, 64, 512, 16384, 8, False))
+    variant("128 VGPRs, no LDS, 64 x 256, 8 us", spins(NF, 64, 256, 0, 8, True), spins(NB, 64, 256, 0, 8, True))
     variant("one 8 x 512 spin, 700 + 1000 us", spins(1, 8, 512, 0, 700), spins(1, 8, 512, 0, 1000))
     variant("one 8 x 1024 spin, 700 + 1000 us", spins(1, 8, 1024, 65536, 700), spins(1, 8, 1024, 65536, 1000))
     variant("one 16 x 512 spin, 500 + 800 us", spins(1, 16, 512, 0, 500), spins(1, 16, 512, 0, 800))
