@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "mask_tolerant: panel-GEMM tests that also run under every FFM_PANEL_MASK tile selection")
 
 
 def _has_gpu():

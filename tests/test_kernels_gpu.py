@@ -119,6 +119,7 @@ def test_gemm_rankop_fused_lora(ops, dt, r, G, kr, use_attr):
 
 
 # ------------------------------------------------- panel GEMM (packed B) ---
+@pytest.mark.mask_tolerant
 @pytest.mark.parametrize("M,N,K,mode", [(6304, 2048, 1536, "b"), (6304, 768, 768, "br"), (6304, 768, 2304, ""),
                                          (6000, 768, 3072, "br"), (4100, 1024, 512, "b")])
 @H16
@@ -146,6 +147,7 @@ def test_gemm_panel_plain(ops, M, N, K, mode, h16):
     check(out, out2.double(), 1e-2, "panel vs 128x128")
 
 
+@pytest.mark.mask_tolerant
 @pytest.mark.parametrize("case", ["fc_fwd", "proj_fwd", "proj_dx", "fc_dx", "proj_dx_deriv"])
 @pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (5500, 16, 2, False), (6304, 4, 3, True)])
 @H16
@@ -209,6 +211,7 @@ def test_gemm_panel_fairlora(ops, case, M, r, G, use_attr, h16):
         check(dsp.double().sum(0), pi_rows.t() @ (0.25 * t_fwd.double() * ref_t), 5e-5, "dS")
 
 
+@pytest.mark.mask_tolerant
 @pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (6250, 16, 2, False), (6304, 4, 3, True), (3000, 8, 3, True)])
 @H16
 def test_gemm_panel_lgrad_partials(ops, M, r, G, use_attr, h16):
@@ -262,6 +265,7 @@ def test_gemm_panel_lgrad_partials(ops, M, r, G, use_attr, h16):
     check(pc.double().sum(0), part.view(ns, N, r).double().sum(0), 2e-5, "against ffm_lora_grad_partial")
 
 
+@pytest.mark.mask_tolerant
 @H16
 def test_gemm_panel_lgrad_race_screen_bitwise_repeatable(ops, h16):
     """The FFM_EPI_LGRAD epilogue lays two 16-bit images over the part of the wave's output stage it has already read and
@@ -273,7 +277,8 @@ def test_gemm_panel_lgrad_race_screen_bitwise_repeatable(ops, h16):
     M, r, G, width, rps = 6304, 8, 3, 768, 197
     N, K = 4 * width, width
     nlg = ops.gemm_lgrad_rows(M, N, K, r, dt, True)
-    assert nlg > 0
+    if nlg <= 0:
+        pytest.skip("no LGRAD tile under this FFM_PANEL_MASK (the engine falls back to the two reduction launches)")
     nrows = ops.gemm_tiles_m(M, N, K, 2 | 4 | 32 | 64, r, dt, True)
     a, b = rnd(M, K, dt=dt, seed=170), rnd(N, K, dt=dt, scale=K ** -0.5, seed=171)
     P, S, lw = rnd(K, r, scale=0.1, seed=173), rnd(G, r, seed=174), rnd(N, r, seed=175)
@@ -757,6 +762,7 @@ def test_x3_gemm_rejects_large_products():
 
 
 # ------------------------------------------------ LayerNorm folded into the GEMMs around it ---
+@pytest.mark.mask_tolerant
 @H16
 def test_gemm_rowstats_partials(h16):
     """FFM_EPI_ROWSTATS (out-proj forward shape): the partial {sum, sum of squares} of every STORED output row, one
@@ -786,6 +792,7 @@ def test_gemm_rowstats_partials(h16):
         ops.gemm_nt(a, w, out, bias=bias, res=res, rowstats=part)
 
 
+@pytest.mark.mask_tolerant
 @pytest.mark.parametrize("np_", [1, 6])
 @H16
 def test_gemm_layernorm_folded_in(np_, h16):
@@ -932,10 +939,10 @@ def test_panel_tile_configurations_behind_the_mask(mask, what):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FFM_PANEL_MASK=str(mask))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_kernels_gpu.py"), "-k",
-                        "gemm_panel or gemm_rowstats or layernorm_folded"], env=env, cwd=root, capture_output=True, text=True,
-                       timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # no -x in the child: the tail then names every failure, not just the first
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-rfE", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m",
+                        "mask_tolerant"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "deselected" in r.stdout
 
 
