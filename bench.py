@@ -3,8 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one GLP_OT_SVLoRA.forward_backward on a synthetic batch already
-resident in HBM: CLIP ViT-B/16 image encoder with FairLoRA r=8 (G=3) + text
+The timed region is ONE GLP_OT_SVLoRA.train(idx) call over a local epoch of K
+synthetic batches already resident in HBM (the metric is
+defined over the wall time of the client's train()); one "step" = one
+forward_backward of that epoch: CLIP ViT-B/16 image encoder with FairLoRA r=8 (G=3) + text
 tower + logits head + cross-entropy, full backward (dX + LoRA/ctx gradients)
 and the fused SGD-momentum update, bf16 activations/frozen weights with fp32
 accumulation and fp32 trainable tensors, batch 32 of 224x224x3
@@ -231,8 +233,16 @@ def build_bench_trainer(mcfg, sd, args, dev, rank):
     from fairfedmed_amd.registry import build_trainer
     from fairfedmed_amd.trainer import SyntheticFedData
     import fairfedmed_amd.trainer  # noqa: F401  (registers GLP_OT_SVLoRA)
-    data = SyntheticFedData(mcfg, 1, train_batches=TRAIN_STEPS if not args.no_trainer else 1, test_batches=1,
-                            batch_size=BATCH, seed=1234 + 7919 * rank, device=dev)
+    data = SyntheticFedData(mcfg, 1, train_batches=max(TRAIN_STEPS if not args.no_trainer else 1, args.steps, args.warmup, 1),
+                            test_batches=1, batch_size=BATCH, seed=1234 + 7919 * rank, device=dev)
+    # Two more "clients" over the same resident batches: an epoch of exactly W batches (warm-up) and one of exactly K (the
+    # timed GLP_OT_SVLoRA.train() call of the headline); client 0 keeps the 32-batch round of SURVEY.md section 8(d).
+    from fairfedmed_amd.trainer import _ListDataset, _Loader
+    ds0 = data.fed_train_loader_x_dict[0].dataset
+    for name, n in (("bench_warmup", args.warmup), ("bench_timed", args.steps)):
+        data.fed_train_loader_x_dict[name] = _Loader(_ListDataset(ds0.batches[:n], ds0.attributes, ds0.num_groups))
+    if not args.no_trainer:
+        data.fed_train_loader_x_dict[0] = _Loader(_ListDataset(ds0.batches[:TRAIN_STEPS], ds0.attributes, ds0.num_groups))
     cfg = NS(SEED=1, OUTPUT_DIR="", DEVICE=dev, VERBOSE=False,
              INPUT=NS(SIZE=(224, 224), PIXEL_MEAN=list(C.CLIP_PIXEL_MEAN), PIXEL_STD=list(C.CLIP_PIXEL_STD)),
              DATASET=NS(NAME="FairFedMed", ATTRIBUTES=["race"], ATTRIBUTE_TYPE="race", MODALITY_TYPE="slo_fundus",
@@ -427,23 +437,27 @@ def main():
         raise SystemExit("--launch graph: the captured step exists for --config c2 only")
     graphed = eng.capture_train_step(BATCH, opt.lr, opt.momentum, opt.weight_decay) if args.launch == "graph" else None
 
-    # SURVEY.md section 8(d) defines the metric on the wall time of the client's train(): for configs[1] a timed step is
-    # therefore what GLP_OT_SVLoRA.run_epoch does per batch - parse_batch_train, forward_backward (engine step + the
-    # reference's double optimizer step), the per-step summary left on the device - on a batch resident in HBM; the bare
-    # engine loop of earlier rounds is reported beside it as `engine_only`.
+    # SURVEY.md section 8(d) defines the metric on the wall time of the client's train(): for configs[1] the timed region
+    # IS one GLP_OT_SVLoRA.train(idx) call - TrainerX.run_epoch (Dassl/dassl/engine/trainer.py:685-741) over a local epoch
+    # of exactly K batches resident in HBM: parse_batch_train, forward_backward (engine step + the reference's double
+    # optimizer step), the per-step summary, the StepLR move and the finite check at the end of the epoch.  The W warm-up
+    # steps are a train() call over W batches.  The bare engine loop of earlier rounds is reported beside it as
+    # `engine_only`.
     trainer_step = tr is not None and graphed is None and not args.engine_step
-    if trainer_step:
-        tr.set_model_mode("train")
-        tr.batch_idx, tr.num_batches = 0, 1 << 30             # never an epoch's last batch: no StepLR move while timing
-        tbatch = {"img": img, "label": label, "attrs": wl.attrs}
 
     def step():
-        if trainer_step:
-            tr.forward_backward(tbatch)
-        elif graphed is None:
+        if graphed is None:
             eager_step()
         else:
             graphed.run(img, attr, label)          # copies the (resident) batch into the graph's inputs, replays
+
+    def run_steps(n, which):
+        if trainer_step:
+            if n > 0:
+                tr.train(idx=which, global_epoch=0, is_fed=True)
+        else:
+            for _ in range(n):
+                step()
 
     def round_boundary():
         nonlocal buf_bytes
@@ -458,16 +472,14 @@ def main():
             eng.load_buffers_flat(buf)
             buf_bytes = buf.numel() * 4
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup, "bench_warmup")
     round_boundary()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps, "bench_timed")
     round_boundary()
     t_enqueue = time.perf_counter() - t0            # host time to enqueue the K steps (no sync inside)
     torch.cuda.synchronize()
@@ -592,10 +604,12 @@ def main():
             "config": {"workload": wl.desc + ("" if world == 1 else "; one client per GPU, FedAvg all-reduce at the round end"),
                        "global_batch": wl.units * world, "clients": world,
                        "trainable_elems": eng.params.numel, "final_loss": loss, "loss_finite": finite,
-                       "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
+                       # (train() ends with the epoch's one host sync, so in the trainer mode this is the epoch's wall time, not the enqueue time)
+                       "host_enqueue_ms_per_step": None if trainer_step else t_enqueue / args.steps * 1e3,
                        "launch": args.launch,
-                       "timed_step": ("GLP_OT_SVLoRA.forward_backward(batch) - the per-batch body of run_epoch / train() "
-                                      "(SURVEY.md section 8(d))" if trainer_step else "engine.forward_backward + sgd_step"),
+                       "timed_step": ("one GLP_OT_SVLoRA.train(idx) call: run_epoch over a local epoch of K resident batches "
+                                      "(SURVEY.md section 8(d)); ms_per_step = its wall time / K"
+                                      if trainer_step else "engine.forward_backward + sgd_step"),
                        "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None},
         }

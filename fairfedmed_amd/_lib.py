@@ -19,7 +19,7 @@ F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the refer
 F32_X3_W16 = 4                           # FFM_F32_X3 with the weight operand stored as IEEE half
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
 EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD = 128, 256, 512
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
                       _i32, _vp],
     "ffm_lora_down_blocks": [_i32, _i32, _i32, _i32],
+    "ffm_lora_down_blocks_max": [_i32, _i32, _i32, _i32],
     "ffm_lora_grad_partial": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_lora_grad_partial_ln": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "ffm_lora_grad_splits": [_i32],

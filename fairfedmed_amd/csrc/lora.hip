@@ -700,17 +700,22 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ffm_reduce_desc
 
 }  // namespace
 
-extern "C" int ffm_lora_down_blocks(int M, int K, int r, int dtype) {
-    // dS partial rows a BACKWARD call (P given as [r][K] rows, t_fwd / ds_part set: the only calls that write them) produces
-    // An UPPER bound over both kernels: callers size ds_part once from their largest batch, and a smaller last batch
-    // (rows < 1024) falls back to the VALU kernel, which can write more partial rows per M than the matrix-core one.
+static int down_valu_blocks(int M, int K, int r, int dtype) {
     const int rows = (LD_WAVES / down_kq(K, dtype == FFM_BF16 ? 2 : 4)) * (64 / down_rp(r, dtype));
-    const int valu = (M + rows - 1) / rows;
-    if (down_mfma_ok(M, K, r, dtype, 1)) {
-        const int mf = (M + LDM_ROWS - 1) / LDM_ROWS;
-        return mf > valu ? mf : valu;
-    }
-    return valu;
+    return (M + rows - 1) / rows;
+}
+extern "C" int ffm_lora_down_blocks(int M, int K, int r, int dtype) {
+    // EXACT: the dS partial rows the BACKWARD call of ffm_lora_down (P given as [r][K] rows, t_fwd / ds_part set: the only
+    // calls that write them) writes for this very (M, K, r, dtype) - the count a reduction over ds_part must use.
+    if (down_mfma_ok(M, K, r, dtype, 1)) return (M + LDM_ROWS - 1) / LDM_ROWS;
+    return down_valu_blocks(M, K, r, dtype);
+}
+extern "C" int ffm_lora_down_blocks_max(int M_max, int K, int r, int dtype) {
+    // UPPER bound over every M <= M_max and both kernels, for SIZING ds_part once from the largest batch: a smaller last
+    // batch (rows < 1024) falls back to the VALU kernel, which can write more partial rows per M than the matrix-core one.
+    const int valu = down_valu_blocks(M_max, K, r, dtype);
+    const int mf = down_mfma_ok(M_max, K, r, dtype, 1) ? (M_max + LDM_ROWS - 1) / LDM_ROWS : 0;
+    return mf > valu ? mf : valu;
 }
 extern "C" int ffm_lora_grad_splits(int M) { return (M + LG_ROWS - 1) / LG_ROWS; }
 

@@ -15,7 +15,8 @@ repeat (1 channel for SLO fundus / chest X-ray), 12x fewer bytes over PCIe; the 
 
 scikit-image is not in this image: ``resize_image`` restates ``skimage.transform.resize`` (order 1, mode 'reflect',
 no anti-aliasing when enlarging, clip to the input range) on scipy.ndimage.zoom - parity for the resize branch is
-unpinned; the branches without a resize are pinned against the imported reference (tests/golden/make_golden.py).
+unpinned; the branches without a resize - both readers, FairFedMedDataset and FedChexMimicDataset, with their
+count_by_attribute - are pinned against the imported reference (tests/golden/make_golden.py -> dataset.json).
 """
 from __future__ import annotations
 
@@ -279,4 +280,38 @@ def write_synthetic_fairfedmed(root: str, sites: int = 2, n_train: int = 12, n_t
                 w = csv.writer(f)
                 w.writerow(["filename"])
                 w.writerows([[x] for x in names])
+    return base
+
+
+def write_synthetic_fedchexmimic(root: str, n_train: int = 12, n_test: int = 6, size: int = 224, seed: int = 0,
+                                 attribute_type: str = "gender") -> str:
+    """A FedChexMimic tree (utils/data_utils.py:729-753): site 1 "chexpert" with its images under the base path, site 2
+    "mimic" under <base>/files_336p; csv columns filename, disease_label, gender_label, race_label.  The images alternate
+    between 8-bit gray PNG, RGB JPEG and RGB PNG, so that the reader's ``convert('L')`` sees all three.  Returns
+    <root>/fedchexmimic."""
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[0xC4E5, seed & 0xFFFFFFFF]))
+    base = os.path.join(root, DATASET_DIRS["FedChexMimic"])
+    k = 0
+    for name, sub in (("chexpert", "."), ("mimic", "files_336p")):
+        for split, n in (("train", n_train), ("test", n_test)):
+            rows = []
+            for _ in range(n):
+                kind = k % 3
+                rel = os.path.join("imgs" if name == "chexpert" else "p10", f"view_{k:05d}." + ("jpg" if kind == 1 else "png"))
+                path = os.path.join(base, sub, rel)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                if kind == 0:
+                    Image.fromarray(g.integers(0, 256, size=(size, size), dtype=np.uint8), "L").save(path)
+                else:
+                    # smooth RGB content (a JPEG of white noise is all quantisation error)
+                    low = g.integers(0, 256, size=(size // 4 + 1, size // 4 + 1, 3), dtype=np.uint8)
+                    arr = np.kron(low, np.ones((4, 4, 1), np.uint8))[:size, :size]
+                    Image.fromarray(arr, "RGB").save(path, **({"quality": 90} if kind == 1 else {}))
+                rows.append([rel, int(g.integers(0, 2)), int(g.integers(0, 2)), int(g.integers(0, 3))])
+                k += 1
+            with open(os.path.join(base, f"meta_{name}_{attribute_type}_{split}.csv"), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["filename", "disease_label", "gender_label", "race_label"])
+                w.writerows(rows)
     return base

@@ -258,7 +258,7 @@ class _Stack:
             # per-layer partial sums of the LoRA gradients; all of them are reduced by ONE launch
             # (ffm_reduce_partials_multi) at the end of the backward pass
             ns = ops.lora_grad_splits(T)
-            nb = max(ops.lora_down_blocks(T, w, rank, dtype), ops.lora_down_blocks(T, 4 * w, rank, dtype),
+            nb = max(ops.lora_down_blocks_max(T, w, rank, dtype), ops.lora_down_blocks_max(T, 4 * w, rank, dtype),
                      _ds_rows(T, 4 * w, w, rank, dtype, dgelu=True), _ds_rows(T, w, 4 * w, rank, dtype))
             self.part = [{"fc_A": f(ns * w * rank), "fc_B": f(ns * 4 * w * rank),
                           "proj_A": f(ns * 4 * w * rank), "proj_B": f(ns * w * rank),

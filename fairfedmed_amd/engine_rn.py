@@ -44,7 +44,7 @@ class _Lora:
         # rank <= 16: the down projections ride inside the GEMMs (FFM_EPI_RANKOP); their operands are the LoRA
         # matrices re-packed to [16, K] in the compute dtype once per step (one launch for all sites)
         self.fused = 0 < r <= 16
-        nb = ops.lora_down_blocks(max_rows, N, r, dt)
+        nb = ops.lora_down_blocks_max(max_rows, N, r, dt)
         if self.fused:
             nb = max(nb, self._tiles(max_rows))
             self.rkA = torch.zeros(16, K, device=eng.device, dtype=dt)

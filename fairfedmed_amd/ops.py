@@ -518,7 +518,13 @@ def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, delta: Te
 
 
 def lora_down_blocks(M: int, K: int, r: int, dtype: torch.dtype) -> int:
+    """dS partial rows ffm_lora_down writes for exactly this (M, K, r, dtype): the count to reduce over."""
     return L.load().ffm_lora_down_blocks(M, K, r, L.dtype_code(dtype))
+
+
+def lora_down_blocks_max(M_max: int, K: int, r: int, dtype: torch.dtype) -> int:
+    """Upper bound of lora_down_blocks over every M <= M_max: for sizing ds_part buffers only."""
+    return L.load().ffm_lora_down_blocks_max(M_max, K, r, L.dtype_code(dtype))
 
 
 class ReducePlan:

@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 9   /* 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 10  /* 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers; 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -338,13 +338,16 @@ int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const 
  * attr: int32 [nsamples] group index, or NULL for the uniform 1/G mix (:462).
  * If t_fwd != NULL also accumulates the dS partials
  *   ds_part[blk][g][j] = sum_{m in blk} pi_{b(m)}[g] * scaling * t_fwd[m][j] * t[m][j]
- * (ds_part has ffm_lora_down_blocks(M, K, r, dtype) * G * r floats).
+ * The call writes exactly ffm_lora_down_blocks(M, K, r, dtype) partial rows of G * r floats (the count a reduction over
+ * ds_part must use); ffm_lora_down_blocks_max(M_max, ...) bounds that count over every M <= M_max and is for sizing a
+ * buffer once from the largest batch - never for summing.
  */
 int ffm_lora_down(const void* x, int ldx, const float* P, int layout_rk, const float* S,
                   const int32_t* attr, int M, int K, int r, int G, int rows_per_sample,
                   float scaling, float lambda_group, float* t, float* ts,
                   const float* t_fwd, float* ds_part, int dtype, void* stream);
-int ffm_lora_down_blocks(int M, int K, int r, int dtype);   /* blocks (= dS partial rows) the call above uses */
+int ffm_lora_down_blocks(int M, int K, int r, int dtype);       /* exact: dS partial rows the call above writes */
+int ffm_lora_down_blocks_max(int M_max, int K, int r, int dtype); /* upper bound over M <= M_max (buffer sizing) */
 
 /*
  * Rank-r gradient reduction over the token rows (the dA / dB sums of

@@ -515,6 +515,26 @@ def golden_dataset():
                         "count_race": RefWrap.count_by_attribute_fairfedmed(NS(data_source=ds), "race"),
                         "count_gender": RefWrap.count_by_attribute_fairfedmed(NS(data_source=ds), "gender"),
                     }
+        # FedChexMimicDataset (utils/data_utils.py:729-790) + count_by_attribute_fedchexmimic (data_manager.py:462-473):
+        # gray PNG / RGB JPEG / RGB PNG -> convert('L') -> float32 -> 3 channels, at the files' own size (no resize)
+        base = D.write_synthetic_fedchexmimic(os.path.join(tmp, "chex"), n_train=7, n_test=4, size=20, seed=5)
+        from utils.data_utils import FedChexMimicDataset as RefChex
+        for site in (1, 2):
+            for train in (True, False):
+                ds = RefChex(base, site, "gender", ["gender", "race"], resolution=20, depth=3, train=train)
+                items = [ds[i] for i in range(len(ds))]
+                res[f"chex.site{site}.{'train' if train else 'test'}"] = {
+                    "len": len(ds), "files": [str(x) for x in ds.data_files], "data_attrs": [int(a) for a in ds.data_attrs],
+                    "shape": list(items[0][0].shape), "dtype": str(items[0][0].dtype),
+                    "sums": [float(np.asarray(it[0], np.float64).sum()) for it in items],
+                    "wsums": [float((np.asarray(it[0], np.float64).reshape(-1)
+                                     * np.arange(1, it[0].size + 1)).sum()) for it in items],
+                    "labels": [int(it[1]) for it in items], "label_dtype": str(items[0][1].dtype),
+                    "attrs": [[int(v) for v in it[2]] for it in items],
+                    "first_corner": np.asarray(items[1][0])[:, :3, :4].tolist(),
+                    "count_gender": RefWrap.count_by_attribute_fedchexmimic(NS(data_source=ds), "gender"),
+                    "count_race": RefWrap.count_by_attribute_fedchexmimic(NS(data_source=ds), "race"),
+                }
     with open(os.path.join(HERE, "dataset.json"), "w") as f:
         json.dump(res, f, indent=1)
     print("dataset.json:", len(res), "cases")

@@ -83,11 +83,10 @@ CASES = {
     # (signal 0.1: the AUC sits at 0.78 after two rounds - at 0.45 the 224 x 224 task saturates at 0.9999, tools/vitb_auc_calib.py)
     "vit_b16":  (lambda: C.vit_b16(rank=8),                "race",   2,     4,      8,  8,     64,     2e-2, 0.10, 1.0),
 }
-# bf16 tolerance per tower.  ViT: north_star's 0.002.  RN: every stored activation of a ReLU / BatchNorm trunk is a
-# 2^-9 perturbation that flips ReLU masks, and the test measures how far THE ORACLE ITSELF moves when its stored
-# activations are rounded to bf16 (oracle.STORE, fp32 arithmetic otherwise): the engine may be as far from the fp32
-# reference as 0.002 + that control's own distance (measured on MI355X: engine 0.0025, fp32 engine with bf16-rounded
-# input pixels alone 0.0002).
+# bf16 tolerance: north_star's plain 0.002 on every tower (round 5; the RN tower measured 0.0012 / 0.0005 / 0.0009 on the
+# round-4 build).  For the RN tower the test still runs and PRINTS a control - the oracle itself with its stored
+# activations rounded to bf16 (oracle.STORE, fp32 arithmetic otherwise), every one of them a 2^-9 perturbation that flips
+# ReLU masks - so that a reader can see what the storage format alone costs; the control no longer widens the bound.
 _ORACLE_RUNS = {}
 
 
@@ -139,7 +138,6 @@ def test_auc_after_equal_rounds(tower, prec, tol):
     hip_auc, ref_auc = [a / 100.0 for a in hip["auc"]], [a / 100.0 for a in ref["auc"]]
     print(tower, prec, "AUC per round  HIP", [round(a, 5) for a in hip_auc], " oracle", [round(a, 5) for a in ref_auc])
     assert max(ref_auc) - min(ref_auc) > 0.002 or abs(ref_auc[-1] - 0.5) > 0.02, "the run must move the AUC"
-    extra = [0.0] * rounds
     if tower.startswith("rn") and prec == "bf16":
         from oracle import fairlora_oracle as O
         O.STORE = O.store_bf16
@@ -148,9 +146,9 @@ def test_auc_after_equal_rounds(tower, prec, tol):
         finally:
             O.STORE = None
         ctl_auc = [a / 100.0 for a in ctl["auc"]]
-        # capped: a control run that wandered far from the fp32 oracle must not make the bound below vacuous
-        extra = [min(abs(c - r), 0.003) for c, r in zip(ctl_auc, ref_auc)]
-        print(tower, "oracle with bf16-stored activations", [round(a, 5) for a in ctl_auc], " its own distance", [round(e, 5) for e in extra])
+        # printed for context only: the bound below is north_star's plain 0.002
+        print(tower, "oracle with bf16-stored activations", [round(a, 5) for a in ctl_auc], " its own distance from the fp32 oracle",
+              [round(abs(c - r), 5) for c, r in zip(ctl_auc, ref_auc)], " engine's distance", [round(abs(h - r), 5) for h, r in zip(hip_auc, ref_auc)])
     if tower.startswith("rn") and prec == "fp16":
         # The fp16 mode's model IS the reference's model with its frozen weights rounded to half (convert_weights,
         # clip/model.py:609-630).  On this fixture that rounding ALONE moves the fp32 oracle's AUC by 0.0007 / 0.0022 /
@@ -169,7 +167,7 @@ def test_auc_after_equal_rounds(tower, prec, tol):
             assert abs(hip_auc[r] - ref_auc[r]) <= abs(half_auc[r] - ref_auc[r]) + 0.0005, (r, hip_auc, half_auc, ref_auc)
         ref_auc = half_auc
     for r in range(rounds):
-        assert abs(hip_auc[r] - ref_auc[r]) <= tol + extra[r], (r, hip_auc, ref_auc, extra)
+        assert abs(hip_auc[r] - ref_auc[r]) <= tol, (r, hip_auc, ref_auc)
         # accuracy (percent, mean over the clients): fp32 may differ by one test sample of one client, 16-bit modes by 5 points
         one_sample = 100.0 / (test_b * test_bs)
         assert abs(hip["acc"][r] - ref["acc"][r]) <= (1e-9 if prec == "fp32" and tower == "vit_tiny" else one_sample if prec == "fp32" else 5.0)

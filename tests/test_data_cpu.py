@@ -222,3 +222,30 @@ def test_precision_flags_map_to_storage_types():
     assert _lib.is16(torch.float16) and _lib.is16(torch.bfloat16) and not _lib.is16(torch.float32)
     with pytest.raises(ValueError):
         resolve_precision("int8")
+
+
+def test_fedchexmimic_reader_vs_reference(tmp_path, gold):
+    """FedChexMimicDataset / count_by_attribute against what the imported reference returns on the same generated tree
+    (utils/data_utils.py:729-790, Dassl/dassl/data/data_manager.py:462-473): both sites' path rules, gray PNG / RGB JPEG /
+    RGB PNG -> convert('L') -> float32 -> 3 channels, label / attribute columns, group counts."""
+    base = D.write_synthetic_fedchexmimic(str(tmp_path / "chex"), n_train=7, n_test=4, size=20, seed=5)
+    for site in (1, 2):
+        for train in (True, False):
+            ref = gold[f"chex.site{site}.{'train' if train else 'test'}"]
+            ds = D.FedChexMimicDataset(base, site, "gender", ["gender", "race"], resolution=20, depth=3, train=train)
+            assert len(ds) == ref["len"] and list(ds.data_files) == ref["files"]
+            assert [int(a) for a in ds.data_attrs] == ref["data_attrs"]
+            for i in range(len(ds)):
+                x, y, a = ds[i]
+                assert list(x.shape) == ref["shape"] and str(x.dtype) == ref["dtype"] == "float32"
+                assert float(np.asarray(x, np.float64).sum()) == ref["sums"][i]
+                w = (np.asarray(x, np.float64).reshape(-1) * np.arange(1, x.size + 1)).sum()
+                assert float(w) == ref["wsums"][i]
+                assert int(y) == ref["labels"][i] and str(y.dtype) == ref["label_dtype"] == "torch.int64"
+                assert [int(v) for v in a] == ref["attrs"][i]
+            assert np.asarray(ds[1][0])[:, :3, :4].tolist() == ref["first_corner"]
+            assert ds.count_by_attribute("gender") == ref["count_gender"]
+            assert ds.count_by_attribute("race") == ref["count_race"]
+            img, rep, _, _ = ds.raw(1)                               # transport form: one uint8 channel, repeated 3x on the GPU
+            assert img.dtype == np.uint8 and img.shape[0] == 1 and rep == 3
+            assert np.array_equal(np.repeat(img.astype(np.float32), rep, axis=0), ds[1][0])

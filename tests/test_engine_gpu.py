@@ -173,7 +173,7 @@ def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
     for k in synth.trainable_keys(mcfg):
         g = eng.params.view(k, "grad").cpu()
         n, ref_n = float(g.norm()), meta[f"{tag}.grad_norms"][k]
-        assert abs(n - ref_n) <= (2e-3 if f32 else 2e-2 if f16 else 8e-2) * ref_n + 1e-12, (k, n, ref_n)
+        assert abs(n - ref_n) <= (2e-3 if f32 else 2e-2 if f16 else 4e-2) * ref_n + 1e-12, (k, n, ref_n)
         key = f"{tag}.grad.{k}" if f"{tag}.grad.{k}" in gold else f"{tag}.gradsub.{k}"
         ref = gold[key]
         got = g.numpy() if key.startswith(f"{tag}.grad.") else sub(g, 1024)
@@ -183,7 +183,7 @@ def test_vitb16_step_vs_reference_golden(golden_dir, dtype, tag, bs):
         if f32:
             assert e < 5e-3, (k, e)
         else:
-            assert cos(got, ref) > (0.995 if f16 else 0.97), (k, cos(got, ref), e)
+            assert cos(got, ref) > (0.995 if f16 else 0.985), (k, cos(got, ref), e)
     print(tag, dtype, "worst grad err", worst, "worst cosine", wcos)
     # the reference's forward_backward trajectory (two optimizer steps per batch: quirk 9)
     for i, ref in enumerate(meta[f"{tag}.traj"]):
@@ -227,8 +227,8 @@ def test_vitb16_bs32_panel_path_vs_fp32_engine():
                 g, gr = eng.params.view(k, "grad"), ref.params.view(k, "grad")
                 c = cos(g, gr)
                 worst = min(worst, c)
-                assert c > 0.97, (k, c)
-                assert abs(float(g.norm()) - float(gr.norm())) <= 8e-2 * float(gr.norm()) + 1e-12, k
+                assert c > 0.985, (k, c)
+                assert abs(float(g.norm()) - float(gr.norm())) <= 4e-2 * float(gr.norm()) + 1e-12, k
             print("bs32 panel path: worst gradient cosine vs the f32 engine", worst)
         ref.sgd_step(1e-3, 0.9, 5e-4)
         eng.sgd_step(1e-3, 0.9, 5e-4)
@@ -283,7 +283,7 @@ def test_vitb16_other_batch_sizes_bf16_vs_fp32_engine(bs):
     for k in synth.trainable_keys(mcfg):
         g, gr = eng.params.view(k, "grad"), ref.params.view(k, "grad")
         if float(gr.abs().max()) > 0:
-            assert cos(g, gr) > 0.97, (k, cos(g, gr))
+            assert cos(g, gr) > 0.985, (k, cos(g, gr))
     # the recorded plan replays bit-identically
     again = eng.forward_backward(img, attr, label)
     assert torch.equal(again["logits"], o["logits"])
@@ -316,3 +316,25 @@ def test_training_is_bit_reproducible_across_engines_and_streams(kind):
         runs.append((torch.cat(losses), eng.params.grad.clone(), eng.params.flat.clone()))
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_vitb16_rank16_ds_partials_across_batch_sizes(dtype):
+    """Rank 9..16, 16-bit storage, K >= 2048, rows >= 1024: block 0's c_fc takes the stand-alone matrix-core down
+    projection, which writes ceil(rows / 16) dS partial rows - fewer than the VALU kernel's count that sizes the buffer.
+    The reduction must sum exactly the rows this step wrote: a larger batch in front of a smaller one leaves stale rows
+    behind them, so the second step's dS has to equal a fresh engine's bit for bit."""
+    mcfg = C.vit_b16(rank=16)
+    sd = synth.make_state_dict(mcfg, seed=3, lora_init="random")
+    big, small = synth.make_batch(mcfg, 8, seed=31, signal=0.2), synth.make_batch(mcfg, 6, seed=32, signal=0.2)
+    eng = make_engine(mcfg, sd, dtype, 8)
+    eng.forward_backward(*to_dev(big))
+    o = eng.forward_backward(*to_dev(small))
+    fresh = make_engine(mcfg, sd, dtype, 6)
+    o_ref = fresh.forward_backward(*to_dev(small))
+    torch.cuda.synchronize()
+    assert int(o["finite"]) == 1 and torch.equal(o["logits"], o_ref["logits"])
+    for k in synth.trainable_keys(mcfg):
+        if "lora_S" in k:
+            g, gr = eng.params.view(k, "grad"), fresh.params.view(k, "grad")
+            assert bool(torch.isfinite(g).all()) and torch.equal(g, gr), k

@@ -117,7 +117,7 @@ def test_full_size_3d_oct_step_vs_oracle(dtype):
         if f32:
             assert rel(g, ref) < 5e-3, (k, rel(g, ref))
         else:
-            assert cos(g, ref) > 0.97, (k, cos(g, ref))
+            assert cos(g, ref) > 0.985, (k, cos(g, ref))
     print("oct3d", dtype, "worst gradient cosine", worst, "worst rel err", werr)
 
 
@@ -179,7 +179,7 @@ def test_3d_oct_at_bench_size_bf16_vs_f32_engine():
         if float(gr.abs().max()) == 0.0:
             continue
         worst = min(worst, (cos(g, gr), k))
-        assert cos(g, gr) > 0.97, (k, cos(g, gr))
+        assert cos(g, gr) > 0.985, (k, cos(g, gr))
         assert 0.9 < float(g.norm() / gr.norm()) < 1.1, (k, float(g.norm() / gr.norm()))
     print("oct3d B=4 bf16 vs f32: worst gradient cosine", worst)
 
@@ -274,7 +274,7 @@ def test_zz_3d_oct_at_bench_size_f32_and_16bit_vs_oracle():
             if f32:
                 assert rel(g, ref) < 5e-3, (k, rel(g, ref))
             else:
-                assert cos(g, ref) > 0.97, (dtype, k, cos(g, ref))
+                assert cos(g, ref) > 0.985, (dtype, k, cos(g, ref))
         print("oct3d B=4 r=16", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits),
               "worst gradient cosine", worst, "worst rel err", werr)
         del eng

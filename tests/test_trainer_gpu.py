@@ -688,3 +688,45 @@ def test_custom_clip_reference_constructor(golden_dir, tag, mk, names, attribute
     batch = synth.make_batch(mcfg, 6, seed=77)
     logits = model(batch["img"].cuda(), batch["attrs"].t()[0].cuda())
     assert rel(logits, unit[f"{tag}.logits"]) < 3e-5, rel(logits, unit[f"{tag}.logits"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_fairlora_linear_rank16_wide_output_ds_sums_only_written_partials(dtype):
+    """FairLoRALinear.backward at rank 16, 3072 outputs, >= 1024 rows in 16-bit storage: the matrix-core down projection
+    writes ceil(M / 16) dS partial rows; the sum over them must not reach into unwritten memory (the allocator's cached
+    blocks are filled with NaN in front of the call) and has to match float64 autograd of the reference's formula
+    (trainers/GLP_OT_SVLoRA.py:450-482)."""
+    from fairfedmed_amd.model import FairLoRALinear
+    from fairfedmed_amd import ops
+    L, Bn, fin, fout, r, G = 300, 4, 768, 3072, 16, 3
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(L, Bn, fin, generator=gen)
+    g = torch.randn(L, Bn, fout, generator=gen) * 0.1
+    attr = torch.randint(0, G, (Bn,), generator=gen)
+    lin = torch.nn.Linear(fin, fout)
+    layer = FairLoRALinear(lin.cuda(), rank=r, alpha=2.0, num_attrs=G)
+    A, Sm, Bm = torch.randn(fin, r, generator=gen) * 0.05, torch.rand(G, r, generator=gen), torch.randn(r, fout, generator=gen) * 0.05
+    layer.lora_A.weight.data.copy_(A)
+    layer.lora_S.weight.data.copy_(Sm)
+    layer.lora_B.weight.data.copy_(Bm)
+    xin = x.cuda().to(dtype).requires_grad_(True)
+    y = layer(xin, attr.cuda())
+    nb = ops.lora_down_blocks(L * Bn, fout, r, dtype)
+    assert nb == (L * Bn + 15) // 16 < ops.lora_down_blocks_max(L * Bn, fout, r, dtype)
+    for n in (nb, ops.lora_down_blocks_max(L * Bn, fout, r, dtype)):     # poison what torch.empty may hand out next
+        junk = [torch.full((n, G, r), float("nan"), device="cuda") for _ in range(3)]
+        del junk
+    y.backward(g.cuda().to(dtype))
+    # float64 autograd of the reference's forward on the 16-bit-rounded operands
+    xd = x.to(dtype).double()
+    Ad, Sd, Bd = (t.double().requires_grad_(True) for t in (A, Sm, Bm))
+    pi = torch.full((Bn, G), 0.3 / (G - 1), dtype=torch.float64)
+    pi[torch.arange(Bn), attr] = 0.7
+    s = pi @ Sd
+    yd = xd @ lin.weight.detach().cpu().double().t() + lin.bias.detach().cpu().double() + (2.0 / r) * (((xd @ Ad) * s[None]) @ Bd)
+    yd.backward(g.to(dtype).double())
+    assert bool(torch.isfinite(layer.lora_S.weight.grad).all())
+    assert rel(y.detach().float(), yd.detach()) < 1.5e-2
+    assert rel(layer.lora_S.weight.grad, Sd.grad) < 4e-2
+    assert rel(layer.lora_A.weight.grad, Ad.grad) < 4e-2
+    assert rel(layer.lora_B.weight.grad, Bd.grad) < 4e-2
