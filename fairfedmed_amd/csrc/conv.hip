@@ -142,13 +142,15 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, const T* __restrict__ p1,
                                                      const T* __restrict__ mask, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ part, int rows,
-                                                     int C, int rpb, T* __restrict__ gout = nullptr) {
+                                                     int C, int rpb, T* __restrict__ gout = nullptr, int strip = 0) {
+    // strip > 0: a block owns `strip` channel chunks (a 128-byte strip of every row) instead of up to 256 - the geometry
+    // of the folded BatchNorm path below, whose few partial rows want many blocks along the channels
     constexpr int VN = VecC<T>::N;
     __shared__ float red[2][256][VN + 1];
     const int cc = C / VN;
-    const int tpr = cc < 256 ? cc : 256, nrl = 256 / tpr;
+    const int tpr = strip > 0 ? (cc < strip ? cc : strip) : (cc < 256 ? cc : 256), nrl = 256 / tpr;
     const int chl = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-    const int ch = blockIdx.y * 256 + chl;
+    const int ch = blockIdx.y * tpr + chl;
     const int r0 = blockIdx.x * rpb, r1 = (r0 + rpb) < rows ? (r0 + rpb) : rows;
     float s0[VN], s1[VN];
 #pragma unroll
@@ -188,42 +190,62 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ p0, c
     __syncthreads();
     for (int i = threadIdx.x; i < tpr * VN; i += 256) {
         const int cl = i / VN, e = i % VN;
-        if (blockIdx.y * 256 + cl >= cc) continue;
+        if (blockIdx.y * tpr + cl >= cc) continue;
         float t0 = 0.f, t1 = 0.f;
         for (int l = 0; l < nrl; ++l) { t0 += red[0][l * tpr + cl][e]; t1 += red[1][l * tpr + cl][e]; }
-        const int c = (blockIdx.y * 256 + cl) * VN + e;
+        const int c = (blockIdx.y * tpr + cl) * VN + e;
         part[((size_t)blockIdx.x * 2 + 0) * C + c] = t0;
         part[((size_t)blockIdx.x * 2 + 1) * C + c] = t1;
     }
 }
 
-// sum of the nblk partial rows of channel c, CS_FL adjacent lanes per channel (block = 256 / CS_FL channels)
-constexpr int CS_FL = 64;
-__device__ __forceinline__ void cs_total(const float* __restrict__ part, int nblk, int C, int c, double& s, double& q) {
-    const int lane = threadIdx.x & (CS_FL - 1);
-    s = q = 0.0;
-    if (c < C) {
-#pragma unroll 4
-        for (int b = lane; b < nblk; b += CS_FL) {
-            s += part[((size_t)b * 2) * C + c];
-            q += part[((size_t)b * 2 + 1) * C + c];
+// totals over nb partial rows [nb][2][C] of the strip's channels [c0, c0 + sw): tot[j * 64 + cl], j = 0 (sum a) / 1 (sum a b).
+// sw <= 64, a multiple of 4; 4 adjacent channels per thread (16-byte loads), 256 / (sw / 2) threads share them along nb.
+__device__ __forceinline__ void bnf_head_totals(const float* __restrict__ part, int nb, int C, int c0, int sw, double* tot,
+                                                double (*red)[4]) {
+    const int nq = sw / 2;                                      // quads of channels x 2 sums
+    const int tq = 256 / nq;
+    const int quad = threadIdx.x % nq, sub = threadIdx.x / nq;
+    const int j = quad / (sw / 4), c = c0 + (quad % (sw / 4)) * 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (sub < tq) {
+#pragma unroll 8
+        for (int b = sub; b < nb; b += tq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + ((size_t)b * 2 + j) * C + c);
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
         }
     }
-#pragma unroll
-    for (int d = 1; d < CS_FL; d <<= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2; red[threadIdx.x][3] = a3;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * sw) {
+        const int jj = threadIdx.x / sw, cl = threadIdx.x % sw;
+        const int q = jj * (sw / 4) + cl / 4, e = cl % 4;
+        double s = 0.0;
+        for (int k = 0; k < tq; ++k) s += red[k * nq + q][e];
+        tot[jj * 64 + cl] = s;
+    }
+    __syncthreads();
 }
+
+// The finalize launches of the three-launch path (large maps).  A block owns `sw` adjacent channels (16; 4 when there are
+// more than 512 partial rows - layer1 and the stem, whose few channels would otherwise make a handful of blocks) and walks the partial rows with 16-byte loads, 256 / (sw / 2) threads side by
+// side (round 4's kernel gave every channel 64 lanes with 4-byte loads: each touched a cache line of its own, 6.4 us).
+__device__ __forceinline__ int fin_sw(int nblk) { return nblk > 512 ? 4 : 16; }
+inline int fin_sw_host(int nblk) { return nblk > 512 ? 4 : 16; }
 
 // mean / rstd of the batch (biased variance, eps 1e-5) + running statistics update (unbiased variance, momentum)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int C,
                                                           float* __restrict__ mean, float* __restrict__ rstd,
                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
                                                           float momentum, float eps) {
-    const int c = blockIdx.x * (256 / CS_FL) + threadIdx.x / CS_FL;
-    double s, q;
-    cs_total(part, nblk, C, c, s, q);
-    if (c >= C || (threadIdx.x & (CS_FL - 1))) return;
-    const double mu = s / rows;
-    double var = q / rows - mu * mu;
+    __shared__ double red[256][4];
+    __shared__ double tot[128];
+    const int sw0 = fin_sw(nblk), c0 = blockIdx.x * sw0, sw = (C - c0) < sw0 ? (C - c0) : sw0;
+    bnf_head_totals(part, nblk, C, c0, sw, tot, red);
+    if ((int)threadIdx.x >= sw) return;
+    const int c = c0 + threadIdx.x;
+    const double mu = tot[threadIdx.x] / rows;
+    double var = tot[64 + threadIdx.x] / rows - mu * mu;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -304,10 +326,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int C,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ k12) {
-    const int c = blockIdx.x * (256 / CS_FL) + threadIdx.x / CS_FL;
-    double s, q;
-    cs_total(part, nblk, C, c, s, q);
-    if (c >= C || (threadIdx.x & (CS_FL - 1))) return;
+    __shared__ double red[256][4];
+    __shared__ double tot[128];
+    const int sw0 = fin_sw(nblk), c0 = blockIdx.x * sw0, sw = (C - c0) < sw0 ? (C - c0) : sw0;
+    bnf_head_totals(part, nblk, C, c0, sw, tot, red);
+    if ((int)threadIdx.x >= sw) return;
+    const int c = c0 + threadIdx.x;
+    const double s = tot[threadIdx.x], q = tot[64 + threadIdx.x];
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     k12[c] = (float)(s / rows);
@@ -330,6 +355,163 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     bn_param<VN>(gamma, L.ch * VN, ga);
     bn_param<VN>(k12, L.ch * VN, k1);
     bn_param<VN>(k12 + C, L.ch * VN, k2);
+    for (int r = blockIdx.x * L.nrl + L.rl; r < rows; r += gridDim.x * L.nrl) {
+        const size_t o = (size_t)r * C + (size_t)L.ch * VN;
+        float g[VN], xv[VN], m[VN];
+        VecC<T>::load(dy + o, g);
+        VecC<T>::load(x + o, xv);
+        if (mask) VecC<T>::load(mask + o, m);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float gg = g[e];
+            if (mask && !(m[e] > 0.f)) gg = 0.f;
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            g[e] = ga[e] * rs[e] * (gg - k1[e] - xh * k2[e]);
+        }
+        VecC<T>::store(dx + o, g);
+    }
+}
+
+
+// ---- BatchNorm on the small maps without the finalize launch ("folded": layer3 / layer4, rows <= FFM_BN_FOLD_ROWS) ----
+// The three-launch path spends a launch of its own (6.4 us + a kernel boundary) on summing the partial rows, 110 times per
+// RN50 step.  Here every block of the apply pass sums the partial rows of ITS channels at its head, in a fixed order (all
+// blocks get the same bits), and the blocks of row group 0 write the per-channel results.  That only pays while the
+// partials are few and the blocks own few channels - head traffic = row groups x partial rows x 8 C bytes - so the
+// geometry is a strip one: a block owns 128 bytes of every row (64 / 32 channels) and one of G row groups; the backward
+// column-sum pass runs on the same strips with G partial rows (bn_fold_geom).  The large maps keep the three launches.
+// Measured on the RN50 step (bs 32, one call): 6.53 ms without, 6.29 with rows <= 8192 folded, 6.26 with layer2 as well.
+constexpr int BNF_STRIP_BYTES = 128;
+struct bn_fold { bool on; int G, strip; };
+inline bn_fold bn_fold_geom(int rows, int C, int vn, int given_part_rows) {
+    static const int max_rows = getenv("FFM_BN_FOLD_ROWS") ? atoi(getenv("FFM_BN_FOLD_ROWS")) : 32768;
+    bn_fold f{false, 0, BNF_STRIP_BYTES / 16};
+    if (rows > max_rows) return f;
+    int G = 1;
+    while ((long long)(G + 1) * (G + 1) * 8 * C <= (16ll << 20) && G < 128) ++G;     // G^2 x 8 C bytes of head traffic <= 16 MB
+    const int most = cs_blocks(rows);                                                  // (the partial buffer is sized by it)
+    if (G > most) G = most;
+    if (G > rows) G = rows;
+    if (given_part_rows > 0) {                                                         // forward: the producer's row tiles
+        if (given_part_rows > 1024) return f;
+        long long g2 = (16ll << 20) / ((long long)given_part_rows * 8 * C);
+        if (g2 < 8) return f;
+        if (g2 < G) G = (int)g2;
+    }
+    // a mid-sized map (layer2: 25 088 rows) with few channels makes too few strips to stream at the HBM rate (C = 128:
+    // 256 blocks, the backward apply pass 11.4 us against 6.4 + a 6.7 us finalize launch): those keep the three launches
+    if (rows > 8192 && (long long)G * ((C / vn + f.strip - 1) / f.strip) < 384) return f;
+    f.on = true;
+    f.G = G < 1 ? 1 : G;
+    return f;
+}
+
+struct bnf_lanes {
+    int tpr, nrl, ch, rl, c0, sw;
+    bool on;
+    template <int VN>
+    __device__ __forceinline__ static bnf_lanes make(int C, int strip) {
+        bnf_lanes l;
+        const int cc = C / VN;
+        l.tpr = cc < strip ? cc : strip;
+        l.nrl = 256 / l.tpr;
+        l.ch = blockIdx.y * l.tpr + threadIdx.x % l.tpr;
+        l.rl = threadIdx.x / l.tpr;
+        l.on = l.rl < l.nrl && l.ch < cc;
+        l.c0 = blockIdx.y * l.tpr * VN;
+        l.sw = (C - l.c0) < l.tpr * VN ? (C - l.c0) : l.tpr * VN;
+        return l;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fold_kernel(const T* __restrict__ x, const float* __restrict__ part, int nb,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const T* __restrict__ res, T* __restrict__ y, int rows, int C,
+                                                            int relu, int strip, float momentum, float eps) {
+    constexpr int VN = VecC<T>::N;
+    __shared__ double red[256][4];
+    __shared__ double tot[128];
+    __shared__ float par[2][64];                                // mean, rstd of the strip
+    const bnf_lanes L = bnf_lanes::make<VN>(C, strip);
+    bnf_head_totals(part, nb, C, L.c0, L.sw, tot, red);
+    if ((int)threadIdx.x < L.sw) {
+        const int c = L.c0 + threadIdx.x;
+        const double mu = tot[threadIdx.x] / rows;
+        double var = tot[64 + threadIdx.x] / rows - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        par[0][threadIdx.x] = m;
+        par[1][threadIdx.x] = r;
+        if (blockIdx.x == 0) {                                  // one writer per channel
+            mean[c] = m;
+            rstd[c] = r;
+            if (run_mean) {
+                const double unb = rows > 1 ? var * rows / (rows - 1) : var;
+                run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mu);
+                run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    if (!L.on) return;
+    float mu[VN], rs[VN], ga[VN], be[VN];
+    const int cl = (L.ch * VN) - L.c0;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { mu[e] = par[0][cl + e]; rs[e] = par[1][cl + e]; }
+    bn_param<VN>(gamma, L.ch * VN, ga);
+    bn_param<VN>(beta, L.ch * VN, be);
+#pragma unroll 4
+    for (int r = blockIdx.x * L.nrl + L.rl; r < rows; r += gridDim.x * L.nrl) {
+        const size_t o = (size_t)r * C + (size_t)L.ch * VN;
+        float v[VN], rr[VN];
+        VecC<T>::load(x + o, v);
+        if (res) VecC<T>::load(res + o, rr);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float t = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+            if (res) t += rr[e];
+            v[e] = relu ? fmaxf(t, 0.f) : t;
+        }
+        VecC<T>::store(y + o, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fold_kernel(const T* __restrict__ dy, const T* __restrict__ mask,
+                                                                const T* __restrict__ x, const float* __restrict__ part, int nb,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, T* __restrict__ dx, int rows, int C,
+                                                                int strip) {
+    constexpr int VN = VecC<T>::N;
+    __shared__ double red[256][4];
+    __shared__ double tot[128];
+    __shared__ float par[2][64];                                // k1 = sum g / N, k2 = sum g xhat / N
+    const bnf_lanes L = bnf_lanes::make<VN>(C, strip);
+    bnf_head_totals(part, nb, C, L.c0, L.sw, tot, red);
+    if ((int)threadIdx.x < L.sw) {
+        const int c = L.c0 + threadIdx.x;
+        const double s = tot[threadIdx.x], q = tot[64 + threadIdx.x];
+        par[0][threadIdx.x] = (float)(s / rows);
+        par[1][threadIdx.x] = (float)(q / rows);
+        if (blockIdx.x == 0) {
+            dbeta[c] = (float)s;
+            dgamma[c] = (float)q;
+        }
+    }
+    __syncthreads();
+    if (!L.on) return;
+    float mu[VN], rs[VN], ga[VN], k1[VN], k2[VN];
+    const int cl = (L.ch * VN) - L.c0;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { k1[e] = par[0][cl + e]; k2[e] = par[1][cl + e]; }
+    bn_param<VN>(mean, L.ch * VN, mu);
+    bn_param<VN>(rstd, L.ch * VN, rs);
+    bn_param<VN>(gamma, L.ch * VN, ga);
+#pragma unroll 2
     for (int r = blockIdx.x * L.nrl + L.rl; r < rows; r += gridDim.x * L.nrl) {
         const size_t o = (size_t)r * C + (size_t)L.ch * VN;
         float g[VN], xv[VN], m[VN];
@@ -533,12 +715,32 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
                           float* mean, float* rstd, float* part, int part_rows, const void* res, void* y, int rows, int C,
                           int training, int relu, int dtype, void* stream) {
     if (!x || !gamma || !beta || !run_mean || !run_var || !mean || !rstd || !y || rows <= 0 || C <= 0) return FFM_EINVAL;
-    if (C % (dtype == FFM_BF16 ? 8 : 4) || (training && !part)) return FFM_EINVAL;
+    if (C % (dtype == FFM_BF16 ? 8 : 4) || (training && !part) || ((uintptr_t)part & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const int vn = dtype == FFM_BF16 ? 8 : 4;
+    const bn_fold fold = training ? bn_fold_geom(rows, C, vn, part_rows) : bn_fold{false, 0, 0};
+    if (fold.on) {                                   // small map: no finalize launch (bn_apply_fold_kernel sums the partials)
+        if (((uintptr_t)part & 15) || C % 4) return FFM_EINVAL;
+        const int gy = (C / vn + fold.strip - 1) / fold.strip;
+        int nb = part_rows;
+        if (part_rows <= 0) {
+            const int rpb = (rows + fold.G - 1) / fold.G;
+            nb = (rows + rpb - 1) / rpb;
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), dim3(nb, gy), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb, (bf16_t*)nullptr, fold.strip),
+                       hipLaunchKernelGGL((colsum_kernel<float, 0>), dim3(nb, gy), dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb, (float*)nullptr, fold.strip))
+            FFM_CHECK_LAUNCH();
+        }
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((bn_apply_fold_kernel<bf16_t>), dim3(fold.G, gy), dim3(256), 0, s, (const bf16_t*)x, part, nb, mean, rstd, run_mean, run_var, gamma, beta, (const bf16_t*)res, (bf16_t*)y, rows, C, relu, fold.strip, 0.1f, 1e-5f),
+                   hipLaunchKernelGGL((bn_apply_fold_kernel<float>), dim3(fold.G, gy), dim3(256), 0, s, (const float*)x, part, nb, mean, rstd, run_mean, run_var, gamma, beta, (const float*)res, (float*)y, rows, C, relu, fold.strip, 0.1f, 1e-5f))
+        FFM_CHECK_LAUNCH();
+        return FFM_OK;
+    }
     if (training && part_rows > 0) {
         // the producer of x left the column sums of its row tiles behind (ffm_gemm_args.colstat_part)
         if (part_rows > 4096) return FFM_EINVAL;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, part_rows, rows, C, mean, rstd, run_mean,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + fin_sw_host(part_rows) - 1) / fin_sw_host(part_rows)), dim3(256), 0, s, part, part_rows, rows, C, mean, rstd, run_mean,
                            run_var, 0.1f, 1e-5f);
     } else if (training) {
         const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
@@ -547,7 +749,7 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
                    hipLaunchKernelGGL((colsum_kernel<bf16_t, 0>), g, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb),
                    hipLaunchKernelGGL((colsum_kernel<float, 0>), g, dim3(256), 0, s, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, rows, C, rpb))
         FFM_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + fin_sw_host(nblk) - 1) / fin_sw_host(nblk)), dim3(256), 0, s, part, nblk, rows, C, mean, rstd, run_mean,
                            run_var, 0.1f, 1e-5f);
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, run_mean, run_var, mean, rstd, C, 1e-5f);
@@ -566,15 +768,30 @@ extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, c
                           int rows, int C, int dtype, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !part || !k12 || !dgamma || !dbeta || !dx || rows <= 0 || C <= 0)
         return FFM_EINVAL;
-    if (C % (dtype == FFM_BF16 ? 8 : 4)) return FFM_EINVAL;
+    if (C % (dtype == FFM_BF16 ? 8 : 4) || ((uintptr_t)part & 15)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const bn_fold fold = bn_fold_geom(rows, C, dtype == FFM_BF16 ? 8 : 4, 0);
+    if (fold.on) {                                   // small map: column sums on strips, no finalize launch
+        if (((uintptr_t)part & 15) || C % 4) return FFM_EINVAL;
+        const int gy = (C / (dtype == FFM_BF16 ? 8 : 4) + fold.strip - 1) / fold.strip;
+        const int rpb = (rows + fold.G - 1) / fold.G, nb = (rows + rpb - 1) / rpb;
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), dim3(nb, gy), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out, fold.strip),
+                   hipLaunchKernelGGL((colsum_kernel<float, 1>), dim3(nb, gy), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out, fold.strip))
+        FFM_CHECK_LAUNCH();
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((bn_bwd_apply_fold_kernel<bf16_t>), dim3(fold.G, gy), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)relu_out, (const bf16_t*)x, part, nb, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, rows, C, fold.strip),
+                   hipLaunchKernelGGL((bn_bwd_apply_fold_kernel<float>), dim3(fold.G, gy), dim3(256), 0, s, (const float*)dy, (const float*)relu_out, (const float*)x, part, nb, mean, rstd, gamma, dgamma, dbeta, (float*)dx, rows, C, fold.strip))
+        FFM_CHECK_LAUNCH();
+        return FFM_OK;
+    }
     const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
     dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out),
                hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out))
     FFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + fin_sw_host(nblk) - 1) / fin_sw_host(nblk)), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();
     const dim3 g2 = bn_apply_grid(rows, C, dtype == FFM_BF16 ? 8 : 4);
     DISPATCH_T(dtype,
