@@ -113,7 +113,11 @@ class GemmTimer:
                 fl += 2.0 * M * K * 16 + 2.0 * M * N * rk.S.shape[1]
                 if getattr(rk, "lgrad", None) is not None:      # FFM_EPI_LGRAD: dB(c_fc) and dA(c_proj), 2 M N r each
                     fl += 2 * 2.0 * M * N * rk.S.shape[1]
-            self.rec.append((e0, e1, fl, M))
+            # algorithmic HBM bytes of the launch: each operand once, the stored output, and every full-size epilogue
+            # stream (residual in, GELU image out, pre-activation in for dGELU) - DESIGN.md section 4.1's count
+            es = a.element_size()
+            streams = 1 + sum(kw.get(k) is not None for k in ("res", "gelu_out", "dgelu_aux"))
+            self.rec.append((e0, e1, fl, M, es * (M * K + N * K + streams * M * N)))
             return r
 
         def timed_conv(x, w, out, *a, **kw):
@@ -121,7 +125,8 @@ class GemmTimer:
             e0.record()
             r = self.orig_conv(x, w, out, *a, **kw)
             e1.record()
-            self.rec.append((e0, e1, 2.0 * x.shape[0] * w.shape[0] * 9 * x.shape[1], x.shape[0]))
+            self.rec.append((e0, e1, 2.0 * x.shape[0] * w.shape[0] * 9 * x.shape[1], x.shape[0],
+                             x.element_size() * (x.numel() + w.numel() + x.shape[0] * w.shape[0])))
             return r
         self.ops.gemm_nt, self.ops.conv3x3 = timed, timed_conv
         return self
@@ -144,8 +149,9 @@ class GemmTimer:
 
     def summary(self, min_rows=0):
         torch.cuda.synchronize()
-        sel = [(e0.elapsed_time(e1), f) for e0, e1, f, M in self.rec if M >= min_rows]
-        return len(sel), sum(t for t, _ in sel), sum(f for _, f in sel)
+        sel = [(e0.elapsed_time(e1), f, by) for e0, e1, f, M, by in self.rec if M >= min_rows]
+        self.alg_bytes = sum(by for _, _, by in sel) / max(1, len(sel))
+        return len(sel), sum(t for t, _, _ in sel), sum(f for _, f, _ in sel)
 
 
 def usable_cores() -> int:
@@ -542,8 +548,9 @@ def main():
                 torch.cuda._sleep(spin)
                 eager_step()
                 gt.calibrate()
-            n, ms, fl = gt.summary(min_rows=wl.min_rows)   # the vision tower's GEMMs (not the text tower's 40 rows)
             n_all, ms_all, fl_all = gt.summary()
+            n, ms, fl = gt.summary(min_rows=wl.min_rows)   # the vision tower's GEMMs (not the text tower's 40 rows)
+            alg_bytes = gt.alg_bytes
             floor_us = gt.pair_floor_us()
         eng.set_overlap(True)
         peak = MFMA_BF16_PEAK_TFLOPS if dtype != torch.float32 else MFMA_F32_PEAK_TFLOPS     # (the f16 MFMA forms run at the bf16 rate)
@@ -570,7 +577,10 @@ def main():
                       "not counted), gemm_nt_kernel otherwise" % (wl.rows, args.dtype))
         roof = {"bound": "mfma", "kernel": kernel,
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), algorithmic mean 54.4e6",
+                "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), mean over the same launches",
+                # what the same launches must move at least (operands once + stored output + full-size epilogue streams),
+                # mean per launch, for THIS workload - the figure `traffic` is to be read against
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic_source": tsrc,
                 "launches_per_step": n // args.steps, "avg_launch_us": ms * 1e3 / n,
                 "gemm_ms_per_step": ms / args.steps,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "ffm_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _i32, _vp],
     "ffm_embed_lnpre": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_slice_blocks": [_i32, _i32],
+    "ffm_slice_wgrad_blocks": [_i32, _i32],
     "ffm_slice_bwd_ab_blocks": [],
     "ffm_slice_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ffm_patchify_minmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _i32, _vp],

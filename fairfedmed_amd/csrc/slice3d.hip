@@ -12,6 +12,12 @@ constexpr int HALO = 2;
 constexpr int IT = TS + 2 * HALO;
 constexpr int MAXD = 16;        // slices per group (reference default 8)
 
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+
 __device__ __forceinline__ void stage_input(const float* __restrict__ img, float* in_s, int n, int D, int H, int W,
                                             int y0, int x0, int tid) {
     for (int idx = tid; idx < D * IT * IT; idx += 256) {
@@ -231,6 +237,302 @@ __global__ __launch_bounds__(256) void slice_conv_wgrad_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation of the two convolution passes (round 5).  The first one staged a 16 x 16 tile with its halo in LDS
+// and read every input AND every weight back from LDS per multiply (forward: 800 LDS reads for 600 FMAs per pixel;
+// weight gradient: two LDS reads per FMA and 196 partial rows of 603 floats per image): 371 us and 552 + 141 us per
+// step of BASELINE configs[3] (100 slice groups of 8 x 224 x 224) against ~90 us of fp32 FMA issue for either.
+// Here a lane owns a COLUMN x of a 64-column strip and walks down the rows:
+//   forward   the wave keeps FW_R output rows x 3 channels in registers; for every input channel and input row it loads
+//             the five values x - 2 .. x + 2 once (coalesced dword loads, L1 hits for the overlap) and feeds the <= 5
+//             output rows they touch - 75 FMAs per 5 loads, the weights of the channel in SGPRs (uniform s_loads);
+//   gradient  a wave owns ONE input channel: 75 + 3 accumulators per lane (3 outputs x 5 x 5 taps), a rolling window
+//             of five input rows in registers, one cross-lane reduction per wave at the end of its WG_R rows; the
+//             partial rows shrink from 196 to 16 per image (the reduction behind them from 141 to ~10 us).
+// Same arithmetic per element as before (image / 255 became image * (1 / 255): one ulp of the input at most).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FW_R = 14;        // output rows per wave, forward (224 = 16 x 14)
+constexpr int WG_R = 56;        // output rows per wave, weight gradient (224 = 4 x 56)
+constexpr int SW = 64;          // columns per strip = lanes
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void slice_conv_fwd2_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              float* __restrict__ mm_part, int D, int H, int W, int nrb) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.z, rb = blockIdx.y * 4 + wave;
+    if (rb >= nrb) return;
+    const int x = blockIdx.x * SW + lane, y0 = rb * FW_R;
+    int xc[5];
+    bool xok[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+        const int xx = x + kx - 2;
+        xok[kx] = xx >= 0 && xx < W;
+        xc[kx] = xx < 0 ? 0 : (xx < W ? xx : W - 1);
+    }
+    float acc[FW_R][3];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+#pragma unroll
+    for (int r = 0; r < FW_R; ++r) { acc[r][0] = b0; acc[r][1] = b1; acc[r][2] = b2; }
+    int xb[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) xb[kx] = xc[kx] * 4;
+    for (int c = 0; c < D; ++c) {
+        const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + ((size_t)n * D + c) * H * W), 0, H * W * 4, 0x00020000);
+        float wr[3][25];                                            // uniform addresses: scalar loads, SGPR operands
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int k = 0; k < 25; ++k) wr[o][k] = w[(o * D + c) * 25 + k];
+        // input rows two ahead of the FMAs that use them; the scheduling barrier at the end of every row keeps hipcc from
+        // hoisting all 90 loads of a channel to its top (240 registers, and spills at 128)
+        float v[FW_R + 4][5];
+        auto load_row = [&](int j) {
+            const int yy = y0 - 2 + j;
+            const int yc = yy < 0 ? 0 : (yy < H ? yy : H - 1);      // (a row outside the image: any row, zeroed at its use)
+            // buffer loads: plane descriptor + uniform row offset (SGPR) + the lane's column offset - no 64-bit lane
+            // addresses (flat loads made hipcc keep 90 loop-invariant address pairs alive: spills at 128 registers)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+                v[j][kx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, xb[kx], yc * W * 4, 0));
+        };
+        // the raw value is scaled / zeroed where it is USED: done at the load, the wait for it would sit there as well
+        auto use_row = [&](int j) {
+            const int yy = y0 - 2 + j;
+            const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) v[j][kx] = (rowok && xok[kx]) ? v[j][kx] * (1.0f / 255.0f) : 0.f;
+        };
+        load_row(0);
+        load_row(1);
+#pragma unroll
+        for (int j = 0; j < FW_R + 4; ++j) {
+            if (j + 2 < FW_R + 4) load_row(j + 2);
+            use_row(j);
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int r = j - ky;
+                if (r < 0 || r >= FW_R) continue;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) acc[r][o] = fmaf(v[j][kx], wr[o][ky * 5 + kx], acc[r][o]);
+            }
+            asm volatile("" ::: "memory");                          // (the loads are readonly intrinsics: pins them in the IR too)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float mn = INFINITY, mx = -INFINITY;
+    if (x < W) {
+#pragma unroll
+        for (int r = 0; r < FW_R; ++r) {
+            const int y = y0 + r;
+            if (y >= H) break;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                out[(((size_t)n * 3 + o) * H + y) * W + x] = acc[r][o];
+                mn = fminf(mn, acc[r][o]);
+                mx = fmaxf(mx, acc[r][o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) {
+        const int nblk = gridDim.x * nrb, blk = blockIdx.x * nrb + rb;
+        mm_part[((size_t)n * nblk + blk) * 2] = mn;
+        mm_part[((size_t)n * nblk + blk) * 2 + 1] = mx;
+    }
+}
+
+// part[(n * nblk + blk)][o*D*25 + c*25 + ky*5 + kx] (+ 3 bias sums at the end), blk = strip * nrb + row block; the wave of
+// channel c writes that channel's 75 entries, the wave of channel 0 the three bias sums as well.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void slice_conv_wgrad2_kernel(const float* __restrict__ img, const float* __restrict__ conv,
+                                                                const float* __restrict__ dconv,
+                                                                const float* __restrict__ mnmx,
+                                                                const float* __restrict__ gmm, float* __restrict__ part,
+                                                                int D, int H, int W, int nrb, int cgroups) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.z / cgroups, c = (blockIdx.z % cgroups) * 4 + wave;
+    if (c >= D) return;
+    const int rb = blockIdx.y, y0 = rb * WG_R;
+    const int rows = (H - y0) < WG_R ? (H - y0) : WG_R;
+    const int x = blockIdx.x * SW + lane;
+    int xc[5];
+    bool xok[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+        const int xx = x + kx - 2;
+        xok[kx] = xx >= 0 && xx < W;
+        xc[kx] = xx < 0 ? 0 : (xx < W ? xx : W - 1);
+    }
+    const bool mine = x < W;
+    const int xs = mine ? x : W - 1;
+    const float mn = mnmx[n * 2], mx = mnmx[n * 2 + 1], g0 = gmm[n * 2], g1 = gmm[n * 2 + 1];
+    const auto plane = __builtin_amdgcn_make_buffer_rsrc((void*)(img + ((size_t)n * D + c) * H * W), 0, H * W * 4, 0x00020000);
+    // outputs 0 and 1 share a register pair per tap (v_pk_fma_f32 with the window value broadcast by op_sel), output 2 a
+    // plain FMA: 50 instructions per row instead of 75
+    f32x2 acc01[25];
+    float acc2[25], bs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 25; ++k) { acc01[k] = (f32x2){0.f, 0.f}; acc2[k] = 0.f; }
+    float win[5][5];                                                // input rows y - 2 .. y + 2 of the current output row
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) win[i][kx] = 0.f;
+    // step t takes input row y0 - 2 + t into slot t % 5; from t = 4 on, output row r = t - 4 is complete: its tap row ky is
+    // input row y0 - 2 + r + ky = slot (t + ky + 1) % 5.  Unrolled by 5 so that every slot index is a compile-time constant.
+    // Everything a step reads from memory was requested one step earlier (raw values; scaled / masked at their use, so that
+    // the waits sit there and not at the loads), and a barrier for the compiler at the end of a step keeps that order.
+    const int steps = rows + 4;
+    int xb[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) xb[kx] = xc[kx] * 4;
+    const auto cplane = __builtin_amdgcn_make_buffer_rsrc((void*)(conv + (size_t)n * 3 * H * W), 0, 3 * H * W * 4, 0x00020000);
+    const auto dplane = __builtin_amdgcn_make_buffer_rsrc((void*)(dconv + (size_t)n * 3 * H * W), 0, 3 * H * W * 4, 0x00020000);
+    float rawn[5], cvn[3], dcn[3];
+    auto prefetch = [&](int t) {
+        const int yy = y0 - 2 + t;
+        const int yc = yy < 0 ? 0 : (yy < H ? yy : H - 1);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+            rawn[kx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, xb[kx], yc * W * 4, 0));
+        const int y = y0 + t - 4, yo = y < 0 ? 0 : (y < H ? y : H - 1);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            cvn[o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cplane, xs * 4, (o * H + yo) * W * 4, 0));
+            dcn[o] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dplane, xs * 4, (o * H + yo) * W * 4, 0));
+        }
+    };
+    prefetch(0);
+    for (int q = 0; q * 5 < steps; ++q) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = q * 5 + i;
+            if (t >= steps) break;
+            const int yy = y0 - 2 + t;
+            const bool rowok = yy >= 0 && yy < H;                   // wave-uniform
+            float cv[3], dc[3];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) win[i][kx] = (rowok && xok[kx]) ? rawn[kx] * (1.0f / 255.0f) : 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) { cv[o] = cvn[o]; dc[o] = dcn[o]; }
+            if (t + 1 < steps) prefetch(t + 1);
+            if (t >= 4) {
+                float g[3];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float gv = dc[o] + (cv[o] == mn ? g0 : 0.f) + (cv[o] == mx ? g1 : 0.f);
+                    g[o] = mine ? gv : 0.f;
+                    bs[o] += g[o];
+                }
+                const f32x2 g01 = {g[0], g[1]};
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const float wv = win[(i + ky + 1) % 5][kx];
+                        acc01[ky * 5 + kx] = __builtin_elementwise_fma(g01, (f32x2){wv, wv}, acc01[ky * 5 + kx]);
+                        acc2[ky * 5 + kx] = fmaf(g[2], wv, acc2[ky * 5 + kx]);
+                    }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int nw = 3 * D * 25, nblk = gridDim.x * nrb, blk = blockIdx.x * nrb + rb;
+    float* __restrict__ prow = part + ((size_t)n * nblk + blk) * (nw + 3);
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int k = 0; k < 25; ++k) {
+            const float s = wave_sum(o == 2 ? acc2[k] : acc01[k][o]);
+            if (lane == 0) prow[(o * D + c) * 25 + k] = s;
+        }
+    if (c == 0) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float s = wave_sum(bs[o]);
+            if (lane == 0) prow[nw + o] = s;
+        }
+    }
+}
+
+// token assembly backward, 16-byte loads issued up front (widths up to 1024: the vision towers'); same arithmetic as the
+// kernel below, which keeps the wider rows
+template <typename T, int MC>
+__global__ __launch_bounds__(256) void embed_lnpre_bwd2_kernel(const T* __restrict__ dx, const T* __restrict__ patch,
+                                                               const T* __restrict__ pos, const float* __restrict__ gamma,
+                                                               T* __restrict__ dpatch, int B, int L, int width) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, l = row % L;
+    if (l == 0) return;                                  // the class token is a frozen parameter
+    const int nchunk = width >> 3;
+    const T* src = patch + ((size_t)b * (L - 1) + (l - 1)) * width;
+    const T* pr = pos + (size_t)l * width;
+    const T* dr = dx + (size_t)row * width;
+    float v[MC][8], gy[MC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float a[8], p[8], g[8];
+            Vec8<T>::load(src + c * 8, a);
+            Vec8<T>::load(pr + c * 8, p);
+            Vec8<T>::load(dr + c * 8, gy[i]);
+            load8f(gamma + c * 8, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = Elem<T>::to_f(Elem<T>::from_f(a[e] + p[e]));
+                s += v[i][e];
+                gy[i][e] *= g[e];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MC; ++i)
+        if (lane + 64 * i < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (v[i][e] - mean) * rstd;
+                s1 += gy[i][e];
+                s2 += gy[i][e] * v[i][e];
+            }
+        }
+    const float m1 = wave_sum(s1) / (float)width, m2 = wave_sum(s2) / (float)width;
+    T* dst = dpatch + ((size_t)b * (L - 1) + (l - 1)) * width;
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (gy[i][e] - m1 - v[i][e] * m2);
+            Vec8<T>::store(dst + c * 8, o);
+        }
+    }
+}
+
 // token assembly backward: LayerNorm backward of ln_pre, rows l >= 1 -> dpatch[b*P + l-1]
 template <typename T>
 __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const T* __restrict__ dx, const T* __restrict__ patch,
@@ -301,17 +603,20 @@ __global__ __launch_bounds__(256) void embed_lnpre_bwd_kernel(const T* __restric
 
 }  // namespace
 
-extern "C" int ffm_slice_blocks(int H, int W) { return ((H + TS - 1) / TS) * ((W + TS - 1) / TS); }
+// partial {min, max} pairs per ViT image the forward pass writes / partial weight-gradient rows per image of ffm_slice_bwd
+extern "C" int ffm_slice_blocks(int H, int W) { return ((H + FW_R - 1) / FW_R) * ((W + SW - 1) / SW); }
+extern "C" int ffm_slice_wgrad_blocks(int H, int W) { return ((H + WG_R - 1) / WG_R) * ((W + SW - 1) / SW); }
 
 extern "C" int ffm_slice_conv_fwd(const float* img, const float* w, const float* bias, float* conv, float* mm_part,
                                   float* mnmx, int32_t* cnt, int N, int D, int H, int W, void* stream) {
     if (!img || !w || !bias || !conv || !mm_part || !mnmx || !cnt || N <= 0 || D <= 0 || D > MAXD || H <= 0 || W <= 0)
         return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, N);
-    hipLaunchKernelGGL(slice_conv_fwd_kernel, grid, dim3(256), 0, s, img, w, bias, conv, mm_part, D, H, W);
+    const int nrb = (H + FW_R - 1) / FW_R, strips = (W + SW - 1) / SW;
+    dim3 grid(strips, (nrb + 3) / 4, N);
+    hipLaunchKernelGGL(slice_conv_fwd2_kernel, grid, dim3(256), 0, s, img, w, bias, conv, mm_part, D, H, W, nrb);
     FFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(N), dim3(256), 0, s, mm_part, mnmx, cnt, (int)(grid.x * grid.y));
+    hipLaunchKernelGGL(minmax_reduce_kernel, dim3(N), dim3(256), 0, s, mm_part, mnmx, cnt, strips * nrb);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -343,7 +648,14 @@ extern "C" int ffm_embed_lnpre_bwd(const void* dx, const void* patch, const void
         return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((B * L + 3) / 4), block(256);
-    if (dtype == FFM_BF16)
+    if (dtype == FFM_BF16 && width % 8 == 0 && width <= 1024) {
+        if (width <= 512)
+            hipLaunchKernelGGL((embed_lnpre_bwd2_kernel<bf16_t, 1>), grid, block, 0, s, (const bf16_t*)dx, (const bf16_t*)patch,
+                               (const bf16_t*)pos, gamma, (bf16_t*)dpatch, B, L, width);
+        else
+            hipLaunchKernelGGL((embed_lnpre_bwd2_kernel<bf16_t, 2>), grid, block, 0, s, (const bf16_t*)dx, (const bf16_t*)patch,
+                               (const bf16_t*)pos, gamma, (bf16_t*)dpatch, B, L, width);
+    } else if (dtype == FFM_BF16)
         hipLaunchKernelGGL((embed_lnpre_bwd_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)dx, (const bf16_t*)patch,
                            (const bf16_t*)pos, gamma, (bf16_t*)dpatch, B, L, width);
     else if (dtype == FFM_F32)
@@ -377,8 +689,9 @@ extern "C" int ffm_slice_bwd(const void* dcols, const float* img, const float* c
     hipLaunchKernelGGL(minmax_grad_kernel, dim3((N + 63) / 64), dim3(64), 0, s, ab_part, mnmx, cnt, gmm, N,
                        SLICE_BWD_BLOCKS);
     FFM_CHECK_LAUNCH();
-    dim3 g3((W + TS - 1) / TS, (H + TS - 1) / TS, N);
-    hipLaunchKernelGGL(slice_conv_wgrad_kernel, g3, dim3(256), 0, s, img, conv, dconv, mnmx, gmm, wpart, D, H, W);
+    const int nrb = (H + WG_R - 1) / WG_R, cg = (D + 3) / 4;
+    dim3 g3((W + SW - 1) / SW, nrb, N * cg);
+    hipLaunchKernelGGL(slice_conv_wgrad2_kernel, g3, dim3(256), 0, s, img, conv, dconv, mnmx, gmm, wpart, D, H, W, nrb, cg);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

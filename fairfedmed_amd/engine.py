@@ -395,7 +395,7 @@ class FairLoRAEngine:
             self.mm_cnt = torch.zeros(max_images, 2, device=dev, dtype=torch.int32)
             self.ab_part = torch.zeros(max_images * ops.slice_bwd_ab_blocks() * 2, device=dev, dtype=f32)
             self.gmm = torch.zeros(max_images, 2, device=dev, dtype=f32)
-            self.wpart = torch.zeros(max_images * nblk * (3 * D * 25 + 3), device=dev, dtype=f32)
+            self.wpart = torch.zeros(max_images * ops.slice_wgrad_blocks(H, H) * (3 * D * 25 + 3), device=dev, dtype=f32)
             self.dcols = torch.zeros_like(self.cols)
             self.dpatch = torch.zeros_like(self.patch_out)
 
@@ -1058,7 +1058,7 @@ class FairLoRAEngine:
                 nw = 3 * D * 25 + 3
                 off = self.params.offsets["proj_per_3d_slice.weight"][0]
                 assert self.params.offsets["proj_per_3d_slice.bias"][0] == off + nw - 3
-                nblk = ops.slice_blocks(self.cfg.vision.image_size, self.cfg.vision.image_size)
+                nblk = ops.slice_wgrad_blocks(self.cfg.vision.image_size, self.cfg.vision.image_size)
                 ops.reduce_partials(self.wpart, images * nblk, nw, self.params.grad[off:off + nw])
             if self.grad_scale != 1.0:
                 ops.scale_check(self.params.grad, 1.0 / self.grad_scale, self.finite)

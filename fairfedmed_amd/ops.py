@@ -283,6 +283,11 @@ def slice_blocks(H: int, W: int) -> int:
     return L.load().ffm_slice_blocks(H, W)
 
 
+def slice_wgrad_blocks(H: int, W: int) -> int:
+    """Partial rows per ViT image of slice_bwd's wpart [N * blocks, 3 D 25 + 3]."""
+    return L.load().ffm_slice_wgrad_blocks(H, W)
+
+
 def slice_bwd_ab_blocks() -> int:
     return L.load().ffm_slice_bwd_ab_blocks()
 

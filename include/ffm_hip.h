@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 10  /* 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers; 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 10  /* 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -242,11 +242,12 @@ int ffm_embed_lnpre(const void* patch, const void* cls, const void* pos, const f
  *   ffm_patchify_minmax  cols = patches of ((conv - min)/(max - min + 1e-5) - mean)/std; counts the tied extrema
  *   ffm_embed_lnpre_bwd  backward of ffm_embed_lnpre w.r.t. the patch rows (class token / pos are frozen)
  *   ffm_slice_bwd        dcols [N*P, 3*ps*ps] -> gradient partials of the conv weight and bias:
- *                        wpart [N * ffm_slice_blocks(H,W)][3*D*25 + 3] (reduce with ffm_reduce_partials);
+ *                        wpart [N * ffm_slice_wgrad_blocks(H,W)][3*D*25 + 3] (reduce with ffm_reduce_partials);
  *                        scratch: dconv [N,3,H,W], ab_part [N * ffm_slice_bwd_ab_blocks() * 2], gmm [N,2]
  * mean3 / std3 are HOST pointers.
  */
-int ffm_slice_blocks(int H, int W);
+int ffm_slice_blocks(int H, int W);         /* {min, max} partial pairs per image (forward) */
+int ffm_slice_wgrad_blocks(int H, int W);   /* weight-gradient partial rows per image (ffm_slice_bwd) */
 int ffm_slice_bwd_ab_blocks(void);
 int ffm_slice_conv_fwd(const float* img, const float* w, const float* bias, float* conv, float* mm_part,
                        float* mnmx, int32_t* cnt, int N, int D, int H, int W, void* stream);

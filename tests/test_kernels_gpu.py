@@ -382,7 +382,10 @@ def test_patchify_and_embed(ops, dt):
 
 # ------------------------------------------------- 3D OCT slice front end ---
 @pytest.mark.parametrize("dt", DT, ids=IDS)
-@pytest.mark.parametrize("N,D,H,ps,width", [(4, 4, 64, 16, 128), (3, 8, 96, 16, 256), (2, 2, 224, 16, 768)])
+@pytest.mark.parametrize("N,D,H,ps,width", [(4, 4, 64, 16, 128), (3, 8, 96, 16, 256), (2, 2, 224, 16, 768),
+                                            (2, 16, 32, 8, 64),      # MAXD slices per group, one strip, ragged row blocks
+                                            (2, 5, 40, 8, 64),       # a slice count that is no multiple of the 4 waves
+                                            (1, 8, 224, 16, 768)])   # the bench geometry: 16 x 14-row / 4 x 56-row blocks
 def test_slice3d_front_end(ops, dt, N, D, H, ps, width):
     """conv5x5 + per-image min-max + patchify, and their backward down to the conv weight/bias gradient,
     against torch autograd in fp64 (trainers/GLP_OT_SVLoRA.py:681-693)."""
@@ -421,17 +424,18 @@ def test_slice3d_front_end(ops, dt, N, D, H, ps, width):
     ab_part = torch.empty(N * ops.slice_bwd_ab_blocks() * 2, device="cuda")
     gmm = torch.empty(N, 2, device="cuda")
     nw = 3 * D * 25 + 3
-    wpart = torch.empty(N * nblk * nw, device="cuda")
+    nwb = ops.slice_wgrad_blocks(H, H)
+    wpart = torch.full((N * nwb * nw,), float("nan"), device="cuda")          # every entry must be written
     ops.slice_bwd(dcols, img, conv, mnmx, cnt, dconv, ab_part, gmm, wpart, D, ps, std3)
     got = torch.empty(nw, device="cuda")
-    ops.reduce_partials(wpart, N * nblk, nw, got)
+    ops.reduce_partials(wpart, N * nwb, nw, got)
     check(got[:nw - 3].reshape(3, D, 5, 5), wd.grad, 2e-4, "slice conv dW")
     check(got[nw - 3:], bd.grad, 2e-4, "slice conv dbias")
 
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
-def test_embed_lnpre_bwd(ops, dt):
-    B, P, width = 3, 16, 128
+@pytest.mark.parametrize("B,P,width", [(3, 16, 128), (2, 196, 768), (2, 9, 1024), (2, 9, 1536)])
+def test_embed_lnpre_bwd(ops, dt, B, P, width):
     patch = rnd(B * P, width, dt=dt, seed=41)
     cls, pos = rnd(width, dt=dt, scale=0.1, seed=42), rnd(P + 1, width, dt=dt, scale=0.1, seed=43)
     gamma, beta = 1 + 0.1 * rnd(width, seed=44), 0.1 * rnd(width, seed=45)
