@@ -270,6 +270,21 @@ class _Stack:
 class FairLoRAEngine:
     """HIP execution engine for CustomCLIP(+FairLoRA) training and inference."""
 
+    @property
+    def grad_scale(self) -> float:
+        """fp16 mode: factor on dloss/dlogits in front of the backward pass, taken out of the fp32 gradients behind it
+        (FFM_F16_GRAD_SCALE, default 4096; 1.0 in the other storage types)."""
+        return self._grad_scale
+
+    @grad_scale.setter
+    def grad_scale(self, value: float) -> None:
+        value = float(value)
+        if not (value > 0.0) or value != value or value == float("inf"):
+            raise ValueError(f"grad_scale must be a positive finite number, got {value!r}")
+        if value != getattr(self, "_grad_scale", value) and hasattr(self, "step_plans"):
+            self.step_plans.clear()                   # the recorded launches hold the old factor
+        self._grad_scale = value
+
     def __init__(self, cfg: ModelCfg, state_dict: Dict[str, Tensor], dtype=torch.bfloat16, max_images: int = 32,
                  device: str = "cuda:0"):
         if not torch.cuda.is_available():
@@ -327,7 +342,9 @@ class FairLoRAEngine:
         # the incoming gradient) and the factor comes out of the fp32 gradient buffer in front of the SGD step, with the
         # finite flag as the overflow guard.  Unscaled, the 16-bit activation gradients of ViT-B/16 sit in half's
         # subnormals (2.8 % error on the lora_S gradient norms at batch 8; 0.3 % scaled: tests/test_engine_gpu.py).
-        self.grad_scale = float(os.environ.get("FFM_F16_GRAD_SCALE", "4096")) if dtype == torch.float16 else 1.0
+        # (a property: the scale-up is captured in the recorded step plans, the unscale reads the live value - changing it
+        # drops the recorded plans, so that a caller's own loss scaler cannot leave the two apart)
+        self._grad_scale = float(os.environ.get("FFM_F16_GRAD_SCALE", "4096")) if dtype == torch.float16 else 1.0
         self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)

@@ -370,7 +370,11 @@ class GLP_OT_SVLoRA:
     def check_finite(self) -> None:
         if int(self._finite_acc) != 1:
             self._finite_acc.fill_(1)
-            raise FloatingPointError("Loss is infinite or NaN!")      # Dassl/dassl/engine/trainer.py:260-262
+            hint = ""
+            if getattr(self.engine, "grad_scale", 1.0) != 1.0:       # fp16: the static gradient scale may have overflowed
+                hint = (f" (PREC fp16: gradients are scaled by {self.engine.grad_scale:g} - FFM_F16_GRAD_SCALE or "
+                        "engine.grad_scale lowers it)")
+            raise FloatingPointError("Loss is infinite or NaN!" + hint)   # Dassl/dassl/engine/trainer.py:260-262
 
     def train(self, idx=-1, global_epoch=0, is_fed=False, is_last_client=False, **_):
         self.time_start = time.time()

@@ -278,3 +278,27 @@ def test_fp16_gradient_scale_and_overflow_guard():
     fbad, gbad = run(2.0 ** 40)
     assert fbad == 0, "an overflowing gradient scale must clear the finite flag"
     assert not all(bool(torch.isfinite(g).all()) for g in gbad.values())
+
+
+def test_fp16_gradient_scale_changed_after_the_plan_was_recorded():
+    """The scale-up sits inside the recorded launch plan, the unscale reads the live value: assigning engine.grad_scale after
+    the first step (what any dynamic loss scaler does) drops the recorded plans, so the two can never be apart - the
+    gradients after the change equal those of an engine that ran on the new scale from the start."""
+    from fairfedmed_amd.engine import FairLoRAEngine
+    mcfg = C.vit_tiny(rank=4)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    batch = synth.make_batch(mcfg, 8, seed=1234)
+    img, attr, label = batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
+    a = FairLoRAEngine(mcfg, sd, dtype=torch.float16, max_images=8)
+    a.forward_backward(img, attr, label)                    # records the plan on the default 4096
+    assert a.step_plans
+    a.grad_scale = 256.0
+    assert not a.step_plans
+    a.forward_backward(img, attr, label)
+    b = FairLoRAEngine(mcfg, sd, dtype=torch.float16, max_images=8)
+    b.grad_scale = 256.0
+    b.forward_backward(img, attr, label)
+    torch.cuda.synchronize()
+    assert torch.equal(a.params.grad, b.params.grad)
+    with pytest.raises(ValueError):
+        a.grad_scale = 0.0

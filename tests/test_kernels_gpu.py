@@ -996,6 +996,48 @@ def test_attention3_lengths(ops, dt, L):
     check(dqkv[:, 2 * E:], qd.grad[:, 2 * E:], 2 * t16, "dv")
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")], ids=["nan", "inf"])
+def test_attention3_propagates_non_finite_inputs(ops, dt, bad):
+    """attention3.hip is compiled with -fno-honor-nans (the row maxima), and the step's only divergence guard is the finite
+    flag ce_loss raises from the logits: a NaN / Inf in q, k or v must therefore come out of the attention output (and a
+    NaN / Inf in dO out of dq, dk, dv) and not be folded away by a max / select the compiler assumed NaN-free."""
+    B, heads, L = 2, 3, 197
+    E = heads * 64
+    b, h = 1, 2                                                   # the (batch, head) pair that is poisoned
+    rows = slice(b * L, (b + 1) * L)
+    for which, row in (("q", 5), ("k", 100), ("v", 196)):
+        qkv = rnd(B * L, 3 * E, dt=dt, seed=250)
+        col = {"q": 0, "k": E, "v": 2 * E}[which] + h * 64 + 7
+        qkv[b * L + row, col] = bad
+        out = torch.zeros(B * L, E, device="cuda", dtype=dt)
+        lse = torch.zeros(B, heads, L, device="cuda")
+        ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+        o = out[rows, h * 64:(h + 1) * 64].float()
+        hit = ~torch.isfinite(o).all(dim=1)
+        if which == "q":
+            assert bool(hit[row]), (which, "the poisoned query's output row is finite")
+        else:
+            assert bool(hit.all()), (which, int(hit.sum()), "every query of the pair sees the poisoned key / value")
+        # everything outside the pair stays finite
+        out[rows, h * 64:(h + 1) * 64] = 0
+        assert bool(torch.isfinite(out.float()).all())
+    qkv = rnd(B * L, 3 * E, dt=dt, seed=251)
+    out = torch.zeros(B * L, E, device="cuda", dtype=dt)
+    lse = torch.zeros(B, heads, L, device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+    dout = rnd(B * L, E, dt=dt, seed=252)
+    dout[b * L + 11, h * 64 + 3] = bad
+    dqkv = torch.zeros(B * L, 3 * E, device="cuda", dtype=dt)
+    delta = torch.zeros(B, heads, L, device="cuda")
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, False)
+    dq = dqkv[rows, h * 64:(h + 1) * 64].float()
+    dk = dqkv[rows, E + h * 64:E + (h + 1) * 64].float()
+    dv = dqkv[rows, 2 * E + h * 64:2 * E + (h + 1) * 64].float()
+    assert not bool(torch.isfinite(dq[11]).all()), "dq of the poisoned row"
+    assert not bool(torch.isfinite(dk).all()) and not bool(torch.isfinite(dv).all()), "dk / dv of the pair"
+
+
 @pytest.mark.parametrize("L", [197, 130])
 def test_attention3_running_maximum_and_rows(ops, L):
     """The second DMA half can raise a row's maximum (the rescale path): one key of the second half is made to dominate
