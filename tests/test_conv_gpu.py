@@ -89,7 +89,15 @@ def test_stem_im2col(ops, dt):
 @pytest.mark.parametrize("dt", DT, ids=IDS)
 @pytest.mark.parametrize("rows,C,relu,with_res", [(2 * 16 * 16, 64, True, False), (1000, 256, False, False), (3 * 49, 2048, True, True),
                                                    (6272, 256, True, True), (7168, 128, True, False), (7169, 64, True, True),
-                                                   (12000, 256, False, False)])
+                                                   (12000, 256, False, False),
+                                                   # round 5: maps of up to 32 768 rows take the folded path (no finalize launch);
+                                                   # the rows below pin both sides of its selection rule (csrc/conv.hip: bn_fold_geom)
+                                                   (40000, 64, True, True),        # large map: colsum + finalize (4-channel blocks) + apply
+                                                   (25088, 128, True, False),      # mid-sized, few strips: stays on the three launches
+                                                   (25088, 512, True, True),       # mid-sized, 8 strips x 64 row groups: folded
+                                                   (1568, 2048, True, True),       # layer4: 32 strips
+                                                   (300, 24, False, False),        # a strip narrower than 64 channels, C % 16 != 0
+                                                   (520, 200, True, False)])       # last strip ragged (200 = 3 x 64 + 8)
 def test_batchnorm_train_forward_backward_and_eval(ops, dt, rows, C, relu, with_res):
     x = rnd(rows, C, dt=dt, seed=7) * 1.5 + 0.3
     gamma, beta = 1 + 0.1 * rnd(C, seed=8), 0.1 * rnd(C, seed=9)
@@ -207,7 +215,9 @@ def test_implicit_gemm_conv3x3_forward_and_input_gradient(ops, dt, B, H, W, C, C
 
 
 @pytest.mark.parametrize("dt", DT, ids=IDS)
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (128 * 7, 64, 256), (3 * 49, 2048, 512), (5000, 192, 128)])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (128 * 7, 64, 256), (3 * 49, 2048, 512), (5000, 192, 128),
+                                   (6272, 1024, 64),      # folded, 49 producer tiles x 16 strips
+                                   (40000, 64, 64)])      # 313 producer tiles: the finalize launch (4-channel blocks)
 def test_gemm_column_sums_feed_batchnorm(ops, dt, M, N, K):
     """ffm_gemm_args.colstat_part: the 128x128 kernel leaves sum / sum of squares of each row tile's STORED columns
     (ragged last tile included); ffm_bn_fwd(part_rows) on them gives the result of its own pass over the tensor."""
