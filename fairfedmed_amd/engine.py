@@ -421,7 +421,8 @@ class FairLoRAEngine:
         cfg, v, dtype, dev = self.cfg, self.cfg.vision, self.dtype, self.device
         # FairLoRA down projections ride inside the GEMMs (FFM_EPI_RANKOP) when the rank fits one MFMA tile
         self.fused_rank = 0 < cfg.lora.rank <= 16
-        self.red_at = int(os.environ.get("FFM_RED_AT", "0"))       # where a block's LoRA-gradient reductions start (_stack_backward)
+        # where a block's LoRA-gradient reductions start (_stack_backward); unset: by row count
+        self.red_at = int(os.environ["FFM_RED_AT"]) if "FFM_RED_AT" in os.environ else None
         self.use_lgrad = os.environ.get("FFM_LGRAD", "1") != "0"    # the two large reductions inside the dX product of c_proj
         ie = "image_encoder.transformer.resblocks."
         self.sops = SOperands(self.params, [f"{ie}{i}.mlp.c_{n}." for i in range(v.layers) for n in ("fc", "proj")],
@@ -744,7 +745,11 @@ class FairLoRAEngine:
                 # block's dX(c_fc) - beside its LayerNorm / out-proj / attention backward; 1: behind its attention backward;
                 # 2: behind the whole block - beside the NEXT block's two FairLoRA products, whose main loops live on
                 # LDS / L2 operands (the last block's have nothing behind them and always start at once)
-                red_at = 0 if last or i == 0 else self.red_at
+                # Measured (one call, alternating): configs[1] (6304 rows) 4.65-4.71 / 4.66-4.67 / 4.75-4.76 ms per step for
+                # 0 / 1 / 2; configs[3] (19 700 rows, rank 16: 52 MB of partials per block, whose sum took the attention
+                # backward beside it from 49 to 74 us) 12.45 / 12.42-12.46 / 12.37-12.38.
+                auto = 2 if rows > 12608 else 0
+                red_at = 0 if last or i == 0 else (auto if self.red_at is None else self.red_at)
                 if red_at == 0:
                     reductions()
                 if last:
