@@ -18,8 +18,8 @@ LIB_PATH = os.environ.get("FFM_LIB_PATH") or os.path.join(_HERE, "csrc", "libffm
 F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the reference's PREC="fp16")
 F32_X3_W16 = 4                           # FFM_F32_X3 with the weight operand stored as IEEE half
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
-EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD = 128, 256, 512
-ABI_VERSION = 10
+EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD, EPI_BNBWD = 128, 256, 512, 1024
+ABI_VERSION = 11
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("gelu_deriv", _i32),
         ("ln_rk", _vp), ("colstat_part", _vp),
         ("lg_v", _vp), ("lg_part_c", _vp), ("lg_part_a", _vp),
+        ("bn_x", _vp), ("bn_mask", _vp), ("bn_mean", _vp), ("bn_rstd", _vp),
     ]
 
 
@@ -78,12 +79,13 @@ SIGNATURES = {
     "ffm_col2im3x3": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_bn_blocks": [_i32],
     "ffm_bn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "ffm_bn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "ffm_avgpool2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_add": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_relu_bwd": [_vp, _vp, _vp, C.c_int64, _i32, _vp],
     "ffm_attnpool_tokens": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_conv3x3_nhwc": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp],
+    "ffm_conv3x3_nhwc_bnbwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "ffm_conv3x3_colstat_rows": [_i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32],
     "ffm_eval_counts": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "ffm_eval_counts_ws_bytes": [_i32],

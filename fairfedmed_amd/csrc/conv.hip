@@ -764,33 +764,42 @@ extern "C" int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, 
 }
 
 extern "C" int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
-                          const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, void* g_out,
-                          int rows, int C, int dtype, void* stream) {
+                          const float* rstd, float* part, int part_rows, float* k12, float* dgamma, float* dbeta, void* dx,
+                          void* g_out, int rows, int C, int dtype, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !part || !k12 || !dgamma || !dbeta || !dx || rows <= 0 || C <= 0)
         return FFM_EINVAL;
     if (C % (dtype == FFM_BF16 ? 8 : 4) || ((uintptr_t)part & 15)) return FFM_EINVAL;
+    if (part_rows < 0 || part_rows > 4096 || (part_rows > 0 && g_out)) return FFM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const bn_fold fold = bn_fold_geom(rows, C, dtype == FFM_BF16 ? 8 : 4, 0);
+    const bn_fold fold = bn_fold_geom(rows, C, dtype == FFM_BF16 ? 8 : 4, part_rows);
     if (fold.on) {                                   // small map: column sums on strips, no finalize launch
         if (((uintptr_t)part & 15) || C % 4) return FFM_EINVAL;
         const int gy = (C / (dtype == FFM_BF16 ? 8 : 4) + fold.strip - 1) / fold.strip;
-        const int rpb = (rows + fold.G - 1) / fold.G, nb = (rows + rpb - 1) / rpb;
-        DISPATCH_T(dtype,
-                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), dim3(nb, gy), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out, fold.strip),
-                   hipLaunchKernelGGL((colsum_kernel<float, 1>), dim3(nb, gy), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out, fold.strip))
-        FFM_CHECK_LAUNCH();
+        const int rpb = (rows + fold.G - 1) / fold.G;
+        int nb = part_rows;                              // (> 0: the producer of dy left the column sums of its row tiles)
+        if (part_rows <= 0) {
+            nb = (rows + rpb - 1) / rpb;
+            DISPATCH_T(dtype,
+                       hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), dim3(nb, gy), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out, fold.strip),
+                       hipLaunchKernelGGL((colsum_kernel<float, 1>), dim3(nb, gy), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out, fold.strip))
+            FFM_CHECK_LAUNCH();
+        }
         DISPATCH_T(dtype,
                    hipLaunchKernelGGL((bn_bwd_apply_fold_kernel<bf16_t>), dim3(fold.G, gy), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)relu_out, (const bf16_t*)x, part, nb, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, rows, C, fold.strip),
                    hipLaunchKernelGGL((bn_bwd_apply_fold_kernel<float>), dim3(fold.G, gy), dim3(256), 0, s, (const float*)dy, (const float*)relu_out, (const float*)x, part, nb, mean, rstd, gamma, dgamma, dbeta, (float*)dx, rows, C, fold.strip))
         FFM_CHECK_LAUNCH();
         return FFM_OK;
     }
-    const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0, nblk = (rows + rpb - 1) / rpb;
-    dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out),
-               hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out))
-    FFM_CHECK_LAUNCH();
+    const int nb0 = cs_blocks(rows), rpb = (rows + nb0 - 1) / nb0;
+    int nblk = part_rows;
+    if (part_rows <= 0) {
+        nblk = (rows + rpb - 1) / rpb;
+        dim3 g(nblk, (C / (dtype == FFM_BF16 ? 8 : 4) + 255) / 256);
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((colsum_kernel<bf16_t, 1>), g, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)relu_out, mean, rstd, part, rows, C, rpb, (bf16_t*)g_out),
+                   hipLaunchKernelGGL((colsum_kernel<float, 1>), g, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)relu_out, mean, rstd, part, rows, C, rpb, (float*)g_out))
+        FFM_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + fin_sw_host(nblk) - 1) / fin_sw_host(nblk)), dim3(256), 0, s, part, nblk, rows, C, dgamma, dbeta, k12);
     FFM_CHECK_LAUNCH();
     const dim3 g2 = bn_apply_grid(rows, C, dtype == FFM_BF16 ? 8 : 4);

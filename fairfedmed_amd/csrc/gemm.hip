@@ -552,9 +552,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     const int erow0 = tid >> 4;                       // rows erow0 + 16*i
     // colstat_part: column sums of the stored tile (the BatchNorm statistics of RN50's convolutions)
     const bool cst = p.colstat_part != nullptr;
-    float cs[8], cq[8];
+    // FFM_EPI_BNBWD only in the kernels instantiated with the bit (a run-time branch cost every kernel of this file ~60
+    // registers: 134 -> 193 in the plain one)
+    constexpr bool BNB = FL > 0 && (FL & FFM_EPI_BNBWD) != 0;
+    const bool bnb = BNB && cst && p.bn_x != nullptr;
+    float cs[8], cq[8], bnmu[8], bnrs[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) cs[c] = cq[c] = 0.f;
+    for (int c = 0; c < 8; ++c) cs[c] = cq[c] = bnmu[c] = bnrs[c] = 0.f;
+    if (bnb && n0 + ecol < p.N) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { bnmu[c] = p.bn_mean[n0 + ecol + c]; bnrs[c] = p.bn_rstd[n0 + ecol + c]; }
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         // this half's residual / pre-activation rows: issue the global loads now, consume after the barrier
@@ -577,6 +585,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.res) + off) + c) : "memory");
                     if (flags & FFM_EPI_DGELU)
                         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raux[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.aux) + off) + c) : "memory");
+                }
+            }
+        }
+        // FFM_EPI_BNBWD: the BatchNorm's input and ReLU-output rows of this half, the same way
+        typename Elem<T>::chunk_t rbx[BNB ? 4 : 1][NCH], rbm[BNB ? 4 : 1][NCH];
+        if constexpr (BNB) if (bnb) {
+            const int gnc = gn < p.N ? gn : (p.N >= 8 ? p.N - 8 : 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gm0 = m0 + half * 64 + erow0 + 16 * i;
+                const size_t off = (size_t)(gm0 < p.M ? gm0 : p.M - 1) * p.ldc + gnc;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rbx[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.bn_x) + off) + c) : "memory");
+                    if (p.bn_mask)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rbm[i][c]) : "v"(reinterpret_cast<const typename Elem<T>::chunk_t*>(reinterpret_cast<const T*>(p.bn_mask) + off) + c) : "memory");
                 }
             }
         }
@@ -621,6 +645,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 for (int c = 0; c < NCH; ++c) {
                     if (flags & FFM_EPI_RESIDUAL) asm volatile("" : "+v"(rres[i][c]));
                     if (flags & FFM_EPI_DGELU) asm volatile("" : "+v"(raux[i][c]));
+                }
+        }
+        if constexpr (BNB) if (bnb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    asm volatile("" : "+v"(rbx[i][c]));
+                    if (p.bn_mask) asm volatile("" : "+v"(rbm[i][c]));
                 }
         }
         if (gn < p.N) {
@@ -692,7 +726,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 } else {
                     Vec8<T>::store(C + off, v[i]);
                 }
-                if (cst) {
+                if (BNB && cst && bnb) {
+                    // {sum g, sum g xhat}, g = stored value * (ReLU output > 0): ffm_bn_bwd's column sums (colsum_kernel MODE 1)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float g = Elem<T>::to_f(Elem<T>::from_f(v[i][c]));
+                        if (p.bn_mask && !(Elem<T>::to_f(rbm[BNB ? i : 0][c / EPC][c % EPC]) > 0.f)) g = 0.f;
+                        cs[c] += g;
+                        cq[c] += g * (Elem<T>::to_f(rbx[BNB ? i : 0][c / EPC][c % EPC]) - bnmu[c]) * bnrs[c];
+                    }
+                } else if (cst) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const float st = Elem<T>::to_f(Elem<T>::from_f(v[i][c]));
@@ -829,6 +872,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_RESIDUAL) && (!a.res || ((uintptr_t)a.res & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_GELU) && (!a.c2 || ((uintptr_t)a.c2 & 15))) return FFM_EINVAL;
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
+    if (a.flags & FFM_EPI_BNBWD) {                                        // BatchNorm-backward column sums: 128x128 kernel
+        if (!a.colstat_part || !a.bn_x || !a.bn_mean || !a.bn_rstd || (a.flags & FFM_EPI_GELU)) return FFM_EINVAL;
+        if (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mask) & 15) return FFM_EINVAL;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (ffm_skinny_ok(a, dtype) && !a.colstat_part) {                    // (column sums: the 128x128 kernel's epilogue)
         static const bool off = getenv("FFM_SKINNY") && getenv("FFM_SKINNY")[0] == 'o';      // FFM_SKINNY=off: A/B runs
@@ -851,6 +898,9 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         if (cfg >= 0) return ffm_panel_launch(a, cfg, s);
     }
     const int fl = a.flags & ~FFM_EPI_RANKOP;
+    // BatchNorm-backward column sums exist in the kernels instantiated with the bit only (cases below; rank <= 16)
+    if ((fl & FFM_EPI_BNBWD) && !(rk && fl == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_BNBWD)) && fl != FFM_EPI_BNBWD) return FFM_EUNSUP;
+    if ((fl & FFM_EPI_BNBWD) && (fl & FFM_EPI_LORA) && a.rank > 16) return FFM_EUNSUP;
     if ((fl & FFM_EPI_LORA) && a.rank > 16) {                             // rank-r update on the VALU: generic-flag kernels
         if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1, false, true>(a, s) : launch_gemm<float, true, -1, false, true>(a, s);
         return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1, false, true>(a, s) : launch_gemm<float, false, -1, false, true>(a, s);
@@ -866,6 +916,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
             FFM_GEMM_CASE(true, FFM_EPI_LORA)                                                      // RN50 conv1 / conv3 (no bias)
             FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA)                                       // RN50 attention-pool projections
             FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_RESIDUAL)                 // RN50 dX of conv1 + identity path
+            FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_BNBWD)                    // RN50 dX of conv3 + bn2's backward sums
             default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1>(a, s) : launch_gemm<float, true, -1>(a, s);
         }
     }
@@ -880,6 +931,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         FFM_GEMM_CASE(false, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL)
         FFM_GEMM_CASE(false, FFM_EPI_LORA | FFM_EPI_LORA_KR)
         FFM_GEMM_CASE(false, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)
+        FFM_GEMM_CASE(false, FFM_EPI_BNBWD)                                                      // a plain dX product + the sums
         default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1>(a, s) : launch_gemm<float, false, -1>(a, s);
     }
 #undef FFM_GEMM_CASE
@@ -905,7 +957,7 @@ namespace {
 // A through the implicit-im2col loader above, the whole weight K-tile (NB rows x 128 B) beside it, two LDS buffers,
 // three blocks per CU.  Epilogue: plain store through LDS (8-element row segments) + optional column sums of the STORED
 // values (colstat_part, as the 128x128 kernel writes them) taken straight from the accumulators.
-template <typename T, int NB>
+template <typename T, int NB, bool BNB = false>
 __global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
     const ffm_gemm_args& p = px.g;
     typedef typename Mma16<T>::frag_t frag_t;
@@ -987,7 +1039,7 @@ __global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 Cs[(wave * 32 + i * 16 + fgrp * 4 + e) * CLD + j * 16 + frow] = acc[i][j][e];
-    if (p.colstat_part) {
+    if (!BNB && p.colstat_part) {
         // lane (frow, fgrp) holds column j*16 + frow of rows fgrp*4 + e: its 8 rows, then the 4 row groups of the wave
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -1016,6 +1068,15 @@ __global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
         constexpr int RPP = 256 / CPR;                // rows per pass
         T* C = reinterpret_cast<T*>(p.c);
         const int cseg = tid % CPR, r0 = tid / CPR;
+        // FFM_EPI_BNBWD (BNB instantiations): {sum g, sum g xhat} of the stored rows, g = value x (ReLU output > 0), from the
+        // row segments as they leave (the BatchNorm's input / output rows are read as 16-byte segments beside them)
+        float cs[VN], cq[VN], bmu[VN], brs[VN];
+#pragma unroll
+        for (int c = 0; c < VN; ++c) cs[c] = cq[c] = bmu[c] = brs[c] = 0.f;
+        if constexpr (BNB) {
+#pragma unroll
+            for (int c = 0; c < VN; ++c) { bmu[c] = p.bn_mean[n0 + cseg * VN + c]; brs[c] = p.bn_rstd[n0 + cseg * VN + c]; }
+        }
 #pragma unroll
         for (int ps = 0; ps < BM / RPP; ++ps) {
             const int row = ps * RPP + r0;
@@ -1023,11 +1084,40 @@ __global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
                 float v[VN];
 #pragma unroll
                 for (int c = 0; c < VN; ++c) v[c] = Cs[row * CLD + cseg * VN + c];
-                Vec8<T>::store(C + (size_t)(m0 + row) * p.ldc + n0 + cseg * VN, v);
+                const size_t off = (size_t)(m0 + row) * p.ldc + n0 + cseg * VN;
+                Vec8<T>::store(C + off, v);
+                if constexpr (BNB) {
+                    float xv[VN], mv[VN];
+                    Vec8<T>::load(reinterpret_cast<const T*>(p.bn_x) + off, xv);
+                    if (p.bn_mask) Vec8<T>::load(reinterpret_cast<const T*>(p.bn_mask) + off, mv);
+#pragma unroll
+                    for (int c = 0; c < VN; ++c) {
+                        float g = Elem<T>::to_f(Elem<T>::from_f(v[c]));
+                        if (p.bn_mask && !(mv[c] > 0.f)) g = 0.f;
+                        cs[c] += g;
+                        cq[c] += g * (xv[c] - bmu[c]) * brs[c];
+                    }
+                }
+            }
+        }
+        if constexpr (BNB) {
+            // the RPP row lanes of a column segment meet in LDS (the C stage is read by now: barrier first) and are added
+            // in a fixed order
+            __syncthreads();
+            float* R0 = Cs;                           // [RPP][NB] x 2
+            float* R1 = Cs + RPP * NB;
+#pragma unroll
+            for (int c = 0; c < VN; ++c) { R0[r0 * NB + cseg * VN + c] = cs[c]; R1[r0 * NB + cseg * VN + c] = cq[c]; }
+            __syncthreads();
+            if (tid < NB) {
+                float s0 = 0.f, s1 = 0.f;
+                for (int l = 0; l < RPP; ++l) { s0 += R0[l * NB + tid]; s1 += R1[l * NB + tid]; }
+                p.colstat_part[((size_t)tm * 2) * p.N + n0 + tid] = s0;
+                p.colstat_part[((size_t)tm * 2 + 1) * p.N + n0 + tid] = s1;
             }
         }
     }
-    if (p.colstat_part && tid < NB) {
+    if (!BNB && p.colstat_part && tid < NB) {
         const float s0 = (Red[tid] + Red[NB + tid]) + (Red[2 * NB + tid] + Red[3 * NB + tid]);
         const float s1 = (Red[4 * NB + tid] + Red[5 * NB + tid]) + (Red[6 * NB + tid] + Red[7 * NB + tid]);
         p.colstat_part[((size_t)tm * 2) * p.N + n0 + tid] = s0;
@@ -1035,11 +1125,11 @@ __global__ __launch_bounds__(256, 3) void conv_narrow_kernel(gemm_kargs px) {
     }
 }
 
-template <typename T, int NB>
+template <typename T, int NB, bool BNB = false>
 int launch_conv_narrow(const gemm_kargs& ka, hipStream_t s) {
     constexpr int ring = 2 * (TILE_BYTES + NB * KT_BYTES), epi = BM * (NB + 4) * 4 + 8 * NB * 4;
     const int tiles = (ka.g.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_narrow_kernel<T, NB>), dim3(tiles, ka.g.N / NB), dim3(256), ring > epi ? ring : epi, s, ka);
+    hipLaunchKernelGGL((conv_narrow_kernel<T, NB, BNB>), dim3(tiles, ka.g.N / NB), dim3(256), ring > epi ? ring : epi, s, ka);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -1064,9 +1154,31 @@ extern "C" int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int K
     return conv_ksplit(M, N, Kp, dtype == FFM_BF16 ? 2 : 4, scratch_elems > 0, scratch_elems) > 1 ? 0 : (M + BM - 1) / BM;
 }
 
+static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp, const void* zeros,
+                        float* splitk_scratch, int64_t scratch_elems, float* colstat_part, const void* bn_x,
+                        const void* bn_mask, const float* bn_mean, const float* bn_rstd, int dtype, void* stream);
+
 extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
                                 const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part,
                                 int dtype, void* stream) {
+    return conv3x3_impl(x, w, y, B, H, W, C, N, Kp, zeros, splitk_scratch, scratch_elems, colstat_part, nullptr, nullptr, nullptr,
+                        nullptr, dtype, stream);
+}
+
+extern "C" int ffm_conv3x3_nhwc_bnbwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
+                                      const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part,
+                                      const void* bn_x, const void* bn_mask, const float* bn_mean, const float* bn_rstd,
+                                      int dtype, void* stream) {
+    if (!colstat_part || !bn_x || !bn_mean || !bn_rstd || (((uintptr_t)bn_x | (uintptr_t)bn_mask) & 15)) return FFM_EINVAL;
+    // (the column sums exist in the launches that are not split over K: ask ffm_conv3x3_colstat_rows first)
+    if (conv_ksplit(B * H * W, N, Kp, dtype == FFM_BF16 ? 2 : 4, splitk_scratch != nullptr, scratch_elems) > 1) return FFM_EUNSUP;
+    return conv3x3_impl(x, w, y, B, H, W, C, N, Kp, zeros, splitk_scratch, scratch_elems, colstat_part, bn_x, bn_mask, bn_mean,
+                        bn_rstd, dtype, stream);
+}
+
+static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp, const void* zeros,
+                        float* splitk_scratch, int64_t scratch_elems, float* colstat_part, const void* bn_x,
+                        const void* bn_mask, const float* bn_mean, const float* bn_rstd, int dtype, void* stream) {
     if (!x || !w || !y || !zeros || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return FFM_EINVAL;
     if (dtype != FFM_BF16 && dtype != FFM_F32) return FFM_EINVAL;
     const size_t es = dtype == FFM_BF16 ? 2 : 4;
@@ -1087,6 +1199,8 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
     const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems);
     if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
     a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: no epilogue, no statistics)
+    const bool bnb = bn_x != nullptr;                              // FFM_EPI_BNBWD: S == 1 (checked by the entry point)
+    if (bnb) { a.flags = FFM_EPI_BNBWD; a.bn_x = bn_x; a.bn_mask = bn_mask; a.bn_mean = bn_mean; a.bn_rstd = bn_rstd; }
     // The stem and layer1 (N = 32 / 64): 128 x N tiles, three blocks per CU (81 -> 33 / 43 us at 112 x 112, 40 -> 25 us at
     // 56 x 56).  FFM_CONV_NARROW=off: the 128x128 kernel (A/B runs); FFM_CONV_NARROW=<t>: also N = 128 / 256 / ... as 64-wide
     // column tiles when the launch has fewer than t 128x128 tiles (measured at t = 512 / 1000 on RN50 bs 32: no gain)
@@ -1094,9 +1208,14 @@ extern "C" int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, in
     static const char* nenv = getenv("FFM_CONV_NARROW");
     static const int narrow_max = nenv ? (nenv[0] == 'o' ? -1 : atoi(nenv)) : 0;
     if (S == 1 && narrow_max >= 0 && (a.N == 32 || a.N == 64 || (a.N % 64 == 0 && t128 < narrow_max))) {
+        if (bnb) {
+            if (a.N == 32) return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 32, true>(ka, s) : launch_conv_narrow<float, 32, true>(ka, s);
+            return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 64, true>(ka, s) : launch_conv_narrow<float, 64, true>(ka, s);
+        }
         if (a.N == 32) return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 32>(ka, s) : launch_conv_narrow<float, 32>(ka, s);
         return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 64>(ka, s) : launch_conv_narrow<float, 64>(ka, s);
     }
+    if (bnb) return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true>(a, s, &ka) : launch_gemm<float, false, FFM_EPI_BNBWD, true>(a, s, &ka);
     const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
     if (e || ka.ksplit <= 1) return e;
     const size_t total = (size_t)a.M * a.N, total4 = total / 4;

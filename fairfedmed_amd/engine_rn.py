@@ -14,6 +14,8 @@ flat parameter buffer, SGD, streams and launch-plan replay are the base class's.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -78,9 +80,10 @@ class _Lora:
         ops.gemm_nt(x, W, out, bias=bias, ts=self.ts[:rows], lw=e.params.view(self.kB), res=res, colstats=colstats)
 
     def bwd(self, g: Tensor, Wt: Tensor, dx: Tensor, x: Tensor, attr: Optional[Tensor], rps: int, res=None,
-            defer: bool = False) -> None:
+            defer: bool = False, bnbwd=None, colstats: Optional[Tensor] = None) -> None:
         """g = dL/dy; writes dx = g W (+ LoRA term) (+ res) and the partial sums of dA, dB, dS (defer: the caller runs
-        grads() itself, on the gradient stream)."""
+        grads() itself, on the gradient stream).  bnbwd / colstats (fused sites only): dx is the gradient of a BatchNorm
+        output, and the product's epilogue leaves that BatchNorm's backward column sums in colstats (ops.gemm_nt)."""
         e, lo = self.eng, self.eng.cfg.lora
         rows = g.shape[0]
         S, G = self._s()
@@ -88,8 +91,10 @@ class _Lora:
         if self.fused:
             ro = ops.RankOp(self.rkB, S, attr, rps, lo.scaling, lo.lambda_group, ts_out=self.us[:rows],
                             t_fwd=self.t[:rows] if self.fair else None, ds_part=self.pS)
-            ops.gemm_nt(g, Wt, dx, lw=e.params.view(self.kA), lw_is_kr=True, res=res, rankop=ro)
+            ops.gemm_nt(g, Wt, dx, lw=e.params.view(self.kA), lw_is_kr=True, res=res, rankop=ro, bnbwd=bnbwd,
+                        colstats=colstats)
         else:
+            assert bnbwd is None
             ops.lora_down(g, e.params.view(self.kB), True, S, attr, lo.rank, G, rps, lo.scaling,
                           lo.lambda_group, self.u[:rows], self.us[:rows], self.t[:rows] if self.fair else None, self.pS)
             ops.gemm_nt(g, Wt, dx, ts=self.us[:rows], lw=e.params.view(self.kA), lw_is_kr=True, res=res)
@@ -135,11 +140,14 @@ class _BN:
                    self.run_var, self.mean, self.rstd, part if part_rows else (e.bn_part_d if self.aux else e.bn_part), y,
                    e.bn_training, relu, res, part_rows=part_rows)
 
-    def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor, g_out: Optional[Tensor] = None) -> None:
+    def bwd(self, dy: Tensor, relu_out: Optional[Tensor], x: Tensor, dx: Tensor, g_out: Optional[Tensor] = None,
+            part: Optional[Tensor] = None, part_rows: int = 0) -> None:
+        """part / part_rows: the backward column sums the GEMM that produced dy left behind (FFM_EPI_BNBWD); else own pass."""
         e = self.eng
         ops.bn_bwd(dy, relu_out, x, e.params.view(self.prefix + "weight"), self.mean, self.rstd,
-                   e.bn_part_d if self.aux else e.bn_part, e.bn_k12_d if self.aux else e.bn_k12,
-                   e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx, g_out)
+                   part if part_rows else (e.bn_part_d if self.aux else e.bn_part), e.bn_k12_d if self.aux else e.bn_k12,
+                   e.params.view(self.prefix + "weight", "grad"), e.params.view(self.prefix + "bias", "grad"), dx, g_out,
+                   part_rows=part_rows)
 
 
 class _Bneck:
@@ -261,14 +269,25 @@ class _Bneck:
             gid = self.gid[:ro]
         a = self.a2p[:ro] if self.stride > 1 else self.a2[:ri]
         side = getattr(e, "grads_on_side", True)
-        self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho, defer=side)
+        # stride 1: conv3's dX product writes the gradient of relu(bn2(.)) itself - its epilogue leaves bn2's backward column
+        # sums of its row tiles behind (FFM_EPI_BNBWD), and bn2's backward skips its pass over dy / x / mask (13 of RN50's 16
+        # blocks; FFM_BN_BWD_FUSED=0: A/B runs)
+        t2 = e.stat_rows(ri) if (self.stride == 1 and self.c3.fused and getattr(e, "bn_bwd_fused", True)) else 0
+        self.c3.bwd(self.dz3[:ro], W[p + "w3t"], self.da2p[:ro], a, attr, Ho * Ho, defer=side,
+                    bnbwd=(self.z2[:ri], self.a2[:ri], self.bn2.mean, self.bn2.rstd) if t2 else None,
+                    colstats=e.stat_buf[0] if t2 else None)
         da2 = self.da2p[:ro]
         if self.stride > 1:
             da2 = self.da2[:ri]
             ops.avgpool2(self.da2p[:ro], da2, images, Hi, Hi, backward=True)
-        self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri])
-        ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk)   # dX = conv3x3(dY; w')
-        self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri])
+        self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri], part=e.stat_buf[0], part_rows=t2)
+        # dX = conv3x3(dY; w') is the gradient of relu(bn1(.)): the same for bn1 where the convolution is not split over K
+        # (layer1 / layer2; conv3x3 returns the partial rows it wrote, 0 for the split launches of layer3 / layer4)
+        fuse1 = e.stat_rows(ri) > 0 and getattr(e, "bn_bwd_fused", True)
+        t1 = ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk,
+                         colstats=e.stat_buf[0] if fuse1 else None,
+                         bnbwd=(self.z1[:ri], self.a1[:ri], self.bn1.mean, self.bn1.rstd) if fuse1 else None)
+        self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri], part=e.stat_buf[0], part_rows=t1 if fuse1 else 0)
         if fork:
             e._ev_wait(main, self.ev_d[3])                        # join: the downsample branch's input gradient
         self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid, defer=side)
@@ -322,6 +341,7 @@ class RN50Engine(FairLoRAEngine):
         self.rnw: Dict[str, Tensor] = {}
         self.bns: List[_BN] = []
         self.bn_scratch = self.bn_cmax = self.stat_scratch = 0
+        self.bn_bwd_fused = os.environ.get("FFM_BN_BWD_FUSED", "1") != "0"      # _Bneck.backward: bn2's sums from conv3's dX product
         self.bn_training = False
         self.pack_entries: list = []
         e = lambda rows, C: torch.zeros(rows, C, device=dev, dtype=dt)

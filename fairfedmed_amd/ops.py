@@ -155,12 +155,15 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
             x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
-            colstats: Optional[Tensor] = None, gelu_deriv: bool = False) -> Tensor:
+            colstats: Optional[Tensor] = None, gelu_deriv: bool = False, bnbwd=None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
     x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores; with
     `b` in float16: FFM_F32_X3_W16, the same on a weight rounded to IEEE half in memory (half the bytes).
     gelu_deriv (with gelu_out / dgelu_aux): `out` receives / `dgelu_aux` holds quick_gelu'(pre) instead of pre
-    (ffm_gemm_args.gelu_deriv)."""
+    (ffm_gemm_args.gelu_deriv).
+    bnbwd = (bn_x, bn_mask or None, mean, rstd) with `colstats`: FFM_EPI_BNBWD - `out` is dL/dy of a train-mode BatchNorm
+    (+ ReLU with output bn_mask) on bn_x, and `colstats` receives the backward's column sums {sum g, sum g xhat} per row tile
+    (bn_bwd's part / part_rows) instead of the forward's {sum, sum of squares}."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
     w16 = x3 and b.dtype == torch.float16            # FFM_F32_X3_W16: float32 activations on a weight stored as IEEE half
     assert a.dtype == out.dtype and (b.dtype == a.dtype or w16) and (not x3 or a.dtype == torch.float32)
@@ -223,10 +226,19 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         assert _f32(lg_v).shape[0] >= M and lg_v.shape[1] == rank
         assert min(_f32(lg_c).numel(), _f32(lg_a).numel()) >= rows * N * rank
         lgx = (L.ptr(lg_v), L.ptr(lg_c), L.ptr(lg_a))
+    bnx = (None, None, None, None)
+    if bnbwd is not None:
+        bn_x, bn_mask, bn_mean, bn_rstd = bnbwd
+        _dev(bn_x, bn_mask, bn_mean, bn_rstd)
+        assert colstats is not None and bn_x.dtype == out.dtype and tuple(bn_x.shape) == (M, N) and _ld(bn_x) == _ld(out)
+        assert bn_mask is None or (bn_mask.dtype == out.dtype and tuple(bn_mask.shape) == (M, N) and _ld(bn_mask) == _ld(out))
+        assert _f32(bn_mean).numel() == N and _f32(bn_rstd).numel() == N
+        flags |= L.EPI_BNBWD
+        bnx = (L.ptr(bn_x), L.ptr(bn_mask), L.ptr(bn_mean), L.ptr(bn_rstd))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,
-                      L.ptr(_f32(colstats)), *lgx)
+                      L.ptr(_f32(colstats)), *lgx, *bnx)
     if colstats is not None:                       # [tiles_m, 2, N] fp32 column sums of the stored output (128x128 kernel)
         _dev(colstats)
         assert b_packed is None and colstats.numel() >= 2 * N * ((M + 127) // 128)
@@ -358,11 +370,14 @@ def col2im3x3(dcols: Tensor, dx: Tensor, B: int, H: int, W: int, stride: int) ->
 
 
 def conv3x3(x: Tensor, w: Tensor, out: Tensor, B: int, H: int, W: int, zeros: Tensor,
-            scratch: Optional[Tensor] = None, colstats: Optional[Tensor] = None) -> int:
+            scratch: Optional[Tensor] = None, colstats: Optional[Tensor] = None, bnbwd=None) -> int:
     """3x3 / pad 1 / stride 1 convolution on NHWC rows as an implicit GEMM (ffm_conv3x3_nhwc): x [B*H*W, C],
     w [N, Kp] with k = (ky*3 + kx)*C + c, out [B*H*W, N].  scratch: fp32 buffer for split-K partial tiles (optional).
     colstats: optional fp32 buffer for the column sums of the output's row tiles; returns the number of partial rows
-    written into it (0 when the launch is split over K or colstats is None: the BatchNorm forms its own sums)."""
+    written into it (0 when the launch is split over K or colstats is None: the BatchNorm forms its own sums).
+    bnbwd = (bn_x, bn_mask or None, mean, rstd): `out` is dL/dy of a train-mode BatchNorm (+ ReLU) on bn_x and the partial
+    rows are that BatchNorm's BACKWARD sums {sum g, sum g xhat} (bn_bwd's part / part_rows); a launch split over K returns
+    0 and writes none (the caller's bn_bwd then runs its own pass)."""
     _dev(x, w, out, zeros, scratch, colstats)
     assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and x.dtype == w.dtype == out.dtype
     assert x.shape[0] == B * H * W and tuple(out.shape) == (B * H * W, w.shape[0]) and zeros.numel() * zeros.element_size() >= 16
@@ -371,9 +386,19 @@ def conv3x3(x: Tensor, w: Tensor, out: Tensor, B: int, H: int, W: int, zeros: Te
     if colstats is not None:
         prow = L.load().ffm_conv3x3_colstat_rows(B, H, W, x.shape[1], w.shape[0], w.shape[1], nsc, L.dtype_code(x.dtype))
         assert prow >= 0 and _f32(colstats).numel() >= 2 * w.shape[0] * prow
+    if bnbwd is not None and prow > 0:
+        bn_x, bn_mask, bn_mean, bn_rstd = bnbwd
+        _dev(bn_x, bn_mask, bn_mean, bn_rstd)
+        assert bn_x.dtype == out.dtype and bn_x.shape == out.shape and bn_x.is_contiguous()
+        assert bn_mask is None or (bn_mask.dtype == out.dtype and bn_mask.shape == out.shape and bn_mask.is_contiguous())
+        assert _f32(bn_mean).numel() == w.shape[0] and _f32(bn_rstd).numel() == w.shape[0]
+        _call("ffm_conv3x3_nhwc_bnbwd", L.ptr(x), L.ptr(w), L.ptr(out), B, H, W, x.shape[1], w.shape[0], w.shape[1], L.ptr(zeros),
+              L.ptr(_f32(scratch)), nsc, L.ptr(colstats), L.ptr(bn_x), L.ptr(bn_mask), L.ptr(bn_mean), L.ptr(bn_rstd),
+              L.dtype_code(x.dtype), L.stream_ptr())
+        return prow
     _call("ffm_conv3x3_nhwc", L.ptr(x), L.ptr(w), L.ptr(out), B, H, W, x.shape[1], w.shape[0], w.shape[1], L.ptr(zeros),
-          L.ptr(_f32(scratch)), nsc, L.ptr(colstats) if prow > 0 else None, L.dtype_code(x.dtype), L.stream_ptr())
-    return prow
+          L.ptr(_f32(scratch)), nsc, L.ptr(colstats) if (prow > 0 and bnbwd is None) else None, L.dtype_code(x.dtype), L.stream_ptr())
+    return prow if bnbwd is None else 0
 
 
 def bn_blocks(rows: int) -> int:
@@ -394,15 +419,18 @@ def bn_fwd(x: Tensor, gamma: Tensor, beta: Tensor, run_mean: Tensor, run_var: Te
 
 
 def bn_bwd(dy: Tensor, relu_out: Optional[Tensor], x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, part: Tensor,
-           k12: Tensor, dgamma: Tensor, dbeta: Tensor, dx: Tensor, g_out: Optional[Tensor] = None) -> None:
-    """g_out (optional, like dy): also receives g = dy * (relu_out > 0), the identity path's gradient."""
+           k12: Tensor, dgamma: Tensor, dbeta: Tensor, dx: Tensor, g_out: Optional[Tensor] = None, part_rows: int = 0) -> None:
+    """g_out (optional, like dy): also receives g = dy * (relu_out > 0), the identity path's gradient.
+    part_rows > 0: `part` already holds that many rows of {sum g, sum g xhat} from the producer of dy (gemm_nt's `bnbwd`):
+    the column-sum pass over dy / x / relu_out is skipped."""
     _dev(dy, relu_out, x, gamma, mean, rstd, part, k12, dgamma, dbeta, dx, g_out)
     rows, Cc = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and dy.dtype == x.dtype == dx.dtype
     assert g_out is None or (g_out.is_contiguous() and g_out.dtype == dy.dtype and g_out.shape == dy.shape)
+    assert part_rows == 0 or (g_out is None and part.numel() >= part_rows * 2 * Cc)
     _call("ffm_bn_bwd", L.ptr(dy), L.ptr(relu_out), L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(mean)), L.ptr(_f32(rstd)),
-          L.ptr(_f32(part)), L.ptr(_f32(k12)), L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), L.ptr(dx), L.ptr(g_out), rows, Cc,
-          L.dtype_code(x.dtype), L.stream_ptr())
+          L.ptr(_f32(part)), part_rows, L.ptr(_f32(k12)), L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), L.ptr(dx), L.ptr(g_out),
+          rows, Cc, L.dtype_code(x.dtype), L.stream_ptr())
 
 
 def avgpool2(inp: Tensor, out: Tensor, B: int, H: int, W: int, backward: bool = False) -> None:

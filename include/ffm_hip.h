@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 10  /* 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 11  /* 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -72,6 +72,7 @@ int ffm_abi_version(void);
 #define FFM_EPI_ROWSTATS  128 /* producer: rowstat_part[tn][m] = {sum, sum of squares} of the stored row over this block's columns */
 #define FFM_EPI_LNIN      256 /* consumer: b / b_packed hold W', bias holds d, ln_c holds c; rows are normalised in the epilogue */
 #define FFM_EPI_LGRAD     512 /* with DGELU | RANKOP: also lg_part_c / lg_part_a, two rank-r gradient partial products (below) */
+#define FFM_EPI_BNBWD     1024 /* colstat_part receives the BatchNorm-BACKWARD column sums of the stored output (bn_* below) */
 
 typedef struct ffm_gemm_args {
     const void* a;      /* [M, K] dtype, row stride lda (elements) */
@@ -145,6 +146,16 @@ typedef struct ffm_gemm_args {
     const float* lg_v;      /* [M, rank] fp32 */
     float*       lg_part_c;
     float*       lg_part_a;
+    /* FFM_EPI_BNBWD (ABI 11; 128x128 kernel, with colstat_part): the stored output IS dL/dy of a train-mode BatchNorm
+     * (+ ReLU) whose input bn_x and output bn_mask [M, N] (dtype, stride ldc; bn_mask may be NULL: no ReLU) the caller
+     * holds - RN50: the dX product of conv3 produces the gradient of relu(bn2(.)), clip/model.py:41-60.  colstat_part
+     * [ffm_gemm_tiles_m][2][N] then receives, per row tile, {sum g, sum g * xhat} with g = c * (bn_mask > 0) and
+     * xhat = (bn_x - bn_mean[n]) * bn_rstd[n]: the two column sums ffm_bn_bwd needs (its part / part_rows), so that it does
+     * not read dy, x and the mask once more to form them. */
+    const void*  bn_x;
+    const void*  bn_mask;
+    const float* bn_mean;   /* [N] */
+    const float* bn_rstd;   /* [N] */
 } ffm_gemm_args;
 
 /*
@@ -290,6 +301,13 @@ int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W,
 /* colstat_part (optional): as ffm_gemm_args.colstat_part; written only when the launch is not split over K -
  * ffm_conv3x3_colstat_rows returns the number of partial rows it will then hold (0: split-K, no statistics) */
 int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int Kp, int64_t scratch_elems, int dtype);
+/* the same product with FFM_EPI_BNBWD's column sums (ABI 11): y is dL/dy of a train-mode BatchNorm (+ ReLU with output
+ * bn_mask, or NULL) on bn_x, and colstat_part receives {sum g, sum g xhat} per row tile (ffm_bn_bwd's part / part_rows =
+ * ffm_conv3x3_colstat_rows).  FFM_EUNSUP when the launch would be split over K (ffm_conv3x3_colstat_rows == 0). */
+int ffm_conv3x3_nhwc_bnbwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
+                           const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part,
+                           const void* bn_x, const void* bn_mask, const float* bn_mean, const float* bn_rstd, int dtype,
+                           void* stream);
 int ffm_stem_im2col(const float* img, void* cols, int B, int H, int W, int stride, int Kp, const float* mean3,
                     const float* std3, int dtype, void* stream);
 int ffm_im2col3x3(const void* x, void* cols, int B, int H, int W, int C, int stride, int Kp, int dtype, void* stream);
@@ -301,10 +319,12 @@ int ffm_bn_fwd(const void* x, const float* gamma, const float* beta, float* run_
 /* part_rows > 0 (training, at most 4096): part already holds that many partial rows [part_rows][2][C] of column sums written by the
  * producer of x (colstat_part): the column-sum pass over x is skipped */
 int ffm_bn_bwd(const void* dy, const void* relu_out, const void* x, const float* gamma, const float* mean,
-               const float* rstd, float* part, float* k12, float* dgamma, float* dbeta, void* dx, void* g_out, int rows,
-               int C, int dtype, void* stream);
+               const float* rstd, float* part, int part_rows, float* k12, float* dgamma, float* dbeta, void* dx, void* g_out,
+               int rows, int C, int dtype, void* stream);
 /* g_out (optional, [rows, C] dtype): also receives g = dy * (relu_out > 0) - the gradient that an identity-skip
- * Bottleneck passes on beside bn3 (clip/model.py:57-59), which is otherwise one more pass (ffm_relu_bwd) */
+ * Bottleneck passes on beside bn3 (clip/model.py:57-59), which is otherwise one more pass (ffm_relu_bwd).
+ * part_rows > 0 (ABI 11, at most 4096; g_out must be NULL): part already holds that many partial rows [part_rows][2][C] of
+ * {sum g, sum g xhat} written by the producer of dy (ffm_gemm_args FFM_EPI_BNBWD): the column-sum pass is skipped */
 int ffm_avgpool2(const void* in, void* out, int B, int H, int W, int C, int backward, int dtype, void* stream);
 int ffm_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 int ffm_relu_bwd(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);

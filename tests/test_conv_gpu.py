@@ -278,3 +278,92 @@ def test_narrow_conv_tiles_on_wide_outputs():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_conv_gpu.py"), "-k",
                         "implicit_gemm or column_sums"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+@pytest.mark.parametrize("M,N,K,relu,lora", [(1000, 256, 64, True, False), (6272, 256, 1024, True, True), (3 * 49, 512, 2048, False, True),
+                                            (25088, 128, 512, True, True), (40000, 64, 256, True, True)])
+def test_gemm_leaves_batchnorm_backward_sums(ops, dt, M, N, K, relu, lora):
+    """FFM_EPI_BNBWD: the dX product whose output is dL/dy of a train-mode BatchNorm (+ ReLU) leaves {sum g, sum g xhat} of
+    its row tiles in colstat_part (g = stored output x (ReLU output > 0)), and ffm_bn_bwd(part_rows) on them gives what its
+    own pass over dy / x / mask gives - folded small maps and the three-launch large ones alike (clip/model.py:41-60:
+    conv3's dX feeds bn2's backward)."""
+    r, G = 8, 2
+    a, b = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    x = rnd(M, N, dt=dt, seed=3) * 1.5 + 0.2                       # the BatchNorm's input
+    gamma, beta = 1 + 0.1 * rnd(N, seed=4), 0.1 * rnd(N, seed=5)
+    mean, rstd = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    y = torch.empty_like(x)
+    ops.bn_fwd(x, gamma, beta, rm, rv, mean, rstd, torch.empty(ops.bn_blocks(M) * 2 * N, device="cuda"), y, True, relu)
+    mask = y if relu else None
+    t = (M + 127) // 128
+    st = torch.full((t, 2, N), float("nan"), device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    kw = {}
+    if lora:
+        P, S, lw = rnd(K, r, scale=0.1, seed=6), rnd(G, r, seed=7), rnd(N, r, seed=8)
+        attr = torch.randint(0, G, ((M + 48) // 49,), device="cuda", dtype=torch.int32)
+        rk = torch.zeros(16, K, device="cuda", dtype=dt)
+        ops.PackPlan([(P, False, rk)], dt, "cuda").run()
+        ro = ops.RankOp(rk, S, attr, 49, 0.25, 0.7, ts_out=torch.empty(M, r, device="cuda"))
+        kw = dict(lw=lw, lw_is_kr=True, rankop=ro)
+    ops.gemm_nt(a, b, out, colstats=st, bnbwd=(x, mask, mean, rstd), **kw)
+    out0 = torch.empty_like(out)
+    if lora:
+        kw["rankop"] = ops.RankOp(rk, S, attr, 49, 0.25, 0.7, ts_out=torch.empty(M, r, device="cuda"))
+    ops.gemm_nt(a, b, out0, **kw)
+    assert torch.equal(out, out0)                                  # the stored product does not change
+    g = out.double() * ((y.double() > 0) if relu else 1.0)
+    xh = (x.double() - mean.double()) * rstd.double()
+    for i in range(t):
+        sl = slice(i * 128, (i + 1) * 128)
+        assert rel(st[i, 0], g[sl].sum(0)) < 2e-5 and rel(st[i, 1], (g[sl] * xh[sl]).sum(0)) < 2e-5, i
+    res = []
+    for pr in (0, t):
+        k12, dg, db = torch.empty(2 * N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        dx = torch.empty_like(x)
+        part = st.clone().flatten() if pr else torch.empty(ops.bn_blocks(M) * 2 * N, device="cuda")
+        ops.bn_bwd(out, mask, x, gamma, mean, rstd, part, k12, dg, db, dx, part_rows=pr)
+        res.append((dx, dg, db))
+    for u, v in zip(res[0], res[1]):
+        assert rel(v, u) < (2e-5 if dt == torch.float32 else 8e-3)
+    # a flag combination without a kernel: refused, not silently ignored
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, b, out, bias=gamma, colstats=st, bnbwd=(x, mask, mean, rstd))
+
+
+@pytest.mark.parametrize("dt", DT, ids=IDS)
+def test_conv3x3_leaves_batchnorm_backward_sums(ops, dt):
+    """ffm_conv3x3_nhwc_bnbwd: the implicit-GEMM convolution whose output is dL/dy of a BatchNorm (+ ReLU) - conv2's dX feeding
+    bn1's backward in a Bottleneck - leaves {sum g, sum g xhat} per row tile: the 128 x 128 kernel (N = 128), both narrow
+    kernels (N = 64 / 32), with and without a ReLU mask; a launch split over K writes none and says so."""
+    kq = 64 if dt != torch.float32 else 32
+    rup = lambda v: (v + kq - 1) // kq * kq
+    zeros = torch.zeros(64, device="cuda", dtype=dt)
+    for (B, H, C, Co, sc, relu) in [(5, 28, 64, 128, False, True), (5, 28, 64, 64, False, True), (2, 16, 64, 32, True, False),
+                                    (3, 12, 32, 32, False, True),
+                                    (4, 14, 256, 256, True, True)]:
+        xin = rnd(B, C, H, H, dt=dt, seed=1)
+        w = rnd(Co, C, 3, 3, dt=dt, scale=1.0 / math.sqrt(9 * C), seed=2)
+        scratch = torch.zeros(8 * B * H * H * max(C, Co), device="cuda") if sc else None
+        M = B * H * H
+        bx = rnd(M, Co, dt=dt, seed=3) * 1.3 + 0.1                      # the BatchNorm's input rows
+        mean, rstd = bx.float().mean(0), 1.0 / torch.sqrt(bx.float().var(0, unbiased=False) + 1e-5)
+        mask = (rnd(M, Co, dt=dt, seed=4) if relu else None)             # its ReLU output (only the sign matters)
+        y, y0 = torch.empty(M, Co, device="cuda", dtype=dt), torch.empty(M, Co, device="cuda", dtype=dt)
+        st = torch.full(((M + 127) // 128, 2, Co), float("nan"), device="cuda")
+        wr = _rows_fwd(w, rup(9 * C)).to(dt)
+        pr = ops.conv3x3(nhwc(xin), wr, y, B, H, H, zeros, scratch, colstats=st, bnbwd=(bx, mask, mean, rstd))
+        ops.conv3x3(nhwc(xin), wr, y0, B, H, H, zeros, scratch)
+        assert torch.equal(y, y0)
+        split = (B, H, C) == (4, 14, 256) or ((B, H, C, Co) == (2, 16, 64, 32) and dt == torch.float32)   # (f32: 18 K tiles)
+        if split:
+            assert pr == 0 and bool(torch.isnan(st).all())            # split over K: no sums
+            continue
+        assert pr == (M + 127) // 128
+        g = y.double() * ((mask.double() > 0) if relu else 1.0)
+        xh = (bx.double() - mean.double()) * rstd.double()
+        for i in range(pr):
+            sl = slice(i * 128, (i + 1) * 128)
+            assert rel(st[i, 0], g[sl].sum(0)) < 2e-5 and rel(st[i, 1], (g[sl] * xh[sl]).sum(0)) < 2e-5, (Co, i)
