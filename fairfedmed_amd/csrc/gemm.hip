@@ -951,6 +951,75 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// The same sum with the column sums of the STORED rows beside it (round 5): a convolution split over K has no epilogue to
+// leave the BatchNorm statistics in, so the BatchNorm behind it used to read the tensor once more (RN50 layer3 / layer4:
+// 7 forward and 9 backward column-sum launches per step).  A block owns R rows x 64 columns (16 column quads along the
+// threads x 16 row lanes, combined through LDS in a fixed order) and writes its 64 columns of partial row
+// cs_part[block][2][N]: {sum, sum of squares} (forward statistics) or, BNB, {sum g, sum g xhat} with g = value x
+// (bn_mask > 0), xhat = (bn_x - mean) rstd (ffm_bn_bwd's sums, FFM_EPI_BNBWD).
+inline int splitk_cs_rows(int M) { return M >= 4096 ? 32 : 8; }                 // rows per block
+inline bool splitk_cs_ok(int M, int N) { return N % 4 == 0 && (M + splitk_cs_rows(M) - 1) / splitk_cs_rows(M) <= 4096; }
+template <typename T, bool BNB>
+__global__ __launch_bounds__(256) void splitk_reduce_cs_kernel(const float* __restrict__ part, T* __restrict__ y, int M, int N,
+                                                               size_t stride, int S, int R, float* __restrict__ cs_part,
+                                                               const T* __restrict__ bn_x, const T* __restrict__ bn_mask,
+                                                               const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd) {
+    // grid (row blocks of R rows, groups of 64 columns): 16 column quads x 16 row lanes per block - the first version (one
+    // block per R rows x all columns: 196 blocks at layer3) streamed the 51 MB of partial tiles at a third of the plain
+    // reduction's rate
+    __shared__ float red[2][256][4];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64 + q * 4;
+    const bool cok = c0 < N;
+    const int r0 = blockIdx.x * R, r1 = (r0 + R) < M ? (r0 + R) : M;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs, mu = cs, rs = cs;
+    if (BNB && cok) {
+        mu = *reinterpret_cast<const f32x4*>(bn_mean + c0);
+        rs = *reinterpret_cast<const f32x4*>(bn_rstd + c0);
+    }
+    if (cok) {
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const size_t o = (size_t)r * N + c0;
+            f32x4 a = *reinterpret_cast<const f32x4*>(part + o);
+#pragma unroll 8
+            for (int s = 1; s < S; ++s) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(part + (size_t)s * stride + o);
+                a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            }
+            Vec4<T>::store(y + o, a);
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+            if (BNB) {
+                xv = Vec4<T>::load(bn_x + o);
+                if (bn_mask) mv = Vec4<T>::load(bn_mask + o);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float st = Elem<T>::to_f(Elem<T>::from_f(a[e]));
+                if (BNB) {
+                    if (!(mv[e] > 0.f)) st = 0.f;
+                    cs[e] += st;
+                    cq[e] += st * (xv[e] - mu[e]) * rs[e];
+                } else {
+                    cs[e] += st;
+                    cq[e] += st * st;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = cs[e]; red[1][threadIdx.x][e] = cq[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x >> 6, cl = threadIdx.x & 63, c = blockIdx.y * 64 + cl;
+        if (c < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) t += red[j][l * 16 + (cl >> 2)][cl & 3];
+            cs_part[((size_t)blockIdx.x * 2 + j) * N + c] = t;
+        }
+    }
+}
+
 namespace {
 // ---- 3x3 convolutions with FEW output channels (N = 32 / 64: RN50's stem and layer1), where a 128-wide tile spends
 // half or three quarters of its MFMAs on padding: block tile 128 x NB, wave w owns rows [32 w, 32 w + 32) x all NB columns,
@@ -1151,7 +1220,9 @@ int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_e
 extern "C" int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int Kp, int64_t scratch_elems, int dtype) {
     if (B <= 0 || H <= 0 || W <= 0 || N <= 0 || (dtype != FFM_BF16 && dtype != FFM_F32)) return FFM_EINVAL;
     const int M = B * H * W;
-    return conv_ksplit(M, N, Kp, dtype == FFM_BF16 ? 2 : 4, scratch_elems > 0, scratch_elems) > 1 ? 0 : (M + BM - 1) / BM;
+    if (conv_ksplit(M, N, Kp, dtype == FFM_BF16 ? 2 : 4, scratch_elems > 0, scratch_elems) > 1)   // the split-K sum leaves them
+        return splitk_cs_ok(M, N) ? (M + splitk_cs_rows(M) - 1) / splitk_cs_rows(M) : 0;
+    return (M + BM - 1) / BM;
 }
 
 static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp, const void* zeros,
@@ -1170,8 +1241,10 @@ extern "C" int ffm_conv3x3_nhwc_bnbwd(const void* x, const void* w, void* y, int
                                       const void* bn_x, const void* bn_mask, const float* bn_mean, const float* bn_rstd,
                                       int dtype, void* stream) {
     if (!colstat_part || !bn_x || !bn_mean || !bn_rstd || (((uintptr_t)bn_x | (uintptr_t)bn_mask) & 15)) return FFM_EINVAL;
-    // (the column sums exist in the launches that are not split over K: ask ffm_conv3x3_colstat_rows first)
-    if (conv_ksplit(B * H * W, N, Kp, dtype == FFM_BF16 ? 2 : 4, splitk_scratch != nullptr, scratch_elems) > 1) return FFM_EUNSUP;
+    // (ask ffm_conv3x3_colstat_rows first: 0 = this launch cannot leave them)
+    if (conv_ksplit(B * H * W, N, Kp, dtype == FFM_BF16 ? 2 : 4, splitk_scratch != nullptr, scratch_elems) > 1 &&
+        !splitk_cs_ok(B * H * W, N))
+        return FFM_EUNSUP;
     return conv3x3_impl(x, w, y, B, H, W, C, N, Kp, zeros, splitk_scratch, scratch_elems, colstat_part, bn_x, bn_mask, bn_mean,
                         bn_rstd, dtype, stream);
 }
@@ -1198,8 +1271,8 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     // that the launch fills the chip; the fp32 partial tiles are summed by one more small kernel.
     const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems);
     if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
-    a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: no epilogue, no statistics)
-    const bool bnb = bn_x != nullptr;                              // FFM_EPI_BNBWD: S == 1 (checked by the entry point)
+    a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: the sums leave with the reduction below)
+    const bool bnb = bn_x != nullptr;                              // FFM_EPI_BNBWD (split over K: in the reduction below)
     if (bnb) { a.flags = FFM_EPI_BNBWD; a.bn_x = bn_x; a.bn_mask = bn_mask; a.bn_mean = bn_mean; a.bn_rstd = bn_rstd; }
     // The stem and layer1 (N = 32 / 64): 128 x N tiles, three blocks per CU (81 -> 33 / 43 us at 112 x 112, 40 -> 25 us at
     // 56 x 56).  FFM_CONV_NARROW=off: the 128x128 kernel (A/B runs); FFM_CONV_NARROW=<t>: also N = 128 / 256 / ... as 64-wide
@@ -1215,10 +1288,20 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
         if (a.N == 32) return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 32>(ka, s) : launch_conv_narrow<float, 32>(ka, s);
         return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 64>(ka, s) : launch_conv_narrow<float, 64>(ka, s);
     }
-    if (bnb) return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true>(a, s, &ka) : launch_gemm<float, false, FFM_EPI_BNBWD, true>(a, s, &ka);
+    if (bnb && S == 1) return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true>(a, s, &ka) : launch_gemm<float, false, FFM_EPI_BNBWD, true>(a, s, &ka);
     const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
     if (e || ka.ksplit <= 1) return e;
     const size_t total = (size_t)a.M * a.N, total4 = total / 4;
+    if (colstat_part && splitk_cs_ok(a.M, a.N)) {
+        const int R = splitk_cs_rows(a.M), nb = (a.M + R - 1) / R;
+#define FFM_SKCS(T, B_) hipLaunchKernelGGL((splitk_reduce_cs_kernel<T, B_>), dim3(nb, (a.N + 63) / 64), dim3(256), 0, s, ka.part, (T*)y, a.M, a.N, total, \
+                                           ka.ksplit, R, colstat_part, (const T*)bn_x, (const T*)bn_mask, bn_mean, bn_rstd)
+        if (dtype == FFM_BF16) { if (bnb) FFM_SKCS(bf16_t, true); else FFM_SKCS(bf16_t, false); }
+        else { if (bnb) FFM_SKCS(float, true); else FFM_SKCS(float, false); }
+#undef FFM_SKCS
+        FFM_CHECK_LAUNCH();
+        return FFM_OK;
+    }
     size_t blocks = (total4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (dtype == FFM_BF16)

@@ -130,6 +130,9 @@ class _BN:
         t = (max_rows + 127) // 128                                # row tiles of the GEMM that produces this layer's input
         if t <= 4096:
             eng.stat_scratch = max(eng.stat_scratch, 2 * t * C)
+        t8 = (max_rows + 7) // 8                                   # (a convolution split over K: 8 / 32 rows per partial row)
+        if t8 <= 4096 or (max_rows >= 4096 and (max_rows + 31) // 32 <= 4096):
+            eng.stat_scratch = max(eng.stat_scratch, 2 * (t8 if max_rows < 4096 else (max_rows + 31) // 32) * C)
         eng.bns.append(self)
 
     def fwd(self, x: Tensor, y: Tensor, relu: bool, res: Optional[Tensor] = None, part: Optional[Tensor] = None,
