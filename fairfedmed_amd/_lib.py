@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("rowstat_part", _vp), ("ln_part", _vp), ("ln_c", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_np", _i32), ("gelu_deriv", _i32),
         ("ln_rk", _vp), ("colstat_part", _vp),
         ("lg_v", _vp), ("lg_part_c", _vp), ("lg_part_a", _vp),
-        ("bn_x", _vp), ("bn_mask", _vp), ("bn_mean", _vp), ("bn_rstd", _vp),
+        ("bn_x", _vp), ("bn_mask", _vp), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_gout", _vp),
     ]
 
 

@@ -728,13 +728,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
                 }
                 if (BNB && cst && bnb) {
                     // {sum g, sum g xhat}, g = stored value * (ReLU output > 0): ffm_bn_bwd's column sums (colsum_kernel MODE 1)
+                    float gm[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         float g = Elem<T>::to_f(Elem<T>::from_f(v[i][c]));
                         if (p.bn_mask && !(Elem<T>::to_f(rbm[BNB ? i : 0][c / EPC][c % EPC]) > 0.f)) g = 0.f;
                         cs[c] += g;
                         cq[c] += g * (Elem<T>::to_f(rbx[BNB ? i : 0][c / EPC][c % EPC]) - bnmu[c]) * bnrs[c];
+                        gm[c] = g;
                     }
+                    if (p.bn_gout) Vec8<T>::store(reinterpret_cast<T*>(p.bn_gout) + off, gm);   // (ffm_bn_bwd's g_out)
                 } else if (cst) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
@@ -874,7 +877,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if ((a.flags & FFM_EPI_DGELU) && (!a.aux || ((uintptr_t)a.aux & 15))) return FFM_EINVAL;
     if (a.flags & FFM_EPI_BNBWD) {                                        // BatchNorm-backward column sums: 128x128 kernel
         if (!a.colstat_part || !a.bn_x || !a.bn_mean || !a.bn_rstd || (a.flags & FFM_EPI_GELU)) return FFM_EINVAL;
-        if (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mask) & 15) return FFM_EINVAL;
+        if (((uintptr_t)a.bn_x | (uintptr_t)a.bn_mask | (uintptr_t)a.bn_gout) & 15) return FFM_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;
     if (ffm_skinny_ok(a, dtype) && !a.colstat_part) {                    // (column sums: the 128x128 kernel's epilogue)
@@ -899,7 +902,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     }
     const int fl = a.flags & ~FFM_EPI_RANKOP;
     // BatchNorm-backward column sums exist in the kernels instantiated with the bit only (cases below; rank <= 16)
-    if ((fl & FFM_EPI_BNBWD) && !(rk && fl == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_BNBWD)) && fl != FFM_EPI_BNBWD) return FFM_EUNSUP;
+    if ((fl & FFM_EPI_BNBWD) && !(rk && (fl & ~FFM_EPI_RESIDUAL) == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_BNBWD)) && fl != FFM_EPI_BNBWD) return FFM_EUNSUP;
     if ((fl & FFM_EPI_BNBWD) && (fl & FFM_EPI_LORA) && a.rank > 16) return FFM_EUNSUP;
     if ((fl & FFM_EPI_LORA) && a.rank > 16) {                             // rank-r update on the VALU: generic-flag kernels
         if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1, false, true>(a, s) : launch_gemm<float, true, -1, false, true>(a, s);
@@ -917,6 +920,7 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
             FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA)                                       // RN50 attention-pool projections
             FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_RESIDUAL)                 // RN50 dX of conv1 + identity path
             FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_BNBWD)                    // RN50 dX of conv3 + bn2's backward sums
+            FFM_GEMM_CASE(true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_RESIDUAL | FFM_EPI_BNBWD) // dX of conv1 + identity + the NEXT block's bn3 sums
             default: return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1>(a, s) : launch_gemm<float, true, -1>(a, s);
         }
     }

@@ -248,14 +248,18 @@ class _Bneck:
         ops.gemm_nt(xi, W[p + "wd"], self.zd[:ro], colstats=e.stat_buf[1] if t_o else None)
         self.bnd.fwd(self.zd[:ro], self.idn[:ro], False, part=e.stat_buf[1], part_rows=t_o)
 
-    def backward(self, g: Tensor, x: Tensor, images: int, attr: Optional[Tensor]) -> Tensor:
-        """g = dL/d(block output) -> dL/d(block input)."""
+    def backward(self, g: Tensor, x: Tensor, images: int, attr: Optional[Tensor], bn3_rows: int = 0,
+                 consumer: Optional["_Bneck"] = None):
+        """g = dL/d(block output) -> (dL/d(block input), partial rows of the CONSUMER's bn3 sums left in stat_buf[0]).
+        bn3_rows > 0: the dX product of the block behind this one (which produced g) has left this block's bn3 backward
+        sums in stat_buf[0] and - identity-skip blocks - the ReLU-masked gradient in self.gid (FFM_EPI_BNBWD)."""
         e, p, W = self.eng, self.p, self.eng.rnw
         Hi, Ho = self.Hin, self.Hout
         ri, ro = images * Hi * Hi, images * Ho * Ho
         out = self.out[:ro]
         # (identity-skip blocks: the ReLU-masked gradient that goes on beside bn3 leaves the same pass)
-        self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro], g_out=None if self.has_down else self.gid[:ro])
+        self.bn3.bwd(g, out, self.z3[:ro], self.dz3[:ro], g_out=None if (self.has_down or bn3_rows) else self.gid[:ro],
+                     part=e.stat_buf[0], part_rows=bn3_rows)
         main = torch.cuda.current_stream(e.device)
         fork = self.has_down and getattr(e, "down_on_side", True) and e.aux_stream != main
         if self.has_down:
@@ -293,7 +297,13 @@ class _Bneck:
         self.bn1.bwd(self.da1[:ri], self.a1[:ri], self.z1[:ri], self.dz1[:ri], part=e.stat_buf[0], part_rows=t1 if fuse1 else 0)
         if fork:
             e._ev_wait(main, self.ev_d[3])                        # join: the downsample branch's input gradient
-        self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid, defer=side)
+        # this block's dX IS dL/d(output) of the block in front of it: its bn3's backward sums (and, for an identity-skip
+        # block, the masked gradient it passes on) leave with this product's epilogue
+        t3 = e.stat_rows(ri) if (consumer is not None and self.c1.fused and getattr(e, "bn_bwd_fused", True)) else 0
+        self.c1.bwd(self.dz1[:ri], W[p + "w1t"], self.dx[:ri], x, attr, Hi * Hi, res=gid, defer=side,
+                    bnbwd=(consumer.z3[:ri], consumer.out[:ri], consumer.bn3.mean, consumer.bn3.rstd,
+                           None if consumer.has_down else consumer.gid[:ri]) if t3 else None,
+                    colstats=e.stat_buf[0] if t3 else None)
         if side:
             # off the dX chain: this block's four rank-r reductions (every operand is a per-block buffer that stays put
             # until the next step's forward)
@@ -306,7 +316,7 @@ class _Bneck:
                 # ... and the sum of this block's partials behind them (round 4: ONE launch for every site of the trunk at the
                 # end of the backward pass sat in the step's tail for 92 us - layer1's sites alone have 784 partial rows)
                 self.reduce_plan(images).run()
-        return self.dx[:ri]
+        return self.dx[:ri], t3
 
     def reduce_plan(self, images: int) -> "ops.ReducePlan":
         if images not in self.rplans:
@@ -581,9 +591,10 @@ class RN50Engine(FairLoRAEngine):
                 self._reduce(b, "ap").run()
         g = self.dx4[:b * HW]
         ops.attnpool_tokens(acc, None, g, b, HW, backward=True)
+        t3 = 0
         for i in range(len(self.blocks) - 1, -1, -1):
             x = self.blocks[i - 1].out[:b * self.blocks[i].Hin ** 2] if i > 0 else self.p0[:b * self.H2 * self.H2]
-            g = self.blocks[i].backward(g, x, b, a32)
+            g, t3 = self.blocks[i].backward(g, x, b, a32, bn3_rows=t3, consumer=self.blocks[i - 1] if i > 0 else None)
         # stem: only the BatchNorm weights / biases train, but their gradients need dX through conv3 and conv2
         H1 = self.H1
         r1 = b * H1 * H1

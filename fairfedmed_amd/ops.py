@@ -161,7 +161,7 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     `b` in float16: FFM_F32_X3_W16, the same on a weight rounded to IEEE half in memory (half the bytes).
     gelu_deriv (with gelu_out / dgelu_aux): `out` receives / `dgelu_aux` holds quick_gelu'(pre) instead of pre
     (ffm_gemm_args.gelu_deriv).
-    bnbwd = (bn_x, bn_mask or None, mean, rstd) with `colstats`: FFM_EPI_BNBWD - `out` is dL/dy of a train-mode BatchNorm
+    bnbwd = (bn_x, bn_mask or None, mean, rstd[, gout]) with `colstats`: FFM_EPI_BNBWD - `out` is dL/dy of a train-mode BatchNorm
     (+ ReLU with output bn_mask) on bn_x, and `colstats` receives the backward's column sums {sum g, sum g xhat} per row tile
     (bn_bwd's part / part_rows) instead of the forward's {sum, sum of squares}."""
     _dev(a, b, out, bias, ts, lw, res, gelu_out, dgelu_aux, b_packed)
@@ -226,15 +226,17 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         assert _f32(lg_v).shape[0] >= M and lg_v.shape[1] == rank
         assert min(_f32(lg_c).numel(), _f32(lg_a).numel()) >= rows * N * rank
         lgx = (L.ptr(lg_v), L.ptr(lg_c), L.ptr(lg_a))
-    bnx = (None, None, None, None)
+    bnx = (None, None, None, None, None)
     if bnbwd is not None:
-        bn_x, bn_mask, bn_mean, bn_rstd = bnbwd
-        _dev(bn_x, bn_mask, bn_mean, bn_rstd)
+        bn_x, bn_mask, bn_mean, bn_rstd = bnbwd[:4]
+        bn_gout = bnbwd[4] if len(bnbwd) > 4 else None       # optional: g = out * (bn_mask > 0), like bn_bwd's g_out
+        _dev(bn_x, bn_mask, bn_mean, bn_rstd, bn_gout)
+        assert bn_gout is None or (bn_gout.dtype == out.dtype and tuple(bn_gout.shape) == (M, N) and _ld(bn_gout) == _ld(out))
         assert colstats is not None and bn_x.dtype == out.dtype and tuple(bn_x.shape) == (M, N) and _ld(bn_x) == _ld(out)
         assert bn_mask is None or (bn_mask.dtype == out.dtype and tuple(bn_mask.shape) == (M, N) and _ld(bn_mask) == _ld(out))
         assert _f32(bn_mean).numel() == N and _f32(bn_rstd).numel() == N
         flags |= L.EPI_BNBWD
-        bnx = (L.ptr(bn_x), L.ptr(bn_mask), L.ptr(bn_mean), L.ptr(bn_rstd))
+        bnx = (L.ptr(bn_x), L.ptr(bn_mask), L.ptr(bn_mean), L.ptr(bn_rstd), L.ptr(bn_gout))
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,

@@ -156,6 +156,8 @@ typedef struct ffm_gemm_args {
     const void*  bn_mask;
     const float* bn_mean;   /* [N] */
     const float* bn_rstd;   /* [N] */
+    void*        bn_gout;   /* optional [M, N] dtype, stride ldc: also receives g = c * (bn_mask > 0), the gradient an identity-skip
+                             * Bottleneck passes on beside bn3 (ffm_bn_bwd's g_out, which a call with part_rows cannot write) */
 } ffm_gemm_args;
 
 /*

@@ -309,12 +309,19 @@ def test_gemm_leaves_batchnorm_backward_sums(ops, dt, M, N, K, relu, lora):
         ops.PackPlan([(P, False, rk)], dt, "cuda").run()
         ro = ops.RankOp(rk, S, attr, 49, 0.25, 0.7, ts_out=torch.empty(M, r, device="cuda"))
         kw = dict(lw=lw, lw_is_kr=True, rankop=ro)
-    ops.gemm_nt(a, b, out, colstats=st, bnbwd=(x, mask, mean, rstd), **kw)
+    # (with the FairLoRA epilogue also the residual form - conv1's dX + the identity path's gradient - and the masked
+    # gradient as a second output: what the dX product of a Bottleneck's conv1 leaves for the block in front of it)
+    gout = torch.full((M, N), float("nan"), device="cuda", dtype=dt) if lora else None
+    if lora:
+        kw["res"] = rnd(M, N, dt=dt, seed=9)
+    ops.gemm_nt(a, b, out, colstats=st, bnbwd=(x, mask, mean, rstd, gout), **kw)
     out0 = torch.empty_like(out)
     if lora:
         kw["rankop"] = ops.RankOp(rk, S, attr, 49, 0.25, 0.7, ts_out=torch.empty(M, r, device="cuda"))
     ops.gemm_nt(a, b, out0, **kw)
     assert torch.equal(out, out0)                                  # the stored product does not change
+    if lora:
+        assert torch.equal(gout, out * (y > 0) if relu else out)
     g = out.double() * ((y.double() > 0) if relu else 1.0)
     xh = (x.double() - mean.double()) * rstd.double()
     for i in range(t):
