@@ -602,10 +602,12 @@ class RN50Engine(FairLoRAEngine):
         dsa, dsz = [t[:r1] for t in self.dsa], [t[:r1] for t in self.dsz]
         ops.avgpool2(g, dsa[2], b, H1, H1, backward=True)
         self.sbn[2].bwd(dsa[2], sa[2], sz[2], dsz[2])
-        ops.conv3x3(dsz[2], W["s3b"], dsa[1], b, H1, H1, self.zero16)
-        self.sbn[1].bwd(dsa[1], sa[1], sz[1], dsz[1])
-        ops.conv3x3(dsz[1], W["s2b"], dsa[0], b, H1, H1, self.zero16)
-        self.sbn[0].bwd(dsa[0], sa[0], sz[0], dsz[0])
+        # (the stem's two 3x3 dX products feed a BatchNorm backward each: its column sums leave with them, as in the blocks)
+        fs = self.stat_rows(r1) > 0 and getattr(self, "bn_bwd_fused", True)
+        for k, wn in ((1, "s3b"), (0, "s2b")):
+            tk = ops.conv3x3(dsz[k + 1], W[wn], dsa[k], b, H1, H1, self.zero16, colstats=self.stat_buf[0] if fs else None,
+                             bnbwd=(sz[k], sa[k], self.sbn[k].mean, self.sbn[k].rstd) if fs else None)
+            self.sbn[k].bwd(dsa[k], sa[k], sz[k], dsz[k], part=self.stat_buf[0], part_rows=tk if fs else 0)
         if getattr(self, "grads_on_side", True):
             # the partial sums of every site -> params.grad, behind the reductions on the gradient stream
             main = torch.cuda.current_stream(self.device)
