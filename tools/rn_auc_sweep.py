@@ -14,7 +14,7 @@ import fairfedmed_amd.trainer  # noqa: F401
 from tests.test_trainer_gpu import make_cfg
 
 USERS = 2
-geom = sys.argv[1] if len(sys.argv) > 1 else "rn_tiny2"
+geom = sys.argv[1] if (len(sys.argv) > 1 and __name__ == "__main__") else "rn_tiny2"
 mcfg = getattr(C, geom)(rank=4, num_groups=2)
 
 
@@ -43,7 +43,7 @@ def run(prec, signal, lr, rounds=3, perturb=False, bn3=1.0, train_b=6, bs=8):
 
 
 f = lambda v: "[" + ", ".join("%.5f" % x for x in v) + "]"
-for bn3 in (0.1, 0.05, 0.25):
+for bn3 in ((0.1, 0.05, 0.25) if __name__ == "__main__" else ()):
     for signal, lr, tb in ((0.45, 2e-3, 12), (0.45, 5e-3, 12), (0.25, 5e-3, 12), (0.45, 1e-2, 6)):
         a32 = run("fp32", signal, lr, bn3=bn3, train_b=tb)
         a16 = run("bf16", signal, lr, bn3=bn3, train_b=tb)
