@@ -48,6 +48,12 @@ constexpr float A3_C = 0.125f * 1.44269504088896341f;     // log2(e) / sqrt(64)
 #ifndef FFM_ATTN3_ABL
 #define FFM_ATTN3_ABL 0
 #endif
+// DMA chunks the forward kernel keeps in flight ahead of the one it computes on.  1: the product build.  2: measured in
+// round 5 on a twin library (tools/bench_attn.py, alternating, three pairs): 14.4 / 13.7 / 14.2 us against 14.3 / 13.7 / 13.5 -
+// inside the run-to-run spread, not kept
+#ifndef FFM_ATTN3_AHEAD
+#define FFM_ATTN3_AHEAD 1
+#endif
 // -DFFM_ATTN3_STAMPS: s_memtime stamps at the phase boundaries of every wave (tools/attn_stamps.py reads them through
 // ffm_attn3_read_stamps); the stamps fence the scheduler, so read their SHARES, never this build's run time.
 #ifdef FFM_ATTN3_STAMPS
@@ -313,6 +319,7 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
         wait_frags<0>(qv);
         return;
     }
+    if constexpr (FFM_ATTN3_AHEAD > 1 && GE::NCH > 1) dma_chunk<T, NT>(1, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
     A3_STAMP(1);
 
     const int ra = row_lane_off(lane), ta = tr_lane_off(lane);
@@ -329,8 +336,10 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
     // as this wait would anyway), then the counted wait for c, then the barrier
     auto chunk_ready = [&](auto C_) {
         constexpr int c = decltype(C_)::value;
-        if constexpr (c + 1 < GE::NCH) dma_chunk<T, NT>(c + 1, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
-        constexpr int pend = c + 1 < GE::NCH ? 2 * GE::RC : 0;
+        constexpr int AH = FFM_ATTN3_AHEAD;
+        if constexpr (c + AH < GE::NCH) dma_chunk<T, NT>(c + AH, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
+        constexpr int last = c + AH < GE::NCH - 1 ? c + AH : GE::NCH - 1;      // youngest chunk in flight
+        constexpr int pend = 2 * GE::RC * (last - c);
         if constexpr (c == 0) {
             wait_frags<pend>(qv);
 #pragma unroll
