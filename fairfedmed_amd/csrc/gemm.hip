@@ -121,8 +121,14 @@ struct ConvA {
 // VL: the rank-r update on the VALU (rank > 16, generic flags only).  Its 64-register LoRA tile pushes every instantiation
 // that carries it into scratch (30 spilled registers in the epilogue, +8 us per launch on RN50's short-K products), so
 // the rank <= 16 variants - the MFMA update - are compiled without it.
-template <typename T, bool RK, int FL, bool CV = false, bool VL = false>
+// NST: stages of the operand ring.  2 (default): the next K tile lands while this one is multiplied, two blocks per CU hide
+// the rest.  4 (round 5; plain operands only): for launches of FEWER tiles than CUs - RN50's layer3 / layer4 products, 52-208
+// blocks - where a block has its CU to itself and every K step waited out one LDS-DMA round trip (~1 us for 0.13 us of
+// MFMAs: 34 us at K = 2048): three K tiles in flight behind hand-counted s_waitcnt vmcnt + one raw barrier per K step.
+// The DMA of that path is issued from inline asm (hipcc must not see it: it would drain vmcnt(0) in front of every ds_read).
+template <typename T, bool RK, int FL, bool CV = false, bool VL = false, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
+    static_assert(NST == 2 || (!CV && !VL), "the deep ring serves the plain A / B loaders only");
     const ffm_gemm_args& p = px.g;
     typedef typename Mma16<T>::frag_t frag_t;
     constexpr int BUF = buf_bytes<RK>();
@@ -171,16 +177,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
         }
     };
 
+    // deep ring (NST > 2): one stage = this wave's 4 + 4 (+ 1, waves 0 / 1 under RANKOP) pieces of 1 KiB, by asm LDS-DMA
+    auto dma16 = [](const char* src, char* dst) {
+        typedef __attribute__((address_space(3))) char lds_c;
+        const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_c*)dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(d)
+                     : "memory");
+    };
+    auto stage_deep = [&](int kt, char* buf) {
+        const int rsub = lane >> 3, slot = lane & 7, chunk = slot ^ rsub;
+        const char* ab = reinterpret_cast<const char*>(A);
+        const char* bb = reinterpret_cast<const char*>(B);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int inst = wave * 4 + q, row = inst * 8 + rsub;
+            int ga_ = m0 + row, gb_ = n0 + row;
+            ga_ = ga_ < p.M ? ga_ : p.M - 1;
+            gb_ = gb_ < p.N ? gb_ : p.N - 1;
+            dma16(ab + ((size_t)ga_ * (size_t)p.lda) * sizeof(T) + (size_t)kt * KT_BYTES + chunk * 16, buf + inst * 1024);
+            dma16(bb + ((size_t)gb_ * (size_t)p.ldb) * sizeof(T) + (size_t)kt * KT_BYTES + chunk * 16, buf + TILE_BYTES + inst * 1024);
+        }
+        if (RK && wave < 2) {
+            const int row = wave * 8 + rsub;
+            dma16(reinterpret_cast<const char*>(p.rk) + (size_t)row * (size_t)p.K * sizeof(T) + (size_t)kt * KT_BYTES + (chunk << 4),
+                  buf + 2 * TILE_BYTES + wave * 1024);
+        }
+    };
+
     // prologue: tile 0 -> buffer 0
     ConvA<T> cva;
-    if constexpr (CV) {
+    if constexpr (NST > 2) {
+        // (issued behind the epilogue operands' loads and their vmcnt(0) below: the counted waits of the loop see nothing else)
+    } else if constexpr (CV) {
         cva.init(px, m0, wave, lane, kt0);
         cva.stage(px, smem, wave);
     } else {
         stage_tile<T>(A, p.lda, m0, p.M, 0, smem, wave, lane);
     }
-    stage_tile<T>(B, p.ldb, n0, p.N, kt0 * KT_BYTES, smem + TILE_BYTES, wave, lane);
-    stage_rank(0, smem + 2 * TILE_BYTES);
+    if constexpr (NST == 2) {
+        stage_tile<T>(B, p.ldb, n0, p.N, kt0 * KT_BYTES, smem + TILE_BYTES, wave, lane);
+        stage_rank(0, smem + 2 * TILE_BYTES);
+    }
 
     // ---- persistent epilogue operands (their loads overlap the main loop)
     const bool has_lora = (flags & FFM_EPI_LORA) != 0;
@@ -189,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     // as 64-byte rows: 32 bf16 / 16 f32 rank slots, zero padded); larger ranks use the VALU update in the epilogue
     constexpr int KE = 64 / (int)sizeof(T);
     const bool lora_mma = has_lora && !VL;
-    float* Ls = reinterpret_cast<float*>(smem + 2 * BUF);     // LoRA matrix tile [r][BN] (VALU path)
-    T* LwB = reinterpret_cast<T*>(smem + 2 * BUF);            // LoRA matrix tile, transposed [BN][KE] (MFMA path)
+    float* Ls = reinterpret_cast<float*>(smem + NST * BUF);   // LoRA matrix tile [r][BN] (VALU path)
+    T* LwB = reinterpret_cast<T*>(smem + NST * BUF);          // LoRA matrix tile, transposed [BN][KE] (MFMA path)
     const int ls_bytes = r * BN * 4 > BN * 64 ? r * BN * 4 : (r ? BN * 64 : 0);
-    float* Bias = reinterpret_cast<float*>(smem + 2 * BUF + ls_bytes);   // [BN]
+    float* Bias = reinterpret_cast<float*>(smem + NST * BUF + ls_bytes); // [BN]
     float* TsAll = Bias + BN;                                 // non-RANKOP: ts rows [BM][r]
     float* Sg = Bias + BN;                                    // RANKOP: lora_S [G][r] (<= 256 floats)
     int* Ga = reinterpret_cast<int*>(Sg + 256);               // RANKOP: group id of each tile row (-1: uniform mix)
@@ -350,7 +390,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     }
 
     const int frow = lane & 15, fgrp = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (NST > 2) {
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0)
+            if (s0 < nk) stage_deep(s0, smem + s0 * BUF);
+        const bool nine = RK && wave < 2;                           // pieces per stage of this wave: 9 or 8
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed when at most the y younger stages (kt + 1 .. kt + NST - 2) are still in flight
+            const int y = (nk - 1 - kt) < (NST - 2) ? (nk - 1 - kt) : (NST - 2);
+            if (nine) {
+                if (y >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else if (y == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (y >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (y == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // every wave's pieces of stage kt are in LDS, and every wave is done reading stage kt - 1: its buffer is free
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + NST - 1 < nk) stage_deep(kt + NST - 1, smem + ((kt + NST - 1) % NST) * BUF);
+            const char* As = smem + (kt % NST) * BUF;
+            const char* Bs = As + TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int chunk = ks * 4 + fgrp;
+                frag_t af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wm * 64 + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const frag_t*>(As + ra * KT_BYTES + ((chunk ^ (ra & 7)) << 4));
+                    const int rb = wn * 64 + i * 16 + frow;
+                    bf[i] = *reinterpret_cast<const frag_t*>(Bs + rb * KT_BYTES + ((chunk ^ (rb & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma16<T>::mma(acc[i][j], af[i], bf[j]);
+                if constexpr (RK) {
+                    const frag_t kf = *reinterpret_cast<const frag_t*>(As + 2 * TILE_BYTES + frow * KT_BYTES +
+                                                                       ((chunk ^ (frow & 7)) << 4));
+                    if (wn == 0) { Mma16<T>::mma(tacc[0], af[0], kf); Mma16<T>::mma(tacc[1], af[1], kf); }
+                    else         { Mma16<T>::mma(tacc[0], af[2], kf); Mma16<T>::mma(tacc[1], af[3], kf); }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring is the epilogue's stage from here on
+    }
+    for (int kt = 0; NST == 2 && kt < nk; ++kt) {
         const int cur = kt & 1;
         char* As = smem + cur * BUF;
         char* Bs = As + TILE_BYTES;
@@ -779,18 +866,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     }
 }
 
-template <typename T, bool RK, int FL, bool CV = false, bool VL = false>
+template <typename T, bool RK, int FL, bool CV = false, bool VL = false, int NST = 2>
 int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = nullptr) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int r = (a.flags & FFM_EPI_LORA) ? a.rank : 0;
     int lds = epi_lds_bytes(r, RK);
-    if (lds < 2 * buf_bytes<RK>()) lds = 2 * buf_bytes<RK>();
+    if (lds < NST * buf_bytes<RK>()) lds = NST * buf_bytes<RK>();
     lds += persist_bytes(r, RK);
+    if (lds > 160 * 1024) return FFM_EUNSUP;
     if (lds > 65536) {
         static bool done = false;                     // one per instantiation
         if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL, CV, VL>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, RK, FL, CV, VL, NST>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, NST == 2 ? 80 * 1024 : 160 * 1024);
             if (e != hipSuccess) return (int)e;
             done = true;
         }
@@ -798,7 +886,7 @@ int launch_gemm(const ffm_gemm_args& a, hipStream_t s, const gemm_kargs* conv = 
     gemm_kargs ka;
     if (conv) ka = *conv;
     else { ka.g = a; ka.conv_h = ka.conv_w = ka.conv_c = 0; ka.conv_zero = nullptr; ka.ksplit = 1; ka.part = nullptr; }
-    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV, VL>), dim3(tiles, ka.ksplit > 1 ? ka.ksplit : 1), dim3(256), lds, s, ka);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, RK, FL, CV, VL, NST>), dim3(tiles, ka.ksplit > 1 ? ka.ksplit : 1), dim3(256), lds, s, ka);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -908,8 +996,15 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
         if (rk) return dtype == FFM_BF16 ? launch_gemm<bf16_t, true, -1, false, true>(a, s) : launch_gemm<float, true, -1, false, true>(a, s);
         return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, -1, false, true>(a, s) : launch_gemm<float, false, -1, false, true>(a, s);
     }
-#define FFM_GEMM_CASE(RKB, F) \
-    case F: return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
+    // fewer tiles than CUs and a K loop worth pipelining (16-bit operands): the four-stage ring, one block per CU
+    // (FFM_GEMM_DEEP=0: A/B runs)
+    static const bool deep_on = !(getenv("FFM_GEMM_DEEP") && getenv("FFM_GEMM_DEEP")[0] == '0');
+    const long tiles_ = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const bool deep = deep_on && dtype == FFM_BF16 && tiles_ <= 256 && (size_t)a.K * es / KT_BYTES >= 6;
+#define FFM_GEMM_CASE(RKB, F)                                                                   \
+    case F:                                                                                      \
+        if (deep) return launch_gemm<bf16_t, RKB, F, false, false, 4>(a, s);                     \
+        return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
     if (rk) {
         switch (fl) {
             FFM_GEMM_CASE(true, FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU)                        // c_fc forward
