@@ -75,6 +75,18 @@ struct gemm_kargs {
     float* part;                     // [ksplit][M][N] fp32 partial products (summed by splitk_reduce_kernel)
 };
 
+// One 1 KiB LDS-DMA piece issued from inline asm (M0 = LDS destination, saved and restored in the same statement): hipcc
+// does not see it, so it places no vmcnt(0) in front of the ds_reads that follow - the four-stage ring's waits are counted by hand.
+__device__ __forceinline__ void lds_dma16(const char* src, char* dst) {
+    typedef __attribute__((address_space(3))) char lds_c;
+    const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_c*)dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(d)
+                 : "memory");
+}
+
 // Implicit im2col: the 16-byte chunk a lane fetches for K-tile kt lies in ONE tap (C % chunk == 0); its source is the
 // same channel offset of the neighbouring pixel, or the zero buffer outside the image / beyond tap 8 (K padding).
 // The lane's chunk index (slot ^ rsub) does not depend on the instruction, so (tap, channel) advance once per K-tile.
@@ -96,6 +108,7 @@ struct ConvA {
         tap = kb / cbytes;
         cb = kb % cbytes;
     }
+    template <bool ASM = false>
     __device__ __forceinline__ void stage(const gemm_kargs& k, char* lds_tile, int wave) {
         const char* xb = reinterpret_cast<const char*>(k.g.a);
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -106,9 +119,12 @@ struct ConvA {
             const bool in = tap < 9 && yy >= 0 && yy < k.conv_h && xx >= 0 && xx < k.conv_w;
             const char* src = in ? xb + (size_t)(pix[q] + dy * k.conv_w + dx) * cbytes + cb
                                  : reinterpret_cast<const char*>(k.conv_zero);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds_tile + (wave * 4 + q) * 1024),
-                                             16, 0, 0);
+            if constexpr (ASM)
+                lds_dma16(src, lds_tile + (wave * 4 + q) * 1024);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds_tile + (wave * 4 + q) * 1024),
+                                                 16, 0, 0);
         }
         cb += KT_BYTES;                                          // next K-tile
         const int cbi = k.conv_c * (int)sizeof(T);
@@ -128,7 +144,7 @@ struct ConvA {
 // The DMA of that path is issued from inline asm (hipcc must not see it: it would drain vmcnt(0) in front of every ds_read).
 template <typename T, bool RK, int FL, bool CV = false, bool VL = false, int NST = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
-    static_assert(NST == 2 || (!CV && !VL), "the deep ring serves the plain A / B loaders only");
+    static_assert(NST == 2 || !VL, "the deep ring has no VALU rank-r variant");
     const ffm_gemm_args& p = px.g;
     typedef typename Mma16<T>::frag_t frag_t;
     constexpr int BUF = buf_bytes<RK>();
@@ -178,39 +194,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(gemm_kargs px) {
     };
 
     // deep ring (NST > 2): one stage = this wave's 4 + 4 (+ 1, waves 0 / 1 under RANKOP) pieces of 1 KiB, by asm LDS-DMA
-    auto dma16 = [](const char* src, char* dst) {
-        typedef __attribute__((address_space(3))) char lds_c;
-        const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_c*)dst);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(src), "s"(d)
-                     : "memory");
-    };
-    auto stage_deep = [&](int kt, char* buf) {
+    ConvA<T> cva;
+    auto stage_deep = [&](int kt, char* buf) {                       // (stages are issued in K order: ConvA advances per call)
         const int rsub = lane >> 3, slot = lane & 7, chunk = slot ^ rsub;
         const char* ab = reinterpret_cast<const char*>(A);
         const char* bb = reinterpret_cast<const char*>(B);
+        if constexpr (CV) cva.template stage<true>(px, buf, wave);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int inst = wave * 4 + q, row = inst * 8 + rsub;
             int ga_ = m0 + row, gb_ = n0 + row;
             ga_ = ga_ < p.M ? ga_ : p.M - 1;
             gb_ = gb_ < p.N ? gb_ : p.N - 1;
-            dma16(ab + ((size_t)ga_ * (size_t)p.lda) * sizeof(T) + (size_t)kt * KT_BYTES + chunk * 16, buf + inst * 1024);
-            dma16(bb + ((size_t)gb_ * (size_t)p.ldb) * sizeof(T) + (size_t)kt * KT_BYTES + chunk * 16, buf + TILE_BYTES + inst * 1024);
+            if constexpr (!CV)
+                lds_dma16(ab + ((size_t)ga_ * (size_t)p.lda) * sizeof(T) + (size_t)kt * KT_BYTES + chunk * 16, buf + inst * 1024);
+            lds_dma16(bb + ((size_t)gb_ * (size_t)p.ldb) * sizeof(T) + (size_t)(kt0 + kt) * KT_BYTES + chunk * 16,
+                      buf + TILE_BYTES + inst * 1024);
         }
         if (RK && wave < 2) {
             const int row = wave * 8 + rsub;
-            dma16(reinterpret_cast<const char*>(p.rk) + (size_t)row * (size_t)p.K * sizeof(T) + (size_t)kt * KT_BYTES + (chunk << 4),
-                  buf + 2 * TILE_BYTES + wave * 1024);
+            lds_dma16(reinterpret_cast<const char*>(p.rk) + (size_t)row * (size_t)p.K * sizeof(T) + (size_t)kt * KT_BYTES + (chunk << 4),
+                      buf + 2 * TILE_BYTES + wave * 1024);
         }
     };
 
     // prologue: tile 0 -> buffer 0
-    ConvA<T> cva;
     if constexpr (NST > 2) {
         // (issued behind the epilogue operands' loads and their vmcnt(0) below: the counted waits of the loop see nothing else)
+        if constexpr (CV) cva.init(px, m0, wave, lane, kt0);
     } else if constexpr (CV) {
         cva.init(px, m0, wave, lane, kt0);
         cva.stage(px, smem, wave);
@@ -1303,7 +1314,7 @@ int launch_conv_narrow(const gemm_kargs& ka, hipStream_t s) {
 }
 
 // K slices ffm_conv3x3_nhwc will use (1: one launch with the full epilogue)
-int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_elems) {
+int conv_ksplit_2buf(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_elems) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
     if (!(scratch && tiles < 160 && nk >= 16 && N % 4 == 0)) return 1;
     int S = 512 / tiles;
@@ -1313,6 +1324,27 @@ int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_e
     if (S <= 1) return 1;
     const int per = (nk + S - 1) / S;
     return (nk + per - 1) / per;                                    // no empty slice
+}
+// Round 5: with the four-stage ring a block that has its CU to itself no longer waits out a DMA round trip per K step, so
+// a convolution of few tiles wants at most 256 blocks (one per CU) instead of 512 on two per CU: the split shrinks to what
+// keeps tiles x S <= 256 (layer3: 98 tiles, 3 -> 2 slices; layer4: 52 tiles, 6 -> 4) and the launch takes the deep ring.
+// deep (out): this launch runs the four-stage ring.  FFM_CONV_DEEP=0: the two-buffer plan (A/B runs).
+int conv_ksplit(int M, int N, int Kp, size_t es, bool scratch, int64_t scratch_elems, bool* deep = nullptr) {
+    static const bool deep_on = !(getenv("FFM_CONV_DEEP") && getenv("FFM_CONV_DEEP")[0] == '0');
+    int S = conv_ksplit_2buf(M, N, Kp, es, scratch, scratch_elems);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (int)((size_t)Kp * es / KT_BYTES);
+    bool d = false;
+    if (deep_on && es == 2 && tiles <= 256 && N != 32 && N != 64) {
+        int Sd = S;
+        while (Sd > 1 && tiles * Sd > 256) --Sd;
+        if (Sd > 1) {
+            const int per = (nk + Sd - 1) / Sd;
+            Sd = (nk + per - 1) / per;
+        }
+        if (nk / Sd >= 6) { S = Sd; d = true; }
+    }
+    if (deep) *deep = d;
+    return S;
 }
 }  // namespace
 
@@ -1368,7 +1400,8 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     hipStream_t s = (hipStream_t)stream;
     // Few output tiles and a long K (layer3 / layer4: 14 x 14 and 7 x 7 maps, K = 2304 / 4608): split K over grid.y so
     // that the launch fills the chip; the fp32 partial tiles are summed by one more small kernel.
-    const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems);
+    bool deep = false;
+    const int S = conv_ksplit(a.M, a.N, Kp, es, splitk_scratch != nullptr, scratch_elems, &deep);
     if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
     a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: the sums leave with the reduction below)
     const bool bnb = bn_x != nullptr;                              // FFM_EPI_BNBWD (split over K: in the reduction below)
@@ -1387,8 +1420,12 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
         if (a.N == 32) return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 32>(ka, s) : launch_conv_narrow<float, 32>(ka, s);
         return dtype == FFM_BF16 ? launch_conv_narrow<bf16_t, 64>(ka, s) : launch_conv_narrow<float, 64>(ka, s);
     }
-    if (bnb && S == 1) return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true>(a, s, &ka) : launch_gemm<float, false, FFM_EPI_BNBWD, true>(a, s, &ka);
-    const int e = dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
+    if (bnb && S == 1) {
+        if (deep && dtype == FFM_BF16) return launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true, false, 4>(a, s, &ka);
+        return dtype == FFM_BF16 ? launch_gemm<bf16_t, false, FFM_EPI_BNBWD, true>(a, s, &ka) : launch_gemm<float, false, FFM_EPI_BNBWD, true>(a, s, &ka);
+    }
+    const int e = (deep && dtype == FFM_BF16) ? launch_gemm<bf16_t, false, 0, true, false, 4>(a, s, &ka)
+                  : dtype == FFM_BF16 ? launch_gemm<bf16_t, false, 0, true>(a, s, &ka) : launch_gemm<float, false, 0, true>(a, s, &ka);
     if (e || ka.ksplit <= 1) return e;
     const size_t total = (size_t)a.M * a.N, total4 = total / 4;
     if (colstat_part && splitk_cs_ok(a.M, a.N)) {
