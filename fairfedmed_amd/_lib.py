@@ -19,7 +19,7 @@ F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the refer
 F32_X3_W16 = 4                           # FFM_F32_X3 with the weight operand stored as IEEE half
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
 EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD, EPI_BNBWD = 128, 256, 512, 1024
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "ffm_sgd_momentum_n": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
     "ffm_sgd_momentum_dev": [_vp, _vp, _vp, _i64, _vp, _vp],
     "ffm_scale_by": [_vp, _vp, _vp, _i64, _vp],
+    "ffm_scale_acc": [_vp, _vp, _vp, _i64, _vp],
     "ffm_fedavg_finish": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "ffm_cast_f32_to": [_vp, _vp, _i64, _i32, _vp],
     "ffm_cast_to_f32": [_vp, _vp, _i64, _i32, _vp],

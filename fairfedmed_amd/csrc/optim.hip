@@ -58,6 +58,14 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__
         out[i] = p[i] * w[i];
 }
 
+// a rank that holds several clients of a round: acc += p (.) w, product and sum rounded separately (no FMA), as the
+// reference's `w_avg[key] += w[idx][key] * weight` (utils/fed_utils.py:79-86) rounds them
+__global__ __launch_bounds__(256) void scale_acc_kernel(const float* __restrict__ p, const float* __restrict__ w,
+                                                        float* __restrict__ acc, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc[i] = __fadd_rn(acc[i], __fmul_rn(p[i], w[i]));
+}
+
 // utils/fed_utils.py:88-98: optional shared_half_s, then EMA with the previous global
 __global__ __launch_bounds__(256) void shared_half_kernel(float* __restrict__ avg, const int64_t* __restrict__ offs,
                                                           int n_s, int G, int r) {
@@ -73,8 +81,9 @@ __global__ __launch_bounds__(256) void shared_half_kernel(float* __restrict__ av
     }
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(const float* __restrict__ avg, const float* __restrict__ prev,
-                                                  float* __restrict__ out, int64_t n, float beta) {
+// (prev and out may be the same buffer: the aggregator updates its global weights in place)
+__global__ __launch_bounds__(256) void ema_kernel(const float* __restrict__ avg, const float* prev, float* out, int64_t n,
+                                                  float beta) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (1.0f - beta) * avg[i] + beta * prev[i];
 }
@@ -159,6 +168,13 @@ extern "C" int ffm_sgd_momentum_dev(float* p, const float* g, float* buf, int64_
 extern "C" int ffm_scale_by(const float* p, const float* w, float* out, int64_t n, void* stream) {
     if (!p || !w || !out || n <= 0) return FFM_EINVAL;
     hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, w, out, n);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_scale_acc(const float* p, const float* w, float* acc, int64_t n, void* stream) {
+    if (!p || !w || !acc || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(scale_acc_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, w, acc, n);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

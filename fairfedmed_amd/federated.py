@@ -192,8 +192,12 @@ def run_fedotplora(trainer, args: FedArgs, attribute: Optional[str] = None, log=
 def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None, log=print) -> Dict[str, list]:
     """One process per GPU.  Round r: client idxs_users[j] trains on rank j % world; every rank then contributes
     sum_k w_k (.) theta_k of ITS clients to one all-reduce of the flat trainable buffer (RCCL over xGMI, gloo on
-    CPU), and finishes shared_half_s + EMA locally.  Frozen tensors are identical on all ranks and stay put."""
-    from .fedavg import element_weights
+    CPU), and finishes shared_half_s + EMA locally.  Frozen tensors are identical on all ranks and stay put.
+
+    The round boundary IS ``fedavg.FedAvgAggregator`` (utils/fed_utils.py:42-100): device-resident cached weight vectors,
+    ffm_scale_by / ffm_scale_acc -> one all_reduce -> ffm_fedavg_finish on the GPU - the same object ``bench.py --gpus N``
+    times.  RN50's BatchNorm buffers go through a second instance of it (plain n_k / sum n weights, no lora_S blocks)."""
+    from .fedavg import FedAvgAggregator
     assert dist.is_initialized(), "launch under torch.distributed.run"
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = trainer.cfg
@@ -206,7 +210,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     flat, offsets = params.flat, params.offsets
     lo = trainer.engine.cfg.lora
     trainer.fed_before_train()
-    global_flat = flat.detach().clone()
+    agg = FedAvgAggregator(flat, offsets, lo.num_groups, lo.rank, shared_half_s=args.shared_half_s, beta=0.999)
+    global_flat = agg.global_prev                                    # updated in place by agg.finish()
     per_client = {i: global_flat.clone() for i in range(users)}      # personalised flat buffers (this rank's view)
     ctx_off, ctx_shape = offsets["prompt_learner.ctx"]
     n_ctx_row = int(np.prod(ctx_shape[1:]))
@@ -217,7 +222,8 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     # entry, with the plain n_k / sum n weights; they ride in a second, small all-reduce
     eng = trainer.engine
     has_buf = hasattr(eng, "buffers_flat")
-    global_buf = eng.buffers_flat() if has_buf else None
+    agg_buf = FedAvgAggregator(eng.buffers_flat(), {}, lo.num_groups, lo.rank, shared_half_s=False, beta=0.999) if has_buf else None
+    global_buf = agg_buf.global_prev if has_buf else None
     per_client_buf = {i: global_buf.clone() for i in range(users)} if has_buf else None
     # LR schedule: the reference's ONE scheduler advances by (local epochs x registered names) per trained client, in
     # client order, whichever process trains it.  Every rank therefore positions its scheduler from the GLOBAL count of
@@ -232,9 +238,9 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         pick = [select_clients(epoch, args, users) if rank == 0 else None]
         dist.broadcast_object_list(pick, src=0)
         idxs_users = [int(u) for u in pick[0]]
-        acc = torch.zeros_like(flat)
-        acc_buf = torch.zeros_like(global_buf) if has_buf else None
-        total = sum(n_client[int(u)] for u in idxs_users)
+        agg.begin()
+        if has_buf:
+            agg_buf.begin()
         local_after: Dict[int, Tensor] = {}
         for j, idx in enumerate(idxs_users):
             mine = j % world == rank
@@ -245,11 +251,11 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
                 if can_position:
                     trainer.set_lr_epoch(sched_pos + j * per_client_epochs)
                 trainer.train(idx=idx, global_epoch=epoch, is_fed=True, is_last_client=idx == idxs_users[-1])
-                local_after[idx] = flat.detach().clone()
-                w = element_weights(offsets, flat.numel(), idx, idxs_users, n_client, by_attr).to(flat.device)
-                acc += w * flat
+                if args.idxs_users_train:
+                    local_after[idx] = flat.detach().clone()
+                agg.add(flat, idx, idxs_users, n_client, by_attr)
                 if has_buf:
-                    acc_buf += eng.buffers_flat() * (n_client[int(idx)] / total)
+                    agg_buf.add(eng.buffers_flat(), idx, idxs_users, n_client, None)
             if args.compat_sequential_optimizer and world > 1:
                 # hand the shared optimizer on: the next client (on whichever rank) starts from this one's momentum
                 # buffers, first-step flag, StepLR counter and learning rate
@@ -261,19 +267,11 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         if can_position:
             sched_pos += len(idxs_users) * per_client_epochs
             trainer.set_lr_epoch(sched_pos)
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        # one all_reduce(SUM) of the flat buffer, shared_half_s under the reference's guard (utils/fed_utils.py:90),
+        # EMA with the previous global: global_flat / global_buf are updated in place
+        agg.finish(epoch, args.round, grouped=by_attr is not None)
         if has_buf:
-            dist.all_reduce(acc_buf, op=dist.ReduceOp.SUM)
-        if args.shared_half_s and by_attr is not None:               # utils/fed_utils.py:90 (same guard as the weights)
-            G, r = lo.num_groups, lo.rank
-            for k, (off, shp) in offsets.items():
-                if is_group_s_block(k, shp, G):
-                    blk = acc[off:off + G * r].view(G, r)
-                    blk[:, : r // 2] = blk[:, : r // 2].mean(0, keepdim=True)
-        beta_decay = 0.999 * (epoch / max(args.round, 1))
-        global_flat = (1 - beta_decay) * acc + beta_decay * global_flat
-        if has_buf:
-            global_buf = (1 - beta_decay) * acc_buf + beta_decay * global_buf
+            agg_buf.finish(epoch, args.round, grouped=False)
         # personalisation needs every trained client's local prompts / lora_S on every rank that may test it:
         # exchange them (a few KB) with one more all-reduce of a zero-padded buffer
         keep = torch.zeros(users, flat.numel(), device=flat.device) if args.idxs_users_train else None
@@ -286,7 +284,7 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
         for idx in all_users:
             per_client[idx] = global_flat.clone()
             if has_buf:
-                per_client_buf[idx] = global_buf
+                per_client_buf[idx] = global_buf.clone()
             if idx in args.idxs_users_train and keep is not None:
                 per_client[idx][lo_a:lo_b] = keep[idx][lo_a:lo_b]
                 if args.local_s:
@@ -313,9 +311,9 @@ def run_fedotplora_ranks(trainer, args: FedArgs, attribute: Optional[str] = None
     flat.copy_(global_flat)
     if has_buf:
         eng.load_buffers_flat(global_buf)
-        hist["global_buffers"] = global_buf
+        hist["global_buffers"] = global_buf.clone()
     trainer.fed_after_train()
-    hist["global_flat"] = global_flat
+    hist["global_flat"] = global_flat.clone()
     # the per-client weights the reference saves as global_client{idx}_final.pth (federated_main.py:771-774), rebuilt
     # from the flat buffers (every rank holds all of them: personalised pieces were exchanged above)
     lwp = {}

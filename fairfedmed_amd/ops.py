@@ -753,6 +753,12 @@ def scale_by(p: Tensor, w: Tensor, out: Tensor) -> None:
     _call("ffm_scale_by", L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(out)), p.numel(), L.stream_ptr())
 
 
+def scale_acc(p: Tensor, w: Tensor, acc: Tensor) -> None:
+    """acc += p * w, product and sum rounded separately (ffm_scale_acc)."""
+    _dev(p, w, acc)
+    _call("ffm_scale_acc", L.ptr(_f32(p)), L.ptr(_f32(w)), L.ptr(_f32(acc)), p.numel(), L.stream_ptr())
+
+
 def scale_check(p: Tensor, scale: float, finite: Optional[Tensor] = None) -> None:
     """p *= scale in place; clears the int32 flag when a product is not finite (ffm_scale_check)."""
     _dev(p, finite)

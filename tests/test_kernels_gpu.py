@@ -611,6 +611,11 @@ def test_fedavg_helpers(ops):
     out = torch.empty(n, device="cuda")
     ops.scale_by(p, w, out)
     assert torch.allclose(out, p * w)
+    # the second client of a rank: acc += p2 * w2 with the product and the sum rounded separately (bit-exact vs torch)
+    p2, w2 = rnd(n, seed=44), torch.rand(n, device="cuda")
+    ref_acc = out + p2 * w2
+    ops.scale_acc(p2, w2, out)
+    assert torch.equal(out, ref_acc)
     avg, prev = rnd(n, seed=41), rnd(n, seed=42)
     offs = torch.tensor([100, 500], device="cuda", dtype=torch.int64)
     ref = avg.clone()
@@ -621,6 +626,10 @@ def test_fedavg_helpers(ops):
     res = torch.empty(n, device="cuda")
     ops.fedavg_finish(avg, prev, res, offs, G, r, True, 0.3)
     check(res, ref, 1e-6, "fedavg_finish")
+    # in place on the previous global (what FedAvgAggregator.finish does): same values
+    prev2 = prev.clone()
+    ops.fedavg_finish(avg.clone(), prev2, prev2, offs, G, r, True, 0.3)
+    assert torch.equal(prev2, res)
 
 
 def test_casts(ops):
