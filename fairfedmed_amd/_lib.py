@@ -115,6 +115,9 @@ SIGNATURES = {
     "ffm_sgd_momentum": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "ffm_sgd_momentum_n": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp],
     "ffm_sgd_momentum_dev": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "ffm_loss_scale": [_vp, _i64, _vp, _vp],
+    "ffm_unscale_check": [_vp, _i64, _vp, _vp],
+    "ffm_sgd_momentum_gated": [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _i32, _vp, _vp],
     "ffm_scale_by": [_vp, _vp, _vp, _i64, _vp],
     "ffm_scale_acc": [_vp, _vp, _vp, _i64, _vp],
     "ffm_fedavg_finish": [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],

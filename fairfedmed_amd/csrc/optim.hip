@@ -136,6 +136,63 @@ __global__ __launch_bounds__(256) void scale_check_kernel(float* __restrict__ p,
     if (finite_flag && __any(bad) && (threadIdx.x & 63) == 0) *finite_flag = 0;
 }
 
+// IEEE-half mode, dynamic gradient scale held in DEVICE memory so that recorded launch plans / captured graphs stay valid
+// while it changes: st = {scale, 1/scale, ok, good_run, overflows, max_scale, growth_interval, min_scale} (floats).
+// A step is  loss_scale(dlogits) -> backward -> unscale_check(grad) -> sgd_gated -> scale_update.
+__global__ __launch_bounds__(256) void loss_scale_kernel(float* __restrict__ p, int64_t n, float* __restrict__ st) {
+    const float sc = st[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] *= sc;
+    // (ok is read by kernels behind this one in stream order only; every block has read st[0] from a different word)
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[2] = 1.0f;
+}
+
+__global__ __launch_bounds__(256) void unscale_check_kernel(float* __restrict__ p, int64_t n, float* __restrict__ st) {
+    const float inv = st[1];
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = p[i] * inv;
+        p[i] = v;
+        bad |= !(fabsf(v) <= 3.4028234e38f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) st[2] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void sgd_gated_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ buf, int64_t n, float lr, float mu, float wd,
+                                                        int first, int repeats, const float* __restrict__ st) {
+    if (st[2] == 0.0f) return;                    // the gradients overflowed: the step is skipped, momentum untouched
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pi = p[i];
+        const float gi = g[i];
+        float b = first ? 0.f : buf[i];
+        for (int k = 0; k < repeats; ++k) {
+            const float d = gi + wd * pi;
+            b = (first && k == 0) ? d : mu * b + d;
+            pi = pi - lr * b;
+        }
+        buf[i] = b;
+        p[i] = pi;
+    }
+}
+
+__global__ void scale_update_kernel(float* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sc = st[0];
+    if (st[2] == 0.0f) {                          // overflow: halve (torch.cuda.amp.GradScaler's backoff), count it
+        sc = fmaxf(sc * 0.5f, st[7]);
+        st[3] = 0.0f;
+        st[4] += 1.0f;
+    } else {
+        st[3] += 1.0f;
+        if (st[6] > 0.0f && st[3] >= st[6] && sc < st[5]) {
+            sc = fminf(sc * 2.0f, st[5]);
+            st[3] = 0.0f;
+        }
+    }
+    st[0] = sc;
+    st[1] = 1.0f / sc;
+}
+
 }  // namespace
 
 extern "C" int ffm_abi_version(void) { return FFM_ABI_VERSION; }
@@ -182,6 +239,31 @@ extern "C" int ffm_scale_acc(const float* p, const float* w, float* acc, int64_t
 extern "C" int ffm_scale_check(float* p, float scale, int64_t n, int32_t* finite_flag, void* stream) {
     if (!p || n <= 0) return FFM_EINVAL;
     hipLaunchKernelGGL(scale_check_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, scale, n, finite_flag);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_loss_scale(float* p, int64_t n, float* state, void* stream) {
+    if (!p || !state || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(loss_scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, state);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_unscale_check(float* g, int64_t n, float* state, void* stream) {
+    if (!g || !state || n <= 0) return FFM_EINVAL;
+    hipLaunchKernelGGL(unscale_check_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, state);
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
+extern "C" int ffm_sgd_momentum_gated(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                                      float weight_decay, int first_step, int repeats, float* state, void* stream) {
+    if (!p || !g || !buf || !state || n <= 0 || repeats < 1 || repeats > 16) return FFM_EINVAL;
+    hipLaunchKernelGGL(sgd_gated_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum,
+                       weight_decay, first_step, repeats, state);
+    FFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }

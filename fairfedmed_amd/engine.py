@@ -272,18 +272,27 @@ class FairLoRAEngine:
 
     @property
     def grad_scale(self) -> float:
-        """fp16 mode: factor on dloss/dlogits in front of the backward pass, taken out of the fp32 gradients behind it
-        (FFM_F16_GRAD_SCALE, default 4096; 1.0 in the other storage types)."""
-        return self._grad_scale
+        """fp16 mode: the factor on dloss/dlogits in front of the backward pass, taken out of the fp32 gradients behind it.
+        It lives in DEVICE memory (``scale_state``, ffm_loss_scale in include/ffm_hip.h) and moves by itself: an overflowed
+        backward pass skips its SGD step and halves it.  Reading it synchronises; 1.0 in the other storage types."""
+        return float(self.scale_state[0]) if self.scale_state is not None else 1.0
 
     @grad_scale.setter
     def grad_scale(self, value: float) -> None:
         value = float(value)
         if not (value > 0.0) or value != value or value == float("inf"):
             raise ValueError(f"grad_scale must be a positive finite number, got {value!r}")
-        if value != getattr(self, "_grad_scale", value) and hasattr(self, "step_plans"):
-            self.step_plans.clear()                   # the recorded launches hold the old factor
-        self._grad_scale = value
+        if self.scale_state is None:
+            if value != 1.0:
+                raise ValueError("grad_scale exists in the IEEE-half mode only")
+            return
+        # recorded plans read the scale through the state's address: nothing to re-record
+        self.scale_state[:2].copy_(torch.tensor([value, 1.0 / value]))
+        self.scale_state[5:6].fill_(max(value, float(self.scale_state[5])))
+
+    def overflow_steps(self) -> int:
+        """fp16 mode: training steps skipped so far because their scaled gradients left half's range (host sync)."""
+        return int(self.scale_state[4]) if self.scale_state is not None else 0
 
     def __init__(self, cfg: ModelCfg, state_dict: Dict[str, Tensor], dtype=torch.bfloat16, max_images: int = 32,
                  device: str = "cuda:0"):
@@ -339,12 +348,17 @@ class FairLoRAEngine:
         self.loss = torch.zeros(1, device=dev, dtype=f32)
         self.finite = torch.ones(1, device=dev, dtype=torch.int32)
         # IEEE-half storage: dloss/dlogits is scaled by 2^k before the backward pass (every backward kernel is linear in
-        # the incoming gradient) and the factor comes out of the fp32 gradient buffer in front of the SGD step, with the
-        # finite flag as the overflow guard.  Unscaled, the 16-bit activation gradients of ViT-B/16 sit in half's
-        # subnormals (2.8 % error on the lora_S gradient norms at batch 8; 0.3 % scaled: tests/test_engine_gpu.py).
-        # (a property: the scale-up is captured in the recorded step plans, the unscale reads the live value - changing it
-        # drops the recorded plans, so that a caller's own loss scaler cannot leave the two apart)
-        self._grad_scale = float(os.environ.get("FFM_F16_GRAD_SCALE", "4096")) if dtype == torch.float16 else 1.0
+        # the incoming gradient) and the factor comes out of the fp32 gradient buffer in front of the SGD step.  Unscaled,
+        # the 16-bit activation gradients of ViT-B/16 sit in half's subnormals (2.8 % error on the lora_S gradient norms
+        # at batch 8; 0.3 % scaled: tests/test_engine_gpu.py).  Round 6: the scale is DYNAMIC and device-resident
+        # (ops.loss_scale / unscale_check / sgd_momentum_gated): a backward pass whose scaled gradients overflow skips its
+        # SGD step and halves the scale - no host sync, recorded plans stay valid - instead of raising; after
+        # FFM_F16_GROWTH_INTERVAL (2000) good steps it doubles again, up to the initial value FFM_F16_GRAD_SCALE (4096).
+        self.scale_state = None
+        if dtype == torch.float16:
+            s0 = float(os.environ.get("FFM_F16_GRAD_SCALE", "4096"))
+            self.scale_state = torch.tensor([s0, 1.0 / s0, 1.0, 0.0, 0.0, s0, float(os.environ.get("FFM_F16_GROWTH_INTERVAL", "2000")), 1.0],
+                                            device=dev, dtype=f32)
         self.dtbar = torch.zeros(cfg.n_cls, v.out_dim, device=dev, dtype=f32)
         self.attr_i32 = torch.zeros(max_images, device=dev, dtype=torch.int32)
         self.label_buf = torch.zeros(max_images, device=dev, dtype=torch.int64)
@@ -1037,8 +1051,8 @@ class FairLoRAEngine:
             self._pack_event = None
         ops.ce_loss(self.logits_img, self.label_buf, self.logits, self.prob, self.loss, self.dlogits_img,
                     self.finite, b, S, cfg.n_cls)
-        if self.grad_scale != 1.0:
-            ops.scale_check(self.dlogits_img[:b * S], self.grad_scale)
+        if self.scale_state is not None:
+            ops.loss_scale(self.dlogits_img[:b * S], self.scale_state)
         self._head_backward(rows, images, L)
         self._ev_record(self.ev_head_bwd, main)
         self._ev_wait(self.side, self.ev_head_bwd)
@@ -1082,8 +1096,8 @@ class FairLoRAEngine:
                 assert self.params.offsets["proj_per_3d_slice.bias"][0] == off + nw - 3
                 nblk = ops.slice_wgrad_blocks(self.cfg.vision.image_size, self.cfg.vision.image_size)
                 ops.reduce_partials(self.wpart, images * nblk, nw, self.params.grad[off:off + nw])
-            if self.grad_scale != 1.0:
-                ops.scale_check(self.params.grad, 1.0 / self.grad_scale, self.finite)
+            if self.scale_state is not None:
+                ops.unscale_check(self.params.grad, self.scale_state)
         out = {"loss": self.loss, "logits": self.logits[:b], "prob": self.prob[:b], "finite": self.finite}
         if self._counts_buf is not None:
             out["counts"] = self._counts_buf          # ffm_eval_counts of (prob, label): rows {unknown, all}
@@ -1093,7 +1107,10 @@ class FairLoRAEngine:
     def sgd_step(self, lr: float, momentum: float, weight_decay: float, repeats: int = 1) -> None:
         """optim.step(), `repeats` times on the gradients of the last forward_backward (one launch)."""
         p = self.params
-        ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0, repeats)
+        if self.scale_state is not None:                # fp16: skipped when the gradients overflowed; the scale then halves
+            ops.sgd_momentum_gated(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0, repeats, self.scale_state)
+        else:
+            ops.sgd_momentum(p.flat, p.grad, p.momentum, lr, momentum, weight_decay, p.steps == 0, repeats)
         p.steps += repeats
 
     def enable_step_counts(self, on: bool = True) -> None:

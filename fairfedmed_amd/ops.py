@@ -742,6 +742,31 @@ def sgd_momentum(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, 
               weight_decay, int(first_step), int(repeats), L.stream_ptr())
 
 
+SCALE_STATE = 8     # floats of the fp16 gradient-scale state (include/ffm_hip.h: ffm_loss_scale)
+
+
+def loss_scale(p: Tensor, state: Tensor) -> None:
+    """p *= state[0] (the device-resident gradient scale); marks the step as good (ffm_loss_scale)."""
+    _dev(p, state)
+    assert p.is_contiguous() and state.numel() == SCALE_STATE
+    _call("ffm_loss_scale", L.ptr(_f32(p)), p.numel(), L.ptr(_f32(state)), L.stream_ptr())
+
+
+def unscale_check(g: Tensor, state: Tensor) -> None:
+    """g *= 1 / scale; a non-finite gradient marks the step as overflowed (ffm_unscale_check)."""
+    _dev(g, state)
+    assert g.is_contiguous() and state.numel() == SCALE_STATE
+    _call("ffm_unscale_check", L.ptr(_f32(g)), g.numel(), L.ptr(_f32(state)), L.stream_ptr())
+
+
+def sgd_momentum_gated(p: Tensor, g: Tensor, buf: Tensor, lr: float, momentum: float, weight_decay: float,
+                       first_step: bool, repeats: int, state: Tensor) -> None:
+    """sgd_momentum unless the step overflowed (then nothing moves); afterwards the scale backs off / grows."""
+    _dev(p, g, buf, state)
+    _call("ffm_sgd_momentum_gated", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), lr, momentum,
+          weight_decay, int(first_step), int(repeats), L.ptr(_f32(state)), L.stream_ptr())
+
+
 def sgd_momentum_dev(p: Tensor, g: Tensor, buf: Tensor, hp: Tensor) -> None:
     _dev(p, g, buf, hp)
     _call("ffm_sgd_momentum_dev", L.ptr(_f32(p)), L.ptr(_f32(g)), L.ptr(_f32(buf)), p.numel(), L.ptr(_f32(hp)),

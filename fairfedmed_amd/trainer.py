@@ -370,11 +370,9 @@ class GLP_OT_SVLoRA:
     def check_finite(self) -> None:
         if int(self._finite_acc) != 1:
             self._finite_acc.fill_(1)
-            hint = ""
-            if getattr(self.engine, "grad_scale", 1.0) != 1.0:       # fp16: the static gradient scale may have overflowed
-                hint = (f" (PREC fp16: gradients are scaled by {self.engine.grad_scale:g} - FFM_F16_GRAD_SCALE or "
-                        "engine.grad_scale lowers it)")
-            raise FloatingPointError("Loss is infinite or NaN!" + hint)   # Dassl/dassl/engine/trainer.py:260-262
+            # (a LOSS that is not finite, as in the reference.  fp16 GRADIENT overflow does not come here: the engine skips
+            # that step and halves its device-resident gradient scale - engine.overflow_steps() counts them)
+            raise FloatingPointError("Loss is infinite or NaN!")      # Dassl/dassl/engine/trainer.py:260-262
 
     def train(self, idx=-1, global_epoch=0, is_fed=False, is_last_client=False, **_):
         self.time_start = time.time()

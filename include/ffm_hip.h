@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 12  /* 12: ffm_scale_acc; 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 12  /* 12: ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -540,6 +540,25 @@ int ffm_sgd_momentum_n(float* p, const float* g, float* buf, int64_t n, float lr
  * step; the flag is the overflow guard (Dassl/dassl/engine/trainer.py:260-262 raises on the host from it).
  */
 int ffm_scale_check(float* p, float scale, int64_t n, int32_t* finite_flag, void* stream);
+
+/*
+ * IEEE-half mode (PREC="fp16"): a DYNAMIC gradient scale that lives in device memory, so that recorded launch plans and
+ * captured graphs stay valid while it changes.  state = 8 floats {scale, 1/scale, ok, good_run, overflows, max_scale,
+ * growth_interval, min_scale}.  One training step is
+ *   ffm_loss_scale(dlogits)      dlogits *= scale; ok = 1
+ *   ... backward ...
+ *   ffm_unscale_check(grad)      grad *= 1/scale; any non-finite entry clears ok
+ *   ffm_sgd_momentum_gated(...)  the ffm_sgd_momentum_n update, skipped entirely when ok == 0; then the scale moves:
+ *                                overflow -> scale = max(scale / 2, min_scale), overflows += 1, good_run = 0;
+ *                                otherwise good_run += 1 and after growth_interval (> 0) good steps scale = min(2 scale, max_scale).
+ * The reference's fp16 run has no scaler (model_backward_and_update, Dassl/dassl/engine/trainer.py:323-342): an overflowed
+ * backward pass poisons its weights and the next loss raises; here the step is skipped and training goes on, as
+ * torch.cuda.amp.GradScaler does for the reference's PREC="amp" (trainers/GLP_OT_SVLoRA.py:889-898).
+ */
+int ffm_loss_scale(float* p, int64_t n, float* state, void* stream);
+int ffm_unscale_check(float* g, int64_t n, float* state, void* stream);
+int ffm_sgd_momentum_gated(float* p, const float* g, float* buf, int64_t n, float lr, float momentum,
+                           float weight_decay, int first_step, int repeats, float* state, void* stream);
 
 /* The same update with {lr, momentum, weight_decay} read from DEVICE memory (hp[3]) and a momentum buffer
  * that starts at zero: safe to capture in a hipGraph while the LR schedule changes lr between replays. */

@@ -241,10 +241,11 @@ def test_prec_amp_trains_without_the_attribute():
 
 def test_fp16_gradient_scale_and_overflow_guard():
     """IEEE-half mode: the backward pass runs scaled (x 2^12 on dloss/dlogits, out again on the fp32 gradient buffer:
-    ffm_scale_check).  (1) the scale leaves no trace in the result: 2^12 and 2^8 give the same gradients to rounding, and no
-    scale at all is visibly worse against the oracle on the smallest gradients (half's subnormals) - never better;
-    (2) an absurd scale overflows half, the unscaled buffer holds inf / nan, and the device-side finite flag is cleared, which
-    the trainer raises as the reference's FloatingPointError (Dassl/dassl/engine/trainer.py:260-262)."""
+    ffm_loss_scale / ffm_unscale_check).  (1) the scale leaves no trace in the result: 2^12 and 2^8 give the same gradients
+    to rounding, and no scale at all is visibly worse against the oracle on the smallest gradients (half's subnormals) -
+    never better; (2) an absurd scale overflows half: the step is marked, its SGD update is SKIPPED (weights and momentum
+    bit-identical to before), the scale halves, and the loss flag stays clean - training goes on (round 6; the reference
+    has no scaler: Dassl/dassl/engine/trainer.py:339-342)."""
     from fairfedmed_amd.engine import FairLoRAEngine
     from oracle import fairlora_oracle as O
     mcfg = C.vit_tiny(rank=4)
@@ -259,11 +260,11 @@ def test_fp16_gradient_scale_and_overflow_guard():
         eng.grad_scale = float(scale)
         out = eng.forward_backward(img, attr, label)
         torch.cuda.synchronize()
-        return int(out["finite"]), {k: eng.params.view(k, "grad").clone() for k in keys}
+        return eng, int(out["finite"]), {k: eng.params.view(k, "grad").clone() for k in keys}
 
-    f12, g12 = run(4096.0)
-    f8, g8 = run(256.0)
-    f0, g0 = run(1.0)
+    _, f12, g12 = run(4096.0)
+    _, f8, g8 = run(256.0)
+    _, f0, g0 = run(1.0)
     assert f12 == 1 and f8 == 1 and f0 == 1
     worst = {1.0: 0.0, 256.0: 0.0, 4096.0: 0.0}
     for k in keys:
@@ -275,30 +276,67 @@ def test_fp16_gradient_scale_and_overflow_guard():
             worst[s] = max(worst[s], rel(g[k], ref))
     print("fp16 worst gradient error vs the oracle by scale:", worst)
     assert worst[4096.0] <= worst[1.0] * 1.05 + 1e-6 and worst[4096.0] < 1e-2
-    fbad, gbad = run(2.0 ** 40)
-    assert fbad == 0, "an overflowing gradient scale must clear the finite flag"
+    eng, fbad, gbad = run(2.0 ** 40)
+    assert fbad == 1, "the loss itself is finite: only the gradient overflowed"
     assert not all(bool(torch.isfinite(g).all()) for g in gbad.values())
+    assert float(eng.scale_state[2]) == 0.0, "an overflowing gradient scale must mark the step"
+    before = (eng.params.flat.clone(), eng.params.momentum.clone())
+    eng.sgd_step(1e-2, 0.9, 5e-4, repeats=2)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params.flat, before[0]) and torch.equal(eng.params.momentum, before[1]), "the overflowed step must be skipped"
+    assert eng.grad_scale == 2.0 ** 39 and eng.overflow_steps() == 1
 
 
-def test_fp16_gradient_scale_changed_after_the_plan_was_recorded():
-    """The scale-up sits inside the recorded launch plan, the unscale reads the live value: assigning engine.grad_scale after
-    the first step (what any dynamic loss scaler does) drops the recorded plans, so the two can never be apart - the
-    gradients after the change equal those of an engine that ran on the new scale from the start."""
+def test_fp16_overflow_recovers_by_halving_the_device_resident_scale():
+    """An injected overflow (scale 2^30 on a tower whose gradients then leave half's range) is skipped step after step, the
+    scale halving each time from DEVICE memory - the recorded launch plan is never re-recorded - until the backward pass
+    fits; from there on training moves the weights and the trajectory equals that of an engine that started on the scale
+    the first one arrived at."""
     from fairfedmed_amd.engine import FairLoRAEngine
     mcfg = C.vit_tiny(rank=4)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
     batch = synth.make_batch(mcfg, 8, seed=1234)
     img, attr, label = batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
     a = FairLoRAEngine(mcfg, sd, dtype=torch.float16, max_images=8)
-    a.forward_backward(img, attr, label)                    # records the plan on the default 4096
-    assert a.step_plans
-    a.grad_scale = 256.0
-    assert not a.step_plans
-    a.forward_backward(img, attr, label)
+    a.grad_scale = 2.0 ** 30
+    start = a.params.flat.clone()
+    plans, skipped = None, 0
+    for step in range(40):
+        out = a.forward_backward(img, attr, label)
+        plans = plans or dict(a.step_plans)
+        a.sgd_step(1e-2, 0.9, 5e-4, repeats=2)
+        assert int(out["finite"]) == 1
+        if torch.equal(a.params.flat, start):
+            skipped += 1
+        else:
+            break
+    assert 0 < skipped < 40 and a.overflow_steps() == skipped, (skipped, a.overflow_steps())
+    assert a.step_plans == plans, "the plan recorded at the first step is still the one replayed"
+    assert a.grad_scale == 2.0 ** (30 - skipped)
     b = FairLoRAEngine(mcfg, sd, dtype=torch.float16, max_images=8)
-    b.grad_scale = 256.0
+    b.grad_scale = a.grad_scale
     b.forward_backward(img, attr, label)
+    b.sgd_step(1e-2, 0.9, 5e-4, repeats=2)
     torch.cuda.synchronize()
-    assert torch.equal(a.params.grad, b.params.grad)
+    assert b.overflow_steps() == 0 and torch.equal(a.params.flat, b.params.flat)
     with pytest.raises(ValueError):
         a.grad_scale = 0.0
+
+
+def test_fp16_trainer_keeps_training_through_an_injected_overflow():
+    """Through the trainer: one absurd scale in the middle of a local epoch costs the skipped steps and nothing else - no
+    FloatingPointError, finite weights at the end, the loss flag untouched."""
+    from fairfedmed_amd.registry import build_trainer
+    from fairfedmed_amd.trainer import SyntheticFedData
+    import fairfedmed_amd.trainer  # noqa: F401
+    from tests.test_trainer_gpu import make_cfg
+    mcfg = C.vit_tiny(rank=4)
+    cfg = make_cfg(prec="fp16", bs=8)
+    cfg.DATA = SyntheticFedData(mcfg, 1, train_batches=6, test_batches=1, batch_size=8)
+    cfg.MODEL.STATE_DICT = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    tr = build_trainer(cfg)
+    tr.engine.grad_scale = 2.0 ** 22
+    tr.train(idx=0, global_epoch=0, is_fed=True, is_last_client=True)
+    torch.cuda.synchronize()
+    assert tr.engine.overflow_steps() >= 1 and bool(torch.isfinite(tr.engine.params.flat).all())
+    assert tr.engine.grad_scale < 2.0 ** 22
