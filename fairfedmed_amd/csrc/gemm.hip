@@ -1014,7 +1014,10 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     const bool deep = deep_on && dtype == FFM_BF16 && tiles_ <= 256 && (size_t)a.K * es / KT_BYTES >= 6;
 #define FFM_GEMM_CASE(RKB, F)                                                                   \
     case F:                                                                                      \
-        if (deep) return launch_gemm<bf16_t, RKB, F, false, false, 4>(a, s);                     \
+        if (deep) {                          /* (its LDS need exceeds 160 KB for this rank / epilogue: two-buffer loop) */ \
+            const int e4 = launch_gemm<bf16_t, RKB, F, false, false, 4>(a, s);                   \
+            if (e4 != FFM_EUNSUP) return e4;                                                     \
+        }                                                                                        \
         return dtype == FFM_BF16 ? launch_gemm<bf16_t, RKB, F>(a, s) : launch_gemm<float, RKB, F>(a, s);
     if (rk) {
         switch (fl) {
@@ -1405,7 +1408,8 @@ static int conv3x3_impl(const void* x, const void* w, void* y, int B, int H, int
     if (S > 1) { ka.ksplit = S; ka.part = splitk_scratch; }
     a.colstat_part = S > 1 ? nullptr : colstat_part;               // (split over K: the sums leave with the reduction below)
     const bool bnb = bn_x != nullptr;                              // FFM_EPI_BNBWD (split over K: in the reduction below)
-    if (bnb) { a.flags = FFM_EPI_BNBWD; a.bn_x = bn_x; a.bn_mask = bn_mask; a.bn_mean = bn_mean; a.bn_rstd = bn_rstd; }
+    if (bnb) { a.bn_x = bn_x; a.bn_mask = bn_mask; a.bn_mean = bn_mean; a.bn_rstd = bn_rstd; }
+    if (bnb && S == 1) a.flags = FFM_EPI_BNBWD;                    // (the split launches run the plain kernels)
     // The stem and layer1 (N = 32 / 64): 128 x N tiles, three blocks per CU (81 -> 33 / 43 us at 112 x 112, 40 -> 25 us at
     // 56 x 56).  FFM_CONV_NARROW=off: the 128x128 kernel (A/B runs); FFM_CONV_NARROW=<t>: also N = 128 / 256 / ... as 64-wide
     // column tiles when the launch has fewer than t 128x128 tiles (measured at t = 512 / 1000 on RN50 bs 32: no gain)

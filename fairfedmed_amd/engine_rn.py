@@ -130,9 +130,11 @@ class _BN:
         t = (max_rows + 127) // 128                                # row tiles of the GEMM that produces this layer's input
         if t <= 4096:
             eng.stat_scratch = max(eng.stat_scratch, 2 * t * C)
-        t8 = (max_rows + 7) // 8                                   # (a convolution split over K: 8 / 32 rows per partial row)
-        if t8 <= 4096 or (max_rows >= 4096 and (max_rows + 31) // 32 <= 4096):
-            eng.stat_scratch = max(eng.stat_scratch, 2 * (t8 if max_rows < 4096 else (max_rows + 31) // 32) * C)
+        # a convolution split over K leaves one partial row per 8 rows below 4096 rows and per 32 rows from there on
+        # (csrc/gemm.hip: splitk_cs_rows) - NOT monotone in the row count, so a ragged last batch can need more partial
+        # rows than the largest one: size for the worst M <= max_rows (at most 4096 partial rows either way)
+        worst = max((min(max_rows, 4095) + 7) // 8, (max_rows + 31) // 32 if max_rows >= 4096 else 0)
+        eng.stat_scratch = max(eng.stat_scratch, 2 * min(worst, 4096) * C)
         eng.bns.append(self)
 
     def fwd(self, x: Tensor, y: Tensor, relu: bool, res: Optional[Tensor] = None, part: Optional[Tensor] = None,
@@ -289,7 +291,8 @@ class _Bneck:
             ops.avgpool2(self.da2p[:ro], da2, images, Hi, Hi, backward=True)
         self.bn2.bwd(da2, self.a2[:ri], self.z2[:ri], self.dz2[:ri], part=e.stat_buf[0], part_rows=t2)
         # dX = conv3x3(dY; w') is the gradient of relu(bn1(.)): the same for bn1 where the convolution is not split over K
-        # (layer1 / layer2; conv3x3 returns the partial rows it wrote, 0 for the split launches of layer3 / layer4)
+        # (conv3x3 returns the partial rows it wrote: one per 128-row tile, or - launches split over K, layer3 / layer4 -
+        # one per 8 / 32 rows from the split-K reduction kernel; 0 only where that would exceed 4096 partial rows)
         fuse1 = e.stat_rows(ri) > 0 and getattr(e, "bn_bwd_fused", True)
         t1 = ops.conv3x3(self.dz2[:ri], W[p + "w2b"], self.da1[:ri], images, Hi, Hi, e.zero16, e.splitk,
                          colstats=e.stat_buf[0] if fuse1 else None,

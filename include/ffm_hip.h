@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 12  /* 12: ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 12  /* 12: ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd / bn_gout), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -300,12 +300,19 @@ int ffm_slice_bwd(const void* dcols, const float* img, const float* conv, const 
 int ffm_conv3x3_nhwc(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
                      const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part, int dtype,
                      void* stream);
-/* colstat_part (optional): as ffm_gemm_args.colstat_part; written only when the launch is not split over K -
- * ffm_conv3x3_colstat_rows returns the number of partial rows it will then hold (0: split-K, no statistics) */
+/* colstat_part (optional): as ffm_gemm_args.colstat_part.  ffm_conv3x3_colstat_rows returns the number of partial rows
+ * [rows][2][N] the launch will leave there, which is what the caller sizes the buffer by and hands to ffm_bn_fwd /
+ * ffm_bn_bwd as part_rows:
+ *   - launch not split over K:  ceil(M / 128), one per row tile (M = B*H*W);
+ *   - launch split over K (few tiles, long K: the 14 x 14 / 7 x 7 maps): the split-K reduction kernel writes them, one
+ *     per 8 rows when M < 4096 and one per 32 rows from there on: ceil(M / 8) or ceil(M / 32) - NOT monotone in M, so
+ *     size for the worst batch, not the largest;
+ *   - 0 when that count would exceed 4096 or N % 4 != 0: no statistics, the BatchNorm makes its own pass. */
 int ffm_conv3x3_colstat_rows(int B, int H, int W, int C, int N, int Kp, int64_t scratch_elems, int dtype);
 /* the same product with FFM_EPI_BNBWD's column sums (ABI 11): y is dL/dy of a train-mode BatchNorm (+ ReLU with output
  * bn_mask, or NULL) on bn_x, and colstat_part receives {sum g, sum g xhat} per row tile (ffm_bn_bwd's part / part_rows =
- * ffm_conv3x3_colstat_rows).  FFM_EUNSUP when the launch would be split over K (ffm_conv3x3_colstat_rows == 0). */
+ * ffm_conv3x3_colstat_rows, both the one-launch and the split-K geometry above).  FFM_EUNSUP only when
+ * ffm_conv3x3_colstat_rows == 0 for this shape. */
 int ffm_conv3x3_nhwc_bnbwd(const void* x, const void* w, void* y, int B, int H, int W, int C, int N, int Kp,
                            const void* zeros, float* splitk_scratch, int64_t scratch_elems, float* colstat_part,
                            const void* bn_x, const void* bn_mask, const float* bn_mean, const float* bn_rstd, int dtype,

@@ -238,9 +238,20 @@ def test_fedchexmimic_reader_vs_reference(tmp_path, gold):
             for i in range(len(ds)):
                 x, y, a = ds[i]
                 assert list(x.shape) == ref["shape"] and str(x.dtype) == ref["dtype"] == "float32"
-                assert float(np.asarray(x, np.float64).sum()) == ref["sums"][i]
-                w = (np.asarray(x, np.float64).reshape(-1) * np.arange(1, x.size + 1)).sum()
-                assert float(w) == ref["wsums"][i]
+                same_codec = True
+                if str(ds.data_files[i]).lower().endswith((".jpg", ".jpeg")):
+                    # JPEG pixels depend on the libjpeg(-turbo) / Pillow build that encodes the tree at test time and decodes
+                    # it: the reader must equal a direct PIL decode of the same file always; the golden sums (made with the
+                    # generating container's codec) are compared only when this machine's codec reproduces them
+                    from PIL import Image
+                    path = os.path.join(ds.data_path, str(ds.data_files[i]))
+                    direct = np.asarray(Image.open(path).convert("L"), np.float32)
+                    assert np.array_equal(np.asarray(x)[0], direct) and np.array_equal(np.asarray(x)[2], direct)
+                    same_codec = float(direct.astype(np.float64).sum() * 3) == ref["sums"][i]
+                if same_codec:
+                    assert float(np.asarray(x, np.float64).sum()) == ref["sums"][i]
+                    w = (np.asarray(x, np.float64).reshape(-1) * np.arange(1, x.size + 1)).sum()
+                    assert float(w) == ref["wsums"][i]
                 assert int(y) == ref["labels"][i] and str(y.dtype) == ref["label_dtype"] == "torch.int64"
                 assert [int(v) for v in a] == ref["attrs"][i]
             assert np.asarray(ds[1][0])[:, :3, :4].tolist() == ref["first_corner"]
