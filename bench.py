@@ -425,7 +425,10 @@ def main():
     opt = C.OptimCfg()
     agg = None
     if use_dist:
+        # the round boundary the product's rank driver runs (federated.run_fedotplora_ranks): the SAME aggregator objects
         agg = FedAvgAggregator(eng.params.flat, eng.params.offsets, mcfg.lora.num_groups, mcfg.lora.rank)
+        agg_buf = (FedAvgAggregator(eng.buffers_flat(), {}, mcfg.lora.num_groups, mcfg.lora.rank, shared_half_s=False)
+                   if wl.has_buf else None)
     n_client = [1024] * world
     by_attr = [wl.by_attr] * world
     buf_bytes = 0
@@ -473,8 +476,9 @@ def main():
         if wl.has_buf:
             # RN50: the BatchNorm running statistics / counters are state_dict entries too and are averaged with the plain
             # n_k / sum n weights (utils/fed_utils.py:76-86): a second, small all-reduce
-            buf = eng.buffers_flat() * (n_client[rank] / float(sum(n_client)))
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            agg_buf.begin()
+            agg_buf.add(eng.buffers_flat(), rank, list(range(world)), n_client, None)
+            buf = agg_buf.finish(1, 50, grouped=False)
             eng.load_buffers_flat(buf)
             buf_bytes = buf.numel() * 4
 
@@ -582,6 +586,9 @@ def main():
                 # mean per launch, for THIS workload - the figure `traffic` is to be read against
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "traffic_source": tsrc,
+                # machine-readable provenance: the PMC passes are separate rocprofv3 runs of this same command (tools/pmc.sh),
+                # committed under profiles/ - the figure is NOT collected inside this timed process
+                "traffic_measured_in_run": False,
                 "launches_per_step": n // args.steps, "avg_launch_us": ms * 1e3 / n,
                 "gemm_ms_per_step": ms / args.steps,
                 # what an event pair measures with NOTHING between the two records (median, same backed-up queue):

@@ -36,13 +36,23 @@ def to_dev(batch):
     return batch["img"].cuda(), batch["attrs"].t()[0].contiguous().cuda(), batch["label"].cuda()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-def test_full_rn50_step_vs_oracle(dtype):
+# Two fixtures.  "raw": every BatchNorm gamma ~ N(1, 0.1) - the random-weight trunk amplifies a perturbation ~1.5x per
+# Bottleneck in EVERY precision, so only the fp32 engine is held there.  "clip": bn3.weight x 0.1 - CLIP
+# zero-initialises the last BatchNorm of every Bottleneck (clip/model.py:545-548) and a trained ResNet's residual branches
+# are small next to its identity path: the stable regime in which the 16-bit modes carry REAL bounds (round 6: loss 5e-3 /
+# 2e-3, logits 8e-2 / 2e-2 of their scale for bf16 / fp16; the raw fixture's 16-bit bounds were 10 % / 0.75, i.e. nothing).
+@pytest.mark.parametrize("fixture,dtype", [("raw", torch.float32), ("clip", torch.float32), ("clip", torch.bfloat16), ("clip", torch.float16)],
+                         ids=["raw-f32", "clip-f32", "clip-bf16", "clip-f16"])
+def test_full_rn50_step_vs_oracle(fixture, dtype):
     from fairfedmed_amd.engine_rn import create_engine, RN50Engine
     from oracle import fairlora_oracle as O
     mcfg = C.rn50(rank=8, num_groups=2)
     assert tuple(mcfg.vision.layers) == (3, 4, 6, 3)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    if fixture == "clip":
+        for k in sd:
+            if k.endswith("bn3.weight"):
+                sd[k] = sd[k] * 0.1
     bs = 4
     batch = synth.make_batch(mcfg, bs, seed=1234)
     keys = synth.trainable_keys(mcfg)
@@ -55,15 +65,23 @@ def test_full_rn50_step_vs_oracle(dtype):
     ref_sd = copy.deepcopy(sd)
     loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
     f32 = dtype == torch.float32
-    print("rn50", dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
+    print("rn50", fixture, dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
     assert int(out["finite"]) == 1
-    assert abs(float(out["loss"]) - float(loss)) <= (1e-4 if f32 else 0.1) * abs(float(loss))
+    loss_tol = {torch.float32: 1e-4, torch.bfloat16: 5e-3, torch.float16: 2e-3}[dtype]
+    logit_tol = {torch.float32: 5e-4, torch.bfloat16: 8e-2, torch.float16: 2e-2}[dtype]
+    assert abs(float(out["loss"]) - float(loss)) <= loss_tol * abs(float(loss))
     # 53 convolutions + train-mode BatchNorm at batch 4: logits agree to 1.5e-4 of their scale (loss to 4e-6).  This
     # random-weight trunk amplifies a perturbation ~1.5x per Bottleneck (tools/rn_colstat_diag.py: the fp32 step with the
     # BatchNorm sums added in another order differs by 5e-7 after block 0 and 7e-5 after block 15; in bf16 the same two
     # orders differ from each other by 0.30 of the logit scale), so the bf16 logits carry no tighter bound than this;
     # the bf16 kernels themselves are held per layer in test_engine_rn_gpu.py / test_conv_gpu.py
-    assert rel(out["logits"], logits) < (5e-4 if f32 else 0.75)
+    assert rel(out["logits"], logits) < logit_tol
+    if not f32:
+        # 16-bit gradients on the stable fixture: every tensor on the right side and the bulk aligned (ReLU masks still flip
+        # under 2^-9 / 2^-11 perturbations, which is what the bf16-storage control below prices tensor by tensor)
+        cs = sorted(cos(eng.params.view(k, "grad"), grads[k]) for k in keys if float(grads[k].abs().max()) > 0)
+        print("rn50", fixture, dtype, "gradient cosine min / 5th percentile / median", cs[0], cs[len(cs) // 20], cs[len(cs) // 2])
+        assert cs[0] > 0.5 and cs[len(cs) // 2] > (0.9 if dtype == torch.bfloat16 else 0.99)
     if f32:
         worst, werr = 1.0, 0.0
         for k in keys:
@@ -85,6 +103,48 @@ def test_full_rn50_step_vs_oracle(dtype):
                 assert int(bufs[k]) == int(ref_sd[k]) == 1, k
             else:
                 assert rel(bufs[k], ref_sd[k]) < 1e-4, k
+
+
+def test_full_rn50_f32_bs32_vs_oracle():
+    """The fp32 RN50 engine AT THE BENCH SIZE (configs[4]: batch 32 - 100 352 rows in layer1, where the 128 x 128 products
+    leave the <= 256-tile four-stage ring and take the two-buffer loop, csrc/gemm.hip) against the oracle's step on the host
+    (~10-20 s), on the CLIP-like fixture (bn3.weight x 0.1, clip/model.py:545-548): strict fp32 bounds - loss 1e-5, logits
+    1e-4 of their scale, every gradient's direction to 1e-3, BatchNorm running statistics to 1e-4."""
+    from fairfedmed_amd.engine_rn import create_engine
+    from oracle import fairlora_oracle as O
+    mcfg = C.rn50(rank=8, num_groups=2)
+    sd = synth.make_state_dict(mcfg, seed=1, lora_init="random")
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.1
+    bs = 32
+    batch = synth.make_batch(mcfg, bs, seed=1234)
+    keys = synth.trainable_keys(mcfg)
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    eng = create_engine(mcfg, sd, dtype=torch.float32, max_images=bs)
+    out = eng.forward_backward(*to_dev(batch))
+    torch.cuda.synchronize()
+    ref_sd = copy.deepcopy(sd)
+    loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
+    print("rn50 f32 bs32 loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
+    assert int(out["finite"]) == 1
+    assert abs(float(out["loss"]) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert rel(out["logits"], logits) < 1e-4
+    worst, werr = (1.0, ""), (0.0, "")
+    for k in keys:
+        g, ref = eng.params.view(k, "grad"), grads[k]
+        if float(ref.abs().max()) == 0.0:
+            assert float(g.abs().max()) < 1e-12, k
+            continue
+        worst, werr = min(worst, (cos(g, ref), k)), max(werr, (rel(g, ref), k))
+        assert cos(g, ref) > 1 - 1e-3 and rel(g, ref) < 0.12, (k, cos(g, ref), rel(g, ref))
+    print("rn50 f32 bs32: worst gradient cosine", worst, "worst rel err", werr)
+    bufs = eng.buffer_state()
+    for k in synth.buffer_keys(mcfg):
+        if k.endswith("num_batches_tracked"):
+            assert int(bufs[k]) == int(ref_sd[k]) == 1, k
+        else:
+            assert rel(bufs[k], ref_sd[k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
