@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("ln_rk", _vp), ("colstat_part", _vp),
         ("lg_v", _vp), ("lg_part_c", _vp), ("lg_part_a", _vp),
         ("bn_x", _vp), ("bn_mask", _vp), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_gout", _vp),
+        ("sk_part", _vp),
     ]
 
 
@@ -55,6 +56,7 @@ class ReduceDesc(C.Structure):
 SIGNATURES = {
     "ffm_abi_version": [],
     "ffm_gemm_nt": [C.POINTER(GemmArgs), _i32, _vp],
+    "ffm_gemm_splitk_floats": [_i32, _i32, _i32, _i32],
     "ffm_gemm_tiles_m": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_gemm_tiles_n": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "ffm_gemm_lgrad_rows": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -142,7 +144,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith("_ws_bytes") else C.c_int
+        fn.restype = C.c_int64 if name.endswith(("_ws_bytes", "_splitk_floats")) else C.c_int
     v = lib.ffm_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"libffm_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")

@@ -325,6 +325,145 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
     }
 }
 
+
+// ---- split over K across the grid (ABI 12, ffm_gemm_args.sk_part) ------------------------------------------------------------
+// The text tower's narrow products (N = 512: c_proj forward, dX(c_fc), dX(qkv)) give the kernels above 16 column groups, i.e.
+// 16 blocks that each walk K = 1536 / 2048 in two or three dependent memory round trips with 576 KB through ONE CU's L2 port:
+// 20-28 us per launch, three dozen launches per step on the side stream - at 8 waves x 150-240 registers, the footprint that
+// keeps a CU from the vision chain's next panel launch (docs/experiments.md E4.6).  Here the grid is (column groups) x (K
+// slices of 128): every block is 4 waves of ONE K32 step each - a single round trip, ~100 registers - and writes its 40 x 32
+// partial tile to scratch [slice][M][N]; a second small launch sums the slices IN ORDER (deterministic: no atomics) and
+// applies the epilogue.  More launches, but each is a few microseconds on many CUs with a footprint that fits beside a panel.
+constexpr int SKS_K = 128;                                         // K per block (4 waves x one K32 step)
+template <typename TB, int NT, int MFC>
+__global__ __launch_bounds__(256) void gemm_skinny_splitk_kernel(ffm_gemm_args p) {
+    typedef SkOps<float, TB, true> O;
+    constexpr int KS = O::KS, KG = KS / 4;
+    __shared__ f32x4 red[4][NT][MFC][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int nmf = (p.M + 15) >> 4;
+    const int n0 = blockIdx.x * SK_COLS * NT, slice = blockIdx.y;
+    const int k0 = slice * SKS_K + wave * KS;
+    const float* A = reinterpret_cast<const float*>(p.a);
+    typename O::braw bf[NT];
+    typename O::afrag af[MFC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        O::loadB(bf[t], reinterpret_cast<const TB*>(p.b) + (size_t)(n0 + t * SK_COLS + col) * p.ldb + k0 + kg * KG);
+#pragma unroll
+    for (int mf = 0; mf < MFC; ++mf) {
+        int row = mf * 16 + col;
+        row = row < p.M ? row : p.M - 1;                           // clamped rows are never stored
+        if (mf < nmf) O::loadA(af[mf], A + (size_t)row * p.lda + k0 + kg * KG);
+    }
+    f32x4 acc[NT][MFC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MFC; ++mf) acc[t][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typename O::bprep b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = O::prep(bf[t]);
+#pragma unroll
+    for (int mf = 0; mf < MFC; ++mf)
+        if (mf < nmf) {
+            const typename O::bprep a = O::prep(af[mf]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) O::mma_split(acc[t][mf], a, b[t]);
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mf = 0; mf < MFC; ++mf)
+            if (mf < nmf) red[wave][t][mf][lane] = acc[t][mf];
+    __syncthreads();
+    // the four K32 steps meet in wave order; wave t < NT finishes tile t, waves NT.. the remaining row fragments
+    for (int item = wave; item < NT * nmf; item += 4) {
+        const int t = item % NT, mf = item / NT;
+        f32x4 v = red[0][t][mf][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 o = red[w][t][mf][lane];
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        const int n = n0 + t * SK_COLS + col;
+        float* part = p.sk_part + (size_t)slice * p.M * p.N;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = mf * 16 + 4 * kg + e;
+            if (row < p.M) part[(size_t)row * p.N + n] = v[e];
+        }
+    }
+}
+
+// sum of the K slices in slice order + the one-launch kernel's epilogue, four columns per thread
+template <int FL>
+__global__ __launch_bounds__(256) void skinny_splitk_finish_kernel(ffm_gemm_args p, int slices) {
+    const int n4 = p.N >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * n4) return;
+    const int row = idx / n4, n = (idx - row * n4) << 2;
+    const size_t mn = (size_t)p.M * p.N;
+    const float* part = p.sk_part + (size_t)row * p.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part);
+    for (int s = 1; s < slices; ++s) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(part + (size_t)s * mn);
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    const size_t o = (size_t)row * p.ldc + n;
+    float* C = reinterpret_cast<float*>(p.c);
+    f32x4 out, out2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + ((FL & FFM_EPI_BIAS) ? p.bias[n + e] : 0.f);
+        if (FL & FFM_EPI_RESIDUAL) x += reinterpret_cast<const float*>(p.res)[o + e];
+        if (FL & FFM_EPI_DGELU) {
+            const float ax = reinterpret_cast<const float*>(p.aux)[o + e];
+            x *= p.gelu_deriv ? ax : Act<float>::gelu_grad(ax);
+        }
+        if ((FL & FFM_EPI_GELU) && p.gelu_deriv) {
+            float ga, gd;
+            Act<float>::gelu_both(x, ga, gd);
+            out[e] = gd;
+            out2[e] = ga;
+        } else {
+            out[e] = x;
+            if (FL & FFM_EPI_GELU) out2[e] = Act<float>::gelu(x);
+        }
+    }
+    *reinterpret_cast<f32x4*>(C + o) = out;
+    if (FL & FFM_EPI_GELU) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c2) + o) = out2;
+}
+
+// which products are split: 40-odd rows, N so narrow that the one-launch kernel has fewer than 32 blocks, K of at least 8
+// slices; FFM_SKINNY_SPLITK=0 switches it off (A/B runs), =<n> moves the N bound
+inline int sk_slices(int M, int N, int K) {
+    static const int nmax = getenv("FFM_SKINNY_SPLITK") ? atoi(getenv("FFM_SKINNY_SPLITK")) : 512;
+    if (M > 48 || N > nmax || N % 32 || K % SKS_K || K / SKS_K < 8 || K / SKS_K > 64) return 0;
+    return K / SKS_K;
+}
+
+template <typename TB>
+int launch_splitk(const ffm_gemm_args& a, hipStream_t s) {
+    const int slices = sk_slices(a.M, a.N, a.K);
+    if ((a.ldc & 3) || (a.N & 3)) return FFM_EUNSUP;
+    hipLaunchKernelGGL((gemm_skinny_splitk_kernel<TB, 2, 3>), dim3(a.N / (SK_COLS * 2), slices), dim3(256), 0, s, a);
+    FFM_CHECK_LAUNCH();
+    const dim3 g((a.M * (a.N >> 2) + 255) / 256);
+    switch (a.flags) {
+        case 0: hipLaunchKernelGGL((skinny_splitk_finish_kernel<0>), g, dim3(256), 0, s, a, slices); break;
+        case FFM_EPI_BIAS: hipLaunchKernelGGL((skinny_splitk_finish_kernel<FFM_EPI_BIAS>), g, dim3(256), 0, s, a, slices); break;
+        case FFM_EPI_BIAS | FFM_EPI_RESIDUAL: hipLaunchKernelGGL((skinny_splitk_finish_kernel<FFM_EPI_BIAS | FFM_EPI_RESIDUAL>), g, dim3(256), 0, s, a, slices); break;
+        case FFM_EPI_BIAS | FFM_EPI_GELU: hipLaunchKernelGGL((skinny_splitk_finish_kernel<FFM_EPI_BIAS | FFM_EPI_GELU>), g, dim3(256), 0, s, a, slices); break;
+        case FFM_EPI_DGELU: hipLaunchKernelGGL((skinny_splitk_finish_kernel<FFM_EPI_DGELU>), g, dim3(256), 0, s, a, slices); break;
+        default: return FFM_EINVAL;
+    }
+    FFM_CHECK_LAUNCH();
+    return FFM_OK;
+}
+
 // Blocks per launch.  Every block of the vision tower's single-round panel GEMMs needs a whole CU, and a panel launch leaves
 // 8-16 of the 256 idle: a side-stream launch that holds more CUs than that when a panel starts keeps some of its blocks
 // waiting (the side streams cost the chain ~0.4 ms per step).  FFM_SKINNY_CAP=<n> caps the grid at n
@@ -409,7 +548,18 @@ bool ffm_skinny_ok(const ffm_gemm_args& a, int dtype) {
     return false;
 }
 
+#ifndef FFM_TWIN_F16     // (defined once: the split products are float32-storage only, the half twin of this file has no use for it)
+extern "C" int64_t ffm_gemm_splitk_floats(int M, int N, int K, int dtype) {
+    if (dtype != FFM_F32_X3 && dtype != FFM_F32_X3_W16) return 0;
+    return (int64_t)sk_slices(M, N, K) * M * N;
+}
+#endif
+
 int ffm_skinny_launch(const ffm_gemm_args& a, int dtype, hipStream_t s) {
+    if (a.sk_part && (dtype == FFM_F32_X3 || dtype == FFM_F32_X3_W16) && sk_slices(a.M, a.N, a.K) > 0 && !(a.ldc & 3)) {
+        const int e = dtype == FFM_F32_X3 ? launch_splitk<float>(a, s) : launch_splitk<_Float16>(a, s);
+        if (e != FFM_EUNSUP) return e;
+    }
     if (dtype == FFM_F32) return launch_waves<float, float, false>(a, s);
     if (dtype == FFM_F32_X3) return launch_waves<float, float, true>(a, s);
     if (dtype == FFM_F32_X3_W16) return launch_waves<float, _Float16, true>(a, s);

@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float* __restrict__
 // reference's `w_avg[key] += w[idx][key] * weight` (utils/fed_utils.py:79-86) rounds them
 __global__ __launch_bounds__(256) void scale_acc_kernel(const float* __restrict__ p, const float* __restrict__ w,
                                                         float* __restrict__ acc, int64_t n) {
+#pragma clang fp contract(off)      // (hipcc contracts a * b + c into an FMA by default, and __fmul_rn is a plain product in HIP)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        acc[i] = __fadd_rn(acc[i], __fmul_rn(p[i], w[i]));
+        acc[i] = acc[i] + p[i] * w[i];
 }
 
 // utils/fed_utils.py:88-98: optional shared_half_s, then EMA with the previous global
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void shared_half_kernel(float* __restrict__ av
 // (prev and out may be the same buffer: the aggregator updates its global weights in place)
 __global__ __launch_bounds__(256) void ema_kernel(const float* __restrict__ avg, const float* prev, float* out, int64_t n,
                                                   float beta) {
+#pragma clang fp contract(off)      // three roundings, as `(1 - b) * avg + b * w_g` has in the reference (utils/fed_utils.py:98)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (1.0f - beta) * avg[i] + beta * prev[i];
 }

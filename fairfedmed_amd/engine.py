@@ -206,9 +206,22 @@ class _Stack:
         # the forward pays for the extra arithmetic.  Off by default; bit-identical in fp32 either way.
         deriv = os.environ.get("FFM_GELU_DERIV", "0") == "1"
 
+        # x3 (the text tower, 40 token rows): scratch for the products that are split over K across the grid
+        # (ffm_gemm_args.sk_part, csrc/gemm_skinny.hip: N = 512 against K = 1536 / 2048 - c_proj forward, dX(c_fc), dX(qkv));
+        # one buffer per tower: its launches are ordered on the tower's stream
+        rows_max = max_images * tokens
+        self.sk_part = None
+        if x3 and rows_max <= 48:
+            need = max(ops.gemm_splitk_floats(rows_max, n_, k_, self.wdtype == torch.float16)
+                       for n_, k_ in ((width, 4 * width), (width, 3 * width), (4 * width, width), (3 * width, width), (width, width)))
+            if need > 0:
+                self.sk_part = torch.empty(need, device=device, dtype=torch.float32)
+
         def _gemm(*a, **k):
             if deriv and (k.get("gelu_out") is not None or k.get("dgelu_aux") is not None):
                 k["gelu_deriv"] = True
+            if self.sk_part is not None:
+                k["sk_part"] = self.sk_part
             return ops.gemm_nt(*a, x3=x3, **k)
         self.gemm = _gemm
         self.blocks: List[_Block] = []

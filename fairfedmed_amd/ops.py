@@ -155,7 +155,8 @@ def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
 def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, lw_is_kr=False, res=None,
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
             x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
-            colstats: Optional[Tensor] = None, gelu_deriv: bool = False, bnbwd=None) -> Tensor:
+            colstats: Optional[Tensor] = None, gelu_deriv: bool = False, bnbwd=None,
+            sk_part: Optional[Tensor] = None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
     x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores; with
     `b` in float16: FFM_F32_X3_W16, the same on a weight rounded to IEEE half in memory (half the bytes).
@@ -240,13 +241,21 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
                       L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,
-                      L.ptr(_f32(colstats)), *lgx, *bnx)
+                      L.ptr(_f32(colstats)), *lgx, *bnx, L.ptr(_f32(sk_part)))
+    if sk_part is not None:                        # x3 products split over K: scratch for the partial tiles (gemm_splitk_floats)
+        _dev(sk_part)
+        assert x3 and sk_part.numel() >= gemm_splitk_floats(M, N, K, w16)
     if colstats is not None:                       # [tiles_m, 2, N] fp32 column sums of the stored output (128x128 kernel)
         _dev(colstats)
         assert b_packed is None and colstats.numel() >= 2 * N * ((M + 127) // 128)
     assert b_packed is None or (b_packed.numel() == N * K and b_packed.dtype == b.dtype)
     _call("ffm_gemm_nt", C.byref(args), (L.F32_X3_W16 if w16 else L.F32_X3) if x3 else L.dtype_code(a.dtype), L.stream_ptr())
     return out
+
+
+def gemm_splitk_floats(M: int, N: int, K: int, w16: bool = False) -> int:
+    """floats of gemm_nt(x3=True, sk_part=...)'s scratch for this product; 0: it runs as one launch."""
+    return int(L.load().ffm_gemm_splitk_floats(M, N, K, L.F32_X3_W16 if w16 else L.F32_X3))
 
 
 def layernorm_fwd(x: Tensor, y: Tensor, gamma: Tensor, beta: Tensor, mean: Optional[Tensor] = None,

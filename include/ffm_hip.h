@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 12  /* 12: ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd / bn_gout), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 12  /* 12: ffm_gemm_args.sk_part + ffm_gemm_splitk_floats (text-tower products split over K), ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd / bn_gout), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -158,6 +158,12 @@ typedef struct ffm_gemm_args {
     const float* bn_rstd;   /* [N] */
     void*        bn_gout;   /* optional [M, N] dtype, stride ldc: also receives g = c * (bn_mask > 0), the gradient an identity-skip
                              * Bottleneck passes on beside bn3 (ffm_bn_bwd's g_out, which a call with part_rows cannot write) */
+    /* ABI 12, FFM_F32_X3 / FFM_F32_X3_W16 products of at most 48 rows (the text tower: 40 token rows against 512..2048-wide
+     * frozen weights): optional scratch of ffm_gemm_splitk_floats(M, N, K) floats.  With it, a product whose N is too narrow
+     * to give every CU a column tile is split over K across the grid - partial tiles [slice][M][N] land here and a second
+     * small launch sums them IN SLICE ORDER (deterministic) and applies the epilogue - instead of a handful of blocks each
+     * walking the whole K.  NULL: the one-launch kernel. */
+    float*       sk_part;
 } ffm_gemm_args;
 
 /*
@@ -170,6 +176,8 @@ typedef struct ffm_gemm_args {
  * Requires K*sizeof(dtype) % 128 == 0, N % 8 == 0, 16-byte aligned rows.
  */
 int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream);
+/* floats ffm_gemm_args.sk_part needs for this product (0: the product is not split over K) */
+int64_t ffm_gemm_splitk_floats(int M, int N, int K, int dtype);
 /* row tiles (= dS partial rows written under FFM_EPI_RANKOP) of the kernel ffm_gemm_nt picks for this call */
 int ffm_gemm_tiles_m(int M, int N, int K, int flags, int rank, int dtype, int packed);
 /* row tiles of lg_part_c / lg_part_a under FFM_EPI_LGRAD for this call (flags with or without the bit), or FFM_EUNSUP when

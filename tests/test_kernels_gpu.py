@@ -724,6 +724,58 @@ def test_skinny_gemm_f32(M, N, K, x3, mode):
     assert rel(out, ref) < tol, rel(out, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(40, 512, 2048), (40, 512, 1536), (33, 512, 1024), (48, 256, 2048), (1, 512, 2048)])
+@pytest.mark.parametrize("w16", [False, True], ids=["x3", "x3w16"])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_res", "bias_gelu", "dgelu"])
+def test_skinny_gemm_split_over_k(M, N, K, w16, mode):
+    """ffm_gemm_args.sk_part (ABI 12): the text tower's narrow products split over K across the grid - partial tiles per
+    128-deep slice, summed in slice order by the finish launch with the one-launch kernel's epilogues.  Against float64 at the
+    X3 tolerance, bit-identical from run to run (no atomics), and the scratch query says which products are split."""
+    from fairfedmed_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 1000 + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
+    if w16:
+        w = w.half()
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    aux = torch.randn(M, N, device="cuda", generator=g)
+    need = ops.gemm_splitk_floats(M, N, K, w16)
+    assert need == (K // 128) * M * N and ops.gemm_splitk_floats(M, 2048, 512, w16) == 0 and ops.gemm_splitk_floats(64, N, K, w16) == 0
+    part = torch.full((need,), float("nan"), device="cuda")
+    rel = lambda got, want: float((got.double() - want.double()).abs().max() / want.double().abs().max())
+    ref = a.double() @ w.double().t()
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        act = torch.full((M, N), float("nan"), device="cuda")
+        kw = {"plain": {}, "bias": dict(bias=bias), "bias_res": dict(bias=bias, res=res), "bias_gelu": dict(bias=bias, gelu_out=act),
+              "dgelu": dict(dgelu_aux=aux)}[mode]
+        ops.gemm_nt(a, w, out, x3=True, sk_part=part, **kw)
+        outs.append((out, act))
+    assert torch.equal(outs[0][0], outs[1][0])
+    out, act = outs[0]
+    tol = 2e-5
+    if mode in ("bias", "bias_res", "bias_gelu"):
+        ref = ref + bias
+    if mode == "bias_res":
+        ref = ref + res.double()
+    if mode == "bias_gelu":
+        assert rel(act, ref * torch.sigmoid(1.702 * ref)) < tol
+    if mode == "dgelu":
+        x = aux.double()
+        sg = torch.sigmoid(1.702 * x)
+        ref = ref * (sg * (1 + 1.702 * x * (1 - sg)))
+    assert not torch.isnan(out).any()
+    assert rel(out, ref) < tol, rel(out, ref)
+    # the one-launch kernel on the same operands: same value to the fp32 summation order
+    one = torch.empty_like(out)
+    kw = {"plain": {}, "bias": dict(bias=bias), "bias_res": dict(bias=bias, res=res), "bias_gelu": dict(bias=bias, gelu_out=torch.empty_like(out)),
+          "dgelu": dict(dgelu_aux=aux)}[mode]
+    ops.gemm_nt(a, w, one, x3=True, **kw)
+    assert rel(out, one) < 5e-6
+
+
 def test_skinny_x3_tiles_per_block_switch():
     """FFM_SKINNY_NT (read once per process): the text tower's X3 product with 1 / 2 / 4 column tiles per block
     (csrc/gemm_skinny.hip, gemm_skinny_nt_kernel: the tiles of a block share the activation fragments).  The partial sums
