@@ -294,12 +294,17 @@ def make_state_dict(cfg: ModelCfg, seed: int = 1, lora_init: str = "reference") 
     return sd
 
 
-def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0, slices: int = 2):
+def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0, slices: int = 2, overlap: float = 0.0):
     """Synthetic batch in the reference's dict contract:
     img f32 [B,C,H,W] raw 0..255 (C = 3, or slices*dim_per_3d_slice for 3D OCT), label i64 [B], attrs i64 [B,1].
 
     signal > 0 adds a label-dependent mean shift on a fixed patch mask and a
-    group-dependent contrast, so AUC can move off 0.5."""
+    group-dependent contrast, so AUC can move off 0.5.
+
+    overlap > 0 (with signal): every sample's shift also carries its own N(0, overlap^2) offset, the same on all pixels of
+    the patch - the two classes' patch means OVERLAP, so the task has an irreducible error and the AUC of a converged model
+    plateaus near Phi(sqrt(2) signal / overlap) < 1 instead of saturating at 1 (the round-6 RN AUC fixture: a plateau set by
+    the data is where a +-0.002 criterion can be asked of 16-bit storage at all, tests/test_auc_parity_gpu.py)."""
     g = np.random.Generator(np.random.Philox(key=[0xBA7C4, seed & 0xFFFFFFFF]))
     v = cfg.vision
     c = 3 if not cfg.dim_per_3d_slice else slices * cfg.dim_per_3d_slice   # 3D OCT: `slices` groups of B-scans
@@ -312,7 +317,10 @@ def make_batch(cfg: ModelCfg, batch: int, seed: int = 1234, signal: float = 0.0,
         mask[h // 4: h // 2, h // 4: h // 2] = 1.0
         contrast = 1.0 - 0.15 * attr.astype(np.float32)
         img = (img - 0.5) * contrast[:, None, None, None] + 0.5
-        img = img + signal * (label.astype(np.float32) * 2 - 1)[:, None, None, None] * mask[None, None]
+        shift = signal * (label.astype(np.float32) * 2 - 1)
+        if overlap > 0:                                # (drawn last: the streams of the other fixtures do not move)
+            shift = shift + np.float32(overlap) * g.standard_normal(batch, dtype=np.float32)
+        img = img + shift[:, None, None, None] * mask[None, None]
         img = np.clip(img, 0.0, 1.0)
     img = img * np.float32(255.0)
     return {

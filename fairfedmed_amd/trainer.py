@@ -110,9 +110,9 @@ class SyntheticFedData:
 
     def __init__(self, mcfg: C.ModelCfg, num_clients: int, train_batches: int, test_batches: int, batch_size: int,
                  attribute: str = "race", classnames=("NOT Glaucoma", "Glaucoma"), seed: int = 1234,
-                 signal: float = 0.25, device: str = "cpu", test_batch_size: Optional[int] = None):
+                 signal: float = 0.25, device: str = "cpu", test_batch_size: Optional[int] = None, overlap: float = 0.0):
         ng = {attribute: mcfg.lora.num_groups}
-        mk = lambda s, n=batch_size: {k: v.to(device) for k, v in synth.make_batch(mcfg, n, seed=s, signal=signal).items()}
+        mk = lambda s, n=batch_size: {k: v.to(device) for k, v in synth.make_batch(mcfg, n, seed=s, signal=signal, overlap=overlap).items()}
         tbs = test_batch_size or batch_size
         self.fed_train_loader_x_dict, self.fed_test_loader_x_dict = {}, {}
         for c in range(num_clients):

@@ -3,7 +3,7 @@
 mode under every summation order the engine has a switch for, against the fp32 engine (which sits < 1e-4 from the oracle,
 same test).  One child process per variant: the C++ switches are read once per process.
 
-    python tools/rn_auc_ab.py [signal,lr,rounds,train_b,bs,bn3 ...]      (GPU box)
+    python tools/rn_auc_ab.py [signal,lr,rounds,train_b,bs,bn3[,test_b,overlap] ...]      (GPU box)
 
 Answers the round-5 advisor's question - is the 16-bit distance summation ORDER or a BIAS in one of the fused paths
 (FFM_EPI_BNBWD, split-K column sums, folded BatchNorm, four-stage ring)? - with the full A/B table, and prices the noise
@@ -35,13 +35,14 @@ def child(spec, prec):
     from tests.test_trainer_gpu import make_cfg
     p = spec.split(",")
     signal, lr, rounds, train_b, bs, bn3 = float(p[0]), float(p[1]), int(p[2]), int(p[3]), int(p[4]), float(p[5])
+    overlap = float(p[7]) if len(p) > 7 else 0.0
     mcfg = C.rn_tiny2(rank=4, num_groups=2)
     sd = synth.make_state_dict(mcfg, seed=1, lora_init="reference")
     for k in sd:
         if k.endswith("bn3.weight"):
             sd[k] = sd[k] * bn3
     data = SyntheticFedData(mcfg, 2, train_batches=train_b, test_batches=32, batch_size=bs, signal=signal, test_batch_size=64,
-                            attribute="gender")
+                            attribute="gender", overlap=overlap)
     cfg = make_cfg(prec=prec, bs=bs, rank=4)
     cfg.TEST.BATCH_SIZE = 64
     cfg.OPTIM.LR, cfg.OPTIM.STEPSIZE = lr, 200
@@ -67,7 +68,7 @@ if __name__ == "__main__":
         child(sys.argv[2], sys.argv[3])
         sys.exit(0)
     f = lambda v: "[" + ", ".join("%.5f" % x for x in v) + "]"
-    for spec in sys.argv[1:] or ["0.08,1e-3,5,12,32,0.0"]:
+    for spec in sys.argv[1:] or ["0.25,1e-3,3,12,32,0.25,32,0.3"]:
         a32 = run_child(spec, "fp32", {})
         print(f"{spec}: fp32 engine {f(a32)}", flush=True)
         for prec in ("bf16", "fp16"):
