@@ -39,8 +39,10 @@ def to_dev(batch):
 # Two fixtures.  "raw": every BatchNorm gamma ~ N(1, 0.1) - the random-weight trunk amplifies a perturbation ~1.5x per
 # Bottleneck in EVERY precision, so only the fp32 engine is held there.  "clip": bn3.weight x 0.1 - CLIP
 # zero-initialises the last BatchNorm of every Bottleneck (clip/model.py:545-548) and a trained ResNet's residual branches
-# are small next to its identity path: the stable regime in which the 16-bit modes carry REAL bounds (round 6: loss 5e-3 /
-# 2e-3, logits 8e-2 / 2e-2 of their scale for bf16 / fp16; the raw fixture's 16-bit bounds were 10 % / 0.75, i.e. nothing).
+# are small next to its identity path: the stable regime in which the 16-bit modes carry REAL bounds (round 6, measured ->
+# bound: bf16 loss 1.0e-3 -> 3e-3, logits 2.5e-2 -> 6e-2 of their scale, gradient cosine min / median 0.81 / 0.93 -> 0.7 / 0.9;
+# fp16 loss 2.3e-4 -> 1e-3, logits 4.0e-3 -> 1e-2, cosine 0.984 / 0.995 -> 0.95 / 0.99; the raw fixture's 16-bit bounds were
+# 10 % / 0.75, i.e. nothing).
 @pytest.mark.parametrize("fixture,dtype", [("raw", torch.float32), ("clip", torch.float32), ("clip", torch.bfloat16), ("clip", torch.float16)],
                          ids=["raw-f32", "clip-f32", "clip-bf16", "clip-f16"])
 def test_full_rn50_step_vs_oracle(fixture, dtype):
@@ -67,8 +69,8 @@ def test_full_rn50_step_vs_oracle(fixture, dtype):
     f32 = dtype == torch.float32
     print("rn50", fixture, dtype, "loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
     assert int(out["finite"]) == 1
-    loss_tol = {torch.float32: 1e-4, torch.bfloat16: 5e-3, torch.float16: 2e-3}[dtype]
-    logit_tol = {torch.float32: 5e-4, torch.bfloat16: 8e-2, torch.float16: 2e-2}[dtype]
+    loss_tol = {torch.float32: 1e-4, torch.bfloat16: 3e-3, torch.float16: 1e-3}[dtype]
+    logit_tol = {torch.float32: 5e-4, torch.bfloat16: 6e-2, torch.float16: 1e-2}[dtype]
     assert abs(float(out["loss"]) - float(loss)) <= loss_tol * abs(float(loss))
     # 53 convolutions + train-mode BatchNorm at batch 4: logits agree to 1.5e-4 of their scale (loss to 4e-6).  This
     # random-weight trunk amplifies a perturbation ~1.5x per Bottleneck (tools/rn_colstat_diag.py: the fp32 step with the
@@ -81,7 +83,7 @@ def test_full_rn50_step_vs_oracle(fixture, dtype):
         # under 2^-9 / 2^-11 perturbations, which is what the bf16-storage control below prices tensor by tensor)
         cs = sorted(cos(eng.params.view(k, "grad"), grads[k]) for k in keys if float(grads[k].abs().max()) > 0)
         print("rn50", fixture, dtype, "gradient cosine min / 5th percentile / median", cs[0], cs[len(cs) // 20], cs[len(cs) // 2])
-        assert cs[0] > 0.5 and cs[len(cs) // 2] > (0.9 if dtype == torch.bfloat16 else 0.99)
+        assert cs[0] > (0.7 if dtype == torch.bfloat16 else 0.95) and cs[len(cs) // 2] > (0.9 if dtype == torch.bfloat16 else 0.99)
     if f32:
         worst, werr = 1.0, 0.0
         for k in keys:
@@ -108,8 +110,9 @@ def test_full_rn50_step_vs_oracle(fixture, dtype):
 def test_full_rn50_f32_bs32_vs_oracle():
     """The fp32 RN50 engine AT THE BENCH SIZE (configs[4]: batch 32 - 100 352 rows in layer1, where the 128 x 128 products
     leave the <= 256-tile four-stage ring and take the two-buffer loop, csrc/gemm.hip) against the oracle's step on the host
-    (~10-20 s), on the CLIP-like fixture (bn3.weight x 0.1, clip/model.py:545-548): strict fp32 bounds - loss 1e-5, logits
-    1e-4 of their scale, every gradient's direction to 1e-3, BatchNorm running statistics to 1e-4."""
+    (~10-20 s), on the CLIP-like fixture (bn3.weight x 0.1, clip/model.py:545-548): strict fp32 bounds - loss 2e-6 (measured
+    8e-8), logits 2e-5 of their scale (3.8e-6), every gradient's direction to 5e-4 (1e-4; the largest single element 0.095 of
+    its tensor's scale - one flipped ReLU unit of layer4.2.bn2, see the batch-4 test), BatchNorm running statistics to 1e-4."""
     from fairfedmed_amd.engine_rn import create_engine
     from oracle import fairlora_oracle as O
     mcfg = C.rn50(rank=8, num_groups=2)
@@ -128,8 +131,8 @@ def test_full_rn50_f32_bs32_vs_oracle():
     loss, logits, grads = O.loss_and_grads(ref_sd, batch, mcfg, keys)
     print("rn50 f32 bs32 loss", float(out["loss"]), "oracle", float(loss), "logits rel", rel(out["logits"], logits))
     assert int(out["finite"]) == 1
-    assert abs(float(out["loss"]) - float(loss)) <= 1e-5 * abs(float(loss))
-    assert rel(out["logits"], logits) < 1e-4
+    assert abs(float(out["loss"]) - float(loss)) <= 2e-6 * abs(float(loss))
+    assert rel(out["logits"], logits) < 2e-5
     worst, werr = (1.0, ""), (0.0, "")
     for k in keys:
         g, ref = eng.params.view(k, "grad"), grads[k]
@@ -137,7 +140,7 @@ def test_full_rn50_f32_bs32_vs_oracle():
             assert float(g.abs().max()) < 1e-12, k
             continue
         worst, werr = min(worst, (cos(g, ref), k)), max(werr, (rel(g, ref), k))
-        assert cos(g, ref) > 1 - 1e-3 and rel(g, ref) < 0.12, (k, cos(g, ref), rel(g, ref))
+        assert cos(g, ref) > 1 - 5e-4 and rel(g, ref) < 0.2, (k, cos(g, ref), rel(g, ref))
     print("rn50 f32 bs32: worst gradient cosine", worst, "worst rel err", werr)
     bufs = eng.buffer_state()
     for k in synth.buffer_keys(mcfg):
