@@ -329,8 +329,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_nt_kernel(ffm_gemm_args p
 // ---- split over K across the grid (ABI 12, ffm_gemm_args.sk_part) ------------------------------------------------------------
 // The text tower's narrow products (N = 512: c_proj forward, dX(c_fc), dX(qkv)) give the kernels above 16 column groups, i.e.
 // 16 blocks that each walk K = 1536 / 2048 in two or three dependent memory round trips with 576 KB through ONE CU's L2 port:
-// 20-28 us per launch, three dozen launches per step on the side stream - at 8 waves x 150-240 registers, the footprint that
-// keeps a CU from the vision chain's next panel launch (docs/experiments.md E4.6).  Here the grid is (column groups) x (K
+// 20-28 us per launch, three dozen launches per step on the side stream - and all of the tower's products run at 8 waves x
+// 150-240 registers, the footprint that keeps a CU from the vision chain's next panel launch (docs/experiments.md E4.6).  Here the grid is (column groups) x (K
 // slices of 128): every block is 4 waves of ONE K32 step each - a single round trip, ~100 registers - and writes its 40 x 32
 // partial tile to scratch [slice][M][N]; a second small launch sums the slices IN ORDER (deterministic: no atomics) and
 // applies the epilogue.  More launches, but each is a few microseconds on many CUs with a footprint that fits beside a panel.
@@ -437,11 +437,13 @@ __global__ __launch_bounds__(256) void skinny_splitk_finish_kernel(ffm_gemm_args
     if (FL & FFM_EPI_GELU) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.c2) + o) = out2;
 }
 
-// which products are split: 40-odd rows, N so narrow that the one-launch kernel has fewer than 32 blocks, K of at least 8
-// slices; FFM_SKINNY_SPLITK=0 switches it off (A/B runs), =<n> moves the N bound
+// which products are split: at most 48 rows, N up to FFM_SKINNY_SPLITK (default 2048: every product of the text tower; 0
+// switches it off: A/B runs), K of at least FFM_SKINNY_SPLITK_MIN (default 4) slices of 128.  Measured on the bench step, three
+// alternating runs each in one call (profiles/r06_splitk_ab3.txt): off 4.669, N <= 512 only 4.677, all products 4.652 ms
 inline int sk_slices(int M, int N, int K) {
-    static const int nmax = getenv("FFM_SKINNY_SPLITK") ? atoi(getenv("FFM_SKINNY_SPLITK")) : 512;
-    if (M > 48 || N > nmax || N % 32 || K % SKS_K || K / SKS_K < 8 || K / SKS_K > 64) return 0;
+    static const int nmax = getenv("FFM_SKINNY_SPLITK") ? atoi(getenv("FFM_SKINNY_SPLITK")) : 2048;
+    static const int smin = getenv("FFM_SKINNY_SPLITK_MIN") ? atoi(getenv("FFM_SKINNY_SPLITK_MIN")) : 4;
+    if (M > 48 || N > nmax || N % 32 || K % SKS_K || K / SKS_K < smin || K / SKS_K > 64) return 0;
     return K / SKS_K;
 }
 

@@ -724,7 +724,7 @@ def test_skinny_gemm_f32(M, N, K, x3, mode):
     assert rel(out, ref) < tol, rel(out, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(40, 512, 2048), (40, 512, 1536), (33, 512, 1024), (48, 256, 2048), (1, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(40, 512, 2048), (40, 512, 1536), (40, 2048, 512), (40, 1536, 512), (33, 512, 1024), (48, 256, 2048), (1, 512, 2048)])
 @pytest.mark.parametrize("w16", [False, True], ids=["x3", "x3w16"])
 @pytest.mark.parametrize("mode", ["plain", "bias", "bias_res", "bias_gelu", "dgelu"])
 def test_skinny_gemm_split_over_k(M, N, K, w16, mode):
@@ -741,7 +741,7 @@ def test_skinny_gemm_split_over_k(M, N, K, w16, mode):
     res = torch.randn(M, N, device="cuda", generator=g)
     aux = torch.randn(M, N, device="cuda", generator=g)
     need = ops.gemm_splitk_floats(M, N, K, w16)
-    assert need == (K // 128) * M * N and ops.gemm_splitk_floats(M, 2048, 512, w16) == 0 and ops.gemm_splitk_floats(64, N, K, w16) == 0
+    assert need == (K // 128) * M * N and ops.gemm_splitk_floats(M, 4096, 512, w16) == 0 and ops.gemm_splitk_floats(64, N, K, w16) == 0 and ops.gemm_splitk_floats(M, N, 256, w16) == 0
     part = torch.full((need,), float("nan"), device="cuda")
     rel = lambda got, want: float((got.double() - want.double()).abs().max() / want.double().abs().max())
     ref = a.double() @ w.double().t()
