@@ -19,6 +19,7 @@ F32, BF16, F32_X3, F16 = 0, 1, 2, 3      # FFM_F16: IEEE half storage (the refer
 F32_X3_W16 = 4                           # FFM_F32_X3 with the weight operand stored as IEEE half
 EPI_BIAS, EPI_LORA, EPI_LORA_KR, EPI_RESIDUAL, EPI_GELU, EPI_DGELU, EPI_RANKOP = 1, 2, 4, 8, 16, 32, 64
 EPI_ROWSTATS, EPI_LNIN, EPI_LGRAD, EPI_BNBWD = 128, 256, 512, 1024
+EPI_LNB_STAT, EPI_LNB_APPLY = 2048, 4096
 ABI_VERSION = 12
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -39,6 +40,7 @@ class GemmArgs(C.Structure):
         ("lg_v", _vp), ("lg_part_c", _vp), ("lg_part_a", _vp),
         ("bn_x", _vp), ("bn_mask", _vp), ("bn_mean", _vp), ("bn_rstd", _vp), ("bn_gout", _vp),
         ("sk_part", _vp),
+        ("lnb_wg", _vp), ("lnb_d", _vp), ("lnb_part", _vp), ("lnb_np", _i32), ("lnb_pad_", _i32), ("lnb_x", _vp), ("lnb_gamma", _vp),
     ]
 
 

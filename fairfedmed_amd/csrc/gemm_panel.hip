@@ -46,10 +46,14 @@ bool plain_flags_ok(int flags) {
 
 bool rk_flags_ok(int flags, int rank) {
     if (rank <= 0 || rank > 16) return false;
+    if (flags & FFM_EPI_LNB_APPLY)                             // LayerNorm backward applied: the dX epilogue of c_fc only
+        return (flags & ~FFM_EPI_RANKOP) == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_LNB_APPLY);
     if (flags & FFM_EPI_LGRAD) {                               // the gradient partial products: the dX epilogue of c_proj only
-        if ((flags & ~FFM_EPI_RANKOP) != (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD) || rank % 4) return false;
+        // (... which may also leave LayerNorm-backward row sums: FFM_EPI_LNB_STAT rides on the LGRAD epilogue)
+        if ((flags & ~(FFM_EPI_RANKOP | FFM_EPI_LNB_STAT)) != (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD) || rank % 4) return false;
         return true;
     }
+    if (flags & FFM_EPI_LNB_STAT) return false;
     if ((flags & FFM_EPI_LNIN) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_LNIN)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_GELU))
         return false;                                          // ln_2 folded in: the c_fc forward epilogue only
     if ((flags & FFM_EPI_ROWSTATS) && (flags & ~(FFM_EPI_RANKOP | FFM_EPI_ROWSTATS)) != (FFM_EPI_BIAS | FFM_EPI_LORA | FFM_EPI_RESIDUAL))
@@ -95,6 +99,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         if (c == 5 || c == 6 || c == 9) continue;              // measured in round 3, lost, no longer instantiated
         if (cf.ks && K % 256) continue;                       // the K-split loop is unrolled by four K64 steps
         if ((flags & FFM_EPI_LGRAD) && c != 7) continue;      // instantiated for the 8-wave 208x384 tile only
+        if ((flags & FFM_EPI_LNB_APPLY) && c != 8) continue;  // ... and for the 4-wave 160x128 FairLoRA tile only
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)

@@ -110,9 +110,12 @@ __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }   
 // f32 | row groups [BM]
 // | (LNIN) c [BN] f32, row mean / rstd [BM] f32 each
 // | (LGRAD) the forward ts rows of the other adapter [BM][r] f32 (room for r = 16)
-__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4, bool lgrad = false) {
-    return pw * 16 * nf * 4 + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) + (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0) +
-           (lgrad ? 16 * mf * 64 : 0);
+// | (LNB_STAT) W gamma [BN], W beta + b [BN] f32      | (LNB_APPLY: the LNIN block - gamma in c's place - and c1, c2 [BM] f32)
+__host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4, bool lgrad = false, bool lnbs = false,
+                                                bool lnba = false) {
+    // (LNB_STAT's two vectors sit right behind the bias: one address register serves all three in the chunk loop)
+    return pw * 16 * nf * 4 + (lnbs ? 2 * pw * 16 * nf * 4 : 0) + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) +
+           (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0) + (lgrad ? 16 * mf * 64 : 0) + (lnba ? 2 * 16 * mf * 4 : 0);
 }
 
 // Two blocks per CU (two waves per SIMD) for the 128 x 256 plain tile: 128 accumulator registers and a 64 KiB ring
@@ -142,6 +145,13 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // per row tile in the output epilogue (see there) instead of by two kernels that read 2 x M x N elements once more
     constexpr bool LGRAD = (FL & FFM_EPI_LGRAD) != 0;
     static_assert(!LGRAD || (RK && (FL & FFM_EPI_DGELU) && !KS), "LGRAD rides on the DGELU + RANKOP epilogue");
+    // LayerNorm backward folded into the two dX products of the MLP (include/ffm_hip.h, FFM_EPI_LNB_*): LNBS - this launch
+    // (dX of c_proj) leaves the two row sums per column tile; LNBA - this launch (dX of c_fc) applies
+    // rstd (gamma g_h - c1/K - xhat c2/K) + res to its rows instead of storing g_h
+    constexpr bool LNBS = (FL & FFM_EPI_LNB_STAT) != 0, LNBA = (FL & FFM_EPI_LNB_APPLY) != 0;
+    static_assert(!LNBS || LGRAD, "LNB_STAT rides on the LGRAD epilogue (its chunk loop holds dpre and pre)");
+    static_assert(!LNBA || (RK && !KS && !(FL & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU | FFM_EPI_GELU | FFM_EPI_LNIN | FFM_EPI_ROWSTATS | FFM_EPI_BIAS))),
+                  "LNB_APPLY: the plain FairLoRA dX epilogue");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -295,6 +305,20 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // small loads waits ~150 cycles for an issue slot (3 us per block, tools/panel_stamps.py)
     constexpr bool LNIN_ = (FL & FFM_EPI_LNIN) != 0;
     f32x2 lnpv[8];
+    float lnb_mu = 0.f, lnb_rs = 0.f;
+    if constexpr (LNBA) {
+        // LNB_APPLY: the producer's partial row sums {P1, P2} and the LayerNorm's saved statistics of this thread's tile row
+        static_assert(16 * MF <= PT, "one tile row per thread");
+        const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int qq = q < p.lnb_np ? q : 0;
+            const float* src = p.lnb_part + ((size_t)qq * p.M + gm) * 2;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lnpv[q]) : "v"(src) : "memory");
+        }
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb_mu) : "v"(p.ln_mean + gm) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lnb_rs) : "v"(p.ln_rstd + gm) : "memory");
+    }
     if constexpr (LNIN_) {
         static_assert(16 * MF <= PT, "one tile row per thread");
         const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
@@ -313,21 +337,27 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PARTB = KS ? CW * (MF * NF + (RK ? TI : 0)) * 1024 : 0;
     constexpr int PBASE = PARTB > G::RING ? PARTB : G::RING;
     float* Bias = reinterpret_cast<float*>(smem + PBASE);
-    bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
+    constexpr bool LNBS_ = (FL & FFM_EPI_LNB_STAT) != 0, LNBA_ = (FL & FFM_EPI_LNB_APPLY) != 0;
+    float* Wgv = Bias + BNp;                                  // LNB_STAT: W gamma [BN]
+    float* Dvv = Wgv + BNp;                                   //           W beta + b [BN]
+    bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + (LNBS_ ? 3 : 1) * BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
     float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
     int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
     constexpr bool LNIN = (flags & FFM_EPI_LNIN) != 0, ROWST = (flags & FFM_EPI_ROWSTATS) != 0;
-    float* Cv = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, false, CW));     // LNIN: c [BN]
+    float* Cv = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, false, CW, false, LNBS_));     // LNIN: c [BN] (LNB_APPLY: gamma)
     float* Mu = Cv + BNp;                                     // row means [BM]
     float* Rs = Mu + BMp;                                     // row 1 / sqrt(var + eps) [BM]
-    float* V1F = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, LNIN, CW));      // LGRAD: lg_v rows [BM][r]
+    constexpr bool LNX = LNIN || LNBA;                        // (LNB_APPLY uses the LNIN block: gamma in c's place, mean, rstd)
+    float* V1F = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, LNX, CW, false, LNBS_));      // LGRAD: lg_v rows [BM][r]
+    float* C1v = reinterpret_cast<float*>(smem + PBASE + persist_bytes(MF, NF, RK, LNX, CW, LGRAD, LNBS_));   // LNB_APPLY: c1 [BM]
+    float* C2v = C1v + BMp;                                   //            c2 [BM]
     const int r = RK ? p.rank : 0;
     // bias, c (LNIN), lora_S and the rows' group ids: inline-asm loads with clamped indices, consumed behind the ONE
     // vmcnt(0) below.  As compiler-visible loads each of them (a conditional load followed by its LDS store) was answered
     // with its own s_waitcnt vmcnt(0) behind the ring fills: four to six memory round trips in a row in every launch.
     constexpr int NBI = (BNp + PT - 1) / PT, NGI = (BMp + PT - 1) / PT;
-    float biasv[NBI], cvv[NBI], sgv = 0.f;
+    float biasv[NBI], cvv[NBI], wgv[NBI], dvv[NBI], sgv = 0.f;
     int gav[NGI];
     auto ldgf = [](const float* q) -> float {
         float v;
@@ -337,9 +367,14 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
 #pragma unroll
     for (int it = 0; it < NBI; ++it) {
         const int i = tid + it * PT, ic = i < BNp ? i : BNp - 1;
-        biasv[it] = cvv[it] = 0.f;
+        biasv[it] = cvv[it] = wgv[it] = dvv[it] = 0.f;
         if constexpr ((flags & FFM_EPI_BIAS) != 0) biasv[it] = ldgf(p.bias + n0 + ic);
         if constexpr (LNIN) cvv[it] = ldgf(p.ln_c + n0 + ic);
+        if constexpr (LNBA) cvv[it] = ldgf(p.lnb_gamma + n0 + ic);
+        if constexpr (LNBS) {
+            wgv[it] = ldgf(p.lnb_wg + n0 + ic);
+            dvv[it] = ldgf(p.lnb_d + n0 + ic);
+        }
     }
 #pragma unroll
     for (int it = 0; it < NGI; ++it) gav[it] = -1;
@@ -453,11 +488,15 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     asm volatile("" : "+v"(sgv));
 #pragma unroll
     for (int it = 0; it < NBI; ++it) {
-        asm volatile("" : "+v"(biasv[it]), "+v"(cvv[it]));
+        asm volatile("" : "+v"(biasv[it]), "+v"(cvv[it]), "+v"(wgv[it]), "+v"(dvv[it]));
         const int i = tid + it * PT;
         if (i < BNp) {
             Bias[i] = biasv[it];
-            if constexpr (LNIN) Cv[i] = cvv[it];
+            if constexpr (LNX) Cv[i] = cvv[it];
+            if constexpr (LNBS) {
+                Wgv[i] = wgv[it];
+                Dvv[i] = dvv[it];
+            }
         }
     }
     if constexpr (RK) {
@@ -493,6 +532,25 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 if (p.ln_mean) p.ln_mean[gm] = mu;
                 if (p.ln_rstd) p.ln_rstd[gm] = rs;
             }
+        }
+    }
+    if constexpr (LNBA) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(lnpv[q]));
+        asm volatile("" : "+v"(lnb_mu), "+v"(lnb_rs));
+        if (tid < BMp) {
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                  // fixed order over the producer's column tiles
+                if (q < p.lnb_np) {
+                    p1 += lnpv[q][0];
+                    p2 += lnpv[q][1];
+                }
+            }
+            Mu[tid] = lnb_mu;
+            Rs[tid] = lnb_rs;
+            C1v[tid] = p1;                                 // (the rank-r corrections are added behind the main loop)
+            C2v[tid] = p2;
         }
     }
     __syncthreads();
@@ -689,14 +747,19 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     bf16_t* C = reinterpret_cast<bf16_t*>(p.c);
 
     // residual / pre-activation rows of the first row groups: issued now, consumed after the rank-r update
-    constexpr bool PRE = (flags & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU)) != 0;
-    const bf16_t* prep = reinterpret_cast<const bf16_t*>((flags & FFM_EPI_RESIDUAL) ? p.res : p.aux);
+    constexpr bool PRE = (flags & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU)) != 0 || LNBA;
+    const bf16_t* prep = reinterpret_cast<const bf16_t*>(((flags & FFM_EPI_RESIDUAL) || LNBA) ? p.res : p.aux);
     bf16x8 rpre[PF][NF];
+    // LNB_APPLY: a second stream beside the residual gradient - the LayerNorm's input rows; the two loads of a chunk are
+    // issued back to back (LPB loads per chunk in the counted waits below)
+    constexpr int LPB = LNBA ? 2 : 1;
+    const bf16_t* prep2 = reinterpret_cast<const bf16_t*>(p.lnb_x);
+    bf16x8 rpre2[LNBA ? PF : 1][NF];
     // The loads are inline asm with hand-counted waits, like the weight fragments of the main loop: left to the
     // compiler, every use of a prefetched row group became s_waitcnt vmcnt(0), which also waits for the stores just
     // issued and for the two younger prefetches (dX(c_proj): 26 us of output epilogue for 13 us of HBM traffic).
     // Rows beyond M (last row tile) are clamped: loaded, never stored.
-    auto load_pre = [&](int rg, bf16x8 (&dst)[NF]) {
+    auto load_pre = [&](int rg, bf16x8 (&dst)[NF], bf16x8 (&dst2)[NF]) {
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             const int idx = lane + 64 * i, row = idx / CPR, ch = idx % CPR;
@@ -704,6 +767,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             gm = gm < p.M ? gm : p.M - 1;
             const bf16_t* src = prep + (size_t)gm * p.ldc + n0w + ch * 8;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[i]) : "v"(src) : "memory");
+            if constexpr (LNBA) {
+                const bf16_t* src2 = prep2 + (size_t)gm * p.ldc + n0w + ch * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst2[i]) : "v"(src2) : "memory");
+            }
         }
     };
     // VMEM operations younger than the load of (row group q >= PF, chunk i), which is issued at the end of group q - PF:
@@ -714,7 +781,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     const bool full_tile = m0 + BMp <= p.M;
     if constexpr (PRE) {
 #pragma unroll
-        for (int g = 0; g < PF; ++g) load_pre(g, rpre[g]);
+        for (int g = 0; g < PF; ++g) load_pre(g, rpre[g], rpre2[LNBA ? g : 0]);
     }
 
     if constexpr (RK) {
@@ -738,6 +805,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
         float lncj = 0.f, lndj = 0.f;
         if constexpr (LNIN) {
             lncj = p.ln_rk[j];
+            lndj = jok ? p.ln_rk[16 + j] : 0.f;
+        }
+        if constexpr (LNBA) {                          // (A^T gamma)[j], (A^T beta)[j]
+            lncj = jok ? p.ln_rk[j] : 0.f;
             lndj = jok ? p.ln_rk[16 + j] : 0.f;
         }
         float ssum = 0.f;
@@ -784,6 +855,24 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     TsA[(row0 + e) * 32 + j] = (bf16_t)tsv[e];
                     TsA[(row0 + e) * 32 + 16 + j] = (bf16_t)0.f;
                     if constexpr (LGRAD) V2F[(row0 + e) * 16 + j] = lg_split(tsv[e]);      // ts rows as hi | lo pairs (zero beyond M and beyond r)
+                }
+                if constexpr (LNBA) {
+                    // the rank-r part of the two LayerNorm-backward row sums: c1 += sum_j us[j] (A^T gamma)[j],
+                    // c2 -= sum_j us[j] (A^T beta)[j] - tsv IS us (rank slot j = frow of row 4 fgrp + e; zero beyond r and M);
+                    // the 16 slots of a row sit in one 16-lane group: four butterfly steps, fixed order
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float k1 = tsv[e] * lncj, k2 = tsv[e] * lndj;
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            k1 += __shfl_xor(k1, o, 64);
+                            k2 += __shfl_xor(k2, o, 64);
+                        }
+                        if (frow == 0) {
+                            C1v[row0 + e] += k1;
+                            C2v[row0 + e] -= k2;
+                        }
+                    }
                 }
                 if (mine && jok) {
 #pragma unroll
@@ -891,6 +980,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // (the accumulators are born in the first row group, behind its stage writes: the AGPRs of the main accumulator's
     // first two fragment rows are free from there on, and the epilogue has no VGPRs to spare on the 8-wave tile)
     f32x4 lgc[NF], lga[NF];
+    // LNB_STAT: per chunk {s1, s2} of the row group in flight, [32 rows][CPR] f32x2 in the wave's own slab of the LoRA-matrix
+    // tile (dead once `lb` above has been read: wave-private, no barrier); per wave and row the sums go to RowP
+    const uint32_t lnq = (uint32_t)(uintptr_t)(reinterpret_cast<char*>(LwB) + colw * WN * 64);
+    static_assert(!LNBS || 32 * CPR * 8 <= WN * 64, "the chunk sums of a row group fit the wave's LoRA-matrix slab");
     const uint32_t t_img = (uint32_t)(uintptr_t)Cw;
     const uint32_t t_rd = t_img + (8 * fgrp + (frow >> 2)) * 2 * TROW + 8 * (lane & 3);     // lane 4q + p of a group: row q, columns 4p..
     static_for<NRG>([&](auto RG_) {
@@ -915,6 +1008,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             const int gm = m0 + rg * 32 + row;
             const bool ok = gm < p.M && rg * 32 + row < BMp;
             float v[8];
+            bf16x8 d8s;                                      // LNB_STAT: the chunk as stored (dpre)
+            (void)d8s;
             const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8]);
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cw[row * PITCH + ch * 8 + 4]);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bias[colw * WN + ch * 8]);
@@ -942,9 +1037,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     constexpr int last_odd = (rg == NRG - 1 && (MF & 1)) ? 1 : 0;
                     constexpr int batches = (PF - 1) - ((rg - 1 + PF >= NRG) ? 1 : 0) - ((rg - 2 + PF >= NRG && PF >= 3) ? 1 : 0);
                     static_assert(PF <= 3, "the count below walks at most two groups back");
-                    constexpr int young_base = (PF - 1) * NF * SPC + (batches > 0 ? batches : 0) * NF;
+                    constexpr int young_base = (PF - 1) * NF * SPC + (batches > 0 ? batches : 0) * NF * LPB;
                     // (i is a loop variable of an unrolled loop: the switch folds to one immediate per copy)
-                    const int young = young_base + (NF - 1 - i) + (last_odd ? 0 : i * SPC);
+                    const int young = young_base + (NF - 1 - i) * LPB + (last_odd ? 0 : i * SPC);
                     if (!full_tile) wait_vm<0>();
                     else switch (young) {
 #define FFM_WV(n) case n: wait_vm<n>(); break;
@@ -959,10 +1054,25 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     }
                 }
                 asm volatile("" : "+v"(rpre[rg % PF][i]));
+                if constexpr (LNBA) asm volatile("" : "+v"(rpre2[rg % PF][i]));
             }
             if constexpr ((flags & FFM_EPI_RESIDUAL) != 0) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] += (float)rpre[rg % PF][i][c];
+            }
+            if constexpr (LNBA) {
+                // LayerNorm backward on the row: rstd (gamma g_h - c1/K - xhat c2/K) + the gradient of the residual path
+                const int trow = rg * 32 + row < BMp ? rg * 32 + row : BMp - 1;
+                const float mu = Mu[trow], rs = Rs[trow], invk = 1.0f / (float)p.N;
+                const float c1 = C1v[trow] * invk, c2 = C2v[trow] * invk;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(&Cv[colw * WN + ch * 8]);
+                const f32x4 g1 = *reinterpret_cast<const f32x4*>(&Cv[colw * WN + ch * 8 + 4]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xh = ((float)rpre2[rg % PF][i][c] - mu) * rs;
+                    const float gm_ = c < 4 ? g0[c & 3] : g1[c & 3];
+                    v[c] = rs * (gm_ * v[c] - c1 - xh * c2) + (float)rpre[rg % PF][i][c];
+                }
             }
             if constexpr (LGRAD) {
                 // (gelu_deriv == 0 here: the launcher checks) derivative and activation from one sigmoid; both chunks into
@@ -977,6 +1087,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     d8[c] = (bf16_t)v[c];
                     a8[c] = (bf16_t)ga;
                 }
+                if constexpr (LNBS) d8s = d8;
                 if constexpr (rg == NRG - 1 && (MF & 1)) {
                     // the last group of an odd MF has 16 rows; the other 16 stage rows hold what the previous group's images
                     // left there - any bit pattern, NaN included, and 0 x NaN is what a masked V row would make of it
@@ -1035,6 +1146,59 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     Vec8<bf16_t>::store(C + off, v);
                 }
             }
+            // (behind the stores: v, the activation chunk and the images' operands are dead here - the tile has 128 registers)
+            if constexpr (LNBS) {
+                // LNB_STAT: this chunk's share of the two row sums, on the values AS STORED (d8s) and the pre-activation
+                // chunk in hand: {sum dpre (W gamma), sum dpre (pre - d)}; the row's CPR chunks meet in the wave's own
+                // (dead) LoRA-matrix slab right behind the chunk loop
+                // (one address register for the three vectors - they sit BNp floats apart behind the bias; four columns at
+                // a time: the tile has no registers to spare)
+                const uint32_t va = (uint32_t)(uintptr_t)&Bias[colw * WN + ch * 8];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 wq, eq;
+                    if (h == 0) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq) : "v"(va), "n"(BNp * 4) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(eq) : "v"(va), "n"(BNp * 8) : "memory");
+                    } else {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq) : "v"(va), "n"(BNp * 4 + 16) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(eq) : "v"(va), "n"(BNp * 8 + 16) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq), "+v"(eq)::"memory");
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = (float)d8s[4 * h + c];
+                        s1 += x * wq[c];
+                        s2 += x * ((float)rpre[rg % PF][i][4 * h + c] - eq[c]);
+                    }
+                }
+                f32x2 sq = {s1, s2};
+                // chunk (row, ch) has index row * CPR + ch = lane + 64 i in the group's table
+                // (the lane id from mbcnt: `lane` itself is not kept live across the epilogue of this 128-register tile)
+                const uint32_t ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                const uint32_t qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)lnq) + (ln_ + 64u * i) * 8u;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(qa), "v"(sq) : "memory");
+            }
+        }
+        if constexpr (LNBS) {
+            // rows of the group: lane r < 32 sums its row's CPR chunks in chunk order (LDS executes a wave's operations in
+            // order: the writes above have landed) and leaves the wave's partial in RowP
+            const int ln_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            if (ln_ < 32 && rg * 32 + ln_ < BMp) {
+                float a1 = 0.f, a2 = 0.f;
+                const f32x2* q = reinterpret_cast<const f32x2*>(reinterpret_cast<char*>(LwB) + colw * WN * 64) + ln_ * CPR;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < CPR; ++c) {
+                    const f32x2 t = q[c];
+                    a1 += t[0];
+                    a2 += t[1];
+                }
+                RowP[(colw * BMp + rg * 32 + ln_) * 2] = a1;
+                RowP[(colw * BMp + rg * 32 + ln_) * 2 + 1] = a2;
+            }
+            asm volatile("" ::: "memory");
         }
         if constexpr (LGRAD) {
             // one operand after the other (registers): V fragment (rank slot frow, rows 8 fgrp .. + 7 of the group) as a
@@ -1091,7 +1255,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
         }
         if constexpr (PRE) {
-            if constexpr (rg + PF < NRG) load_pre(rg + PF, rpre[rg % PF]);
+            if constexpr (rg + PF < NRG) load_pre(rg + PF, rpre[rg % PF], rpre2[LNBA ? rg % PF : 0]);
         }
         fence();
     });
@@ -1116,6 +1280,21 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     p.lg_part_c[o + jj] = lgc[cf][e];
                     p.lg_part_a[o + jj] = lga[cf][e];
                 }
+            }
+        }
+    }
+    if constexpr (LNBS) {
+        __syncthreads();
+        for (int i = tid; i < BMp; i += ET) {
+            if (m0 + i < p.M) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < CW; ++w) {                        // fixed order over the column slabs
+                    a1 += RowP[(w * BMp + i) * 2];
+                    a2 += RowP[(w * BMp + i) * 2 + 1];
+                }
+                f32x2 o = {a1, a2};
+                *reinterpret_cast<f32x2*>(p.lnb_part + ((size_t)tn * p.M + m0 + i) * 2) = o;
             }
         }
     }
@@ -1147,9 +1326,11 @@ int launch_panel(const ffm_gemm_args& a, hipStream_t s) {
     using G = PanelGeom<MF, RK, PWV>;
     const int tiles = ((a.M + 16 * MF - 1) / (16 * MF)) * (a.N / (CW * 16 * NF));
     constexpr int partb = KS ? CW * (MF * NF + (RK ? (MF + CW - 1) / CW : 0)) * 1024 : 0;      // K split: partial accumulators
-    constexpr int lds = (partb > G::RING ? partb : G::RING) + persist_bytes(MF, NF, RK, (FL & FFM_EPI_LNIN) != 0, CW, (FL & FFM_EPI_LGRAD) != 0);
+    constexpr int lds = (partb > G::RING ? partb : G::RING) +
+                        persist_bytes(MF, NF, RK, (FL & (FFM_EPI_LNIN | FFM_EPI_LNB_APPLY)) != 0, CW, (FL & FFM_EPI_LGRAD) != 0,
+                                      (FL & FFM_EPI_LNB_STAT) != 0, (FL & FFM_EPI_LNB_APPLY) != 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert((RK ? 16 * MF * 192 : 0) + CW * 32 * stage_pitch(NF) * 4 + ((FL & FFM_EPI_ROWSTATS) ? CW * 16 * MF * 8 : 0) <= G::RING,
+    static_assert((RK ? 16 * MF * 192 : 0) + CW * 32 * stage_pitch(NF) * 4 + ((FL & (FFM_EPI_ROWSTATS | FFM_EPI_LNB_STAT)) ? CW * 16 * MF * 8 : 0) <= G::RING,
                   "epilogue tiles alias the ring");
     if (KS && (a.K % 256)) return FFM_EUNSUP;         // the K-split loop is unrolled by four K64 steps
     static bool done = false;                         // one per instantiation

@@ -22,6 +22,9 @@ int ffm_panel_launch_rk2(const ffm_gemm_args& a, int cfg, hipStream_t s) {
             return FFM_EINVAL;
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                      // dX of c_proj
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR)                                      // dX of c_fc
+        case FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_LNB_APPLY:                           // ... applying ln_2's backward
+            if (cfg == 8) return ffm_panel::launch_panel<10, 2, true, FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_LNB_APPLY>(a, s);
+            return FFM_EINVAL;
     }
     return FFM_EINVAL;
 }

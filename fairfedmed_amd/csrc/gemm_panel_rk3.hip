@@ -18,6 +18,7 @@ int ffm_panel_launch_rk3(const ffm_gemm_args& a, int cfg, hipStream_t s) {
             return FFM_EINVAL;
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU)                      // dX of c_proj
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD)      // ... with the two gradient partial products
+        PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD | FFM_EPI_LNB_STAT)   // ... and ln_2's backward row sums
         PANEL_RK_CASE(FFM_EPI_LORA | FFM_EPI_LORA_KR)                                      // dX of c_fc
     }
     return FFM_EINVAL;

@@ -244,6 +244,10 @@ class _Stack:
         # embed_lnpre) for the ln_1 that is folded into the qkv product: up to 8 column tiles
         self.rowp = [f(8 * T * 2) for _ in range(layers + 1)] if (rank and _is16(dtype)) else None
         self.rowp2 = [f(8 * T * 2) for _ in range(layers)] if (rank and _is16(dtype)) else None   # ... of xm (ln_2)
+        # ln_2's BACKWARD folded into dX(c_proj) / dX(c_fc) (FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY): the producer's partial row
+        # sums, consumed by the very next launch - one buffer per tower; rows -> column tiles of the producer (0: not folded)
+        self.lnb_part = f(8 * T * 2) if (rank and _is16(dtype)) else None
+        self.foldb = {}
         self.fold = {}                                       # rows -> (np of the c_proj forward, ok) decision cache
         self.fold2 = {}                                      # rows -> np of the out-proj forward (ln_2 into c_fc)
         if rank:
@@ -621,6 +625,26 @@ class FairLoRAEngine:
             st.fold2[rows] = npo if (npo > 0 and npo <= 8 and nf > 0 and w % 128 == 0 and r <= 16) else 0
         return st.fold2[rows]
 
+    def _fold_ln2_bwd(self, st: _Stack, rows: int, blk: _Block) -> int:
+        """ln_2's BACKWARD folded into the two dX products around it (round 6; include/ffm_hip.h FFM_EPI_LNB_*): 0 - the
+        LayerNorm backward runs as its own kernel; otherwise the column tiles of the dX product of c_proj, which leaves the
+        two row sums beside its FFM_EPI_LGRAD partial products, and the dX product of c_fc stores dL/d x_mid directly.
+        Needs the forward fold (its W gamma / W beta + b / A^T gamma / A^T beta vectors), the LGRAD epilogue and both
+        kernels for this row count.  FFM_LNB_FOLD=0: off (A/B runs)."""
+        if st.lnb_part is None or os.environ.get("FFM_LNB_FOLD", "1") == "0":
+            return 0
+        if rows not in st.foldb:
+            w, r = st.width, st.rank
+            n = 0
+            if self._fold_ln2(st, rows) and self._lgrad_rows(st, rows, blk) > 0:
+                f1 = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_DGELU | L.EPI_RANKOP | L.EPI_LGRAD | L.EPI_LNB_STAT
+                f2 = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_RANKOP | L.EPI_LNB_APPLY
+                n1 = ops.gemm_tiles_n(rows, 4 * w, w, f1, r, st.dtype, True)
+                n2 = ops.gemm_tiles_n(rows, w, 4 * w, f2, r, st.dtype, True)
+                n = n1 if (0 < n1 <= 8 and n2 > 0) else 0
+            st.foldb[rows] = n
+        return st.foldb[rows]
+
     def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
                        save: bool = True) -> Tensor:
         """x[0][:rows] holds the tower input; returns the tower output view."""
@@ -715,13 +739,16 @@ class FairLoRAEngine:
                 # holds dpre and (through pre) act in registers - per row tile, into the buffers the two reduction launches
                 # they replace would have filled (77 MB per block that the side stream no longer reads beside the chain)
                 lg = self._lgrad_rows(st, rows, blk) if fused else 0
+                # ln_2's backward rides in this block's two dX products (not block 0 of a tower that stops there)
+                lnb = self._fold_ln2_bwd(st, rows, blk) if (fused and lg and not last) else 0
                 if fused:
                     ro = ops.RankOp(self.rk[i]["proj_B"], self._S(i, "proj"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us2, t_fwd=st.t2[i][:rows], ds_part=pt["proj_S"],
                                     lw_wide=self.lw_wide[i].get("proj_A"),
                                     lgrad=(st.ts1[i][:rows], pt["fc_B"], pt["proj_A"]) if lg else None)
                     gemm(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
-                                dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"))
+                                dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"),
+                                lnb_stat=ops.LnBwdStat(blk.c_fc, blk.d_fc, st.lnb_part) if lnb else None)
                 else:
                     ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._S(i, "proj"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])
@@ -732,8 +759,15 @@ class FairLoRAEngine:
                     ro = ops.RankOp(self.rk[i]["fc_B"], self._S(i, "fc"), attr, rows_per_sample,
                                     lo.scaling, lo.lambda_group, ts_out=us1, t_fwd=st.t1[i][:rows], ds_part=pt["fc_S"],
                                     lw_wide=self.lw_wide[i].get("fc_A"))
-                    gemm(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
-                                rankop=ro, b_packed=blk.pk("w_fc_t"))
+                    if lnb:
+                        # ... and stores dL/d x_mid = LayerNorm backward(g_h) + gi directly: no ffm_layernorm_bwd launch
+                        gemm(dpre, blk.w_fc_t, g1, lw=self._lora_view(blk, "fc_A"), lw_is_kr=True, rankop=ro,
+                             b_packed=blk.pk("w_fc_t"),
+                             lnb_apply=ops.LnBwdApply(st.lnb_part, lnb, xm, blk.ln2_w, st.st2[i][0], st.st2[i][1],
+                                                      self.rk[i]["fc_A_lnrk"], gi))
+                    else:
+                        gemm(dpre, blk.w_fc_t, st.dh[:rows], lw=self._lora_view(blk, "fc_A"), lw_is_kr=True,
+                             rankop=ro, b_packed=blk.pk("w_fc_t"))
                 else:
                     if last:
                         # the dX chain ends with this down projection: the three reductions that do not need its result
@@ -787,9 +821,11 @@ class FairLoRAEngine:
                 gout = st.g_l[i - 1][:rows] if i > 0 else g
             else:
                 gi, dpre, gout = g, st.dpre[:rows], g
+                lnb = 0
                 gemm(gi, blk.w_proj_t, dpre, dgelu_aux=pre)
                 gemm(dpre, blk.w_fc_t, st.dh[:rows])
-            ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], gi, g1)
+            if not lnb:
+                ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], gi, g1)
             gemm(g1, blk.w_out_t, st.do[:rows], b_packed=blk.pk("w_out_t"))
             ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
                               images, st.L, st.heads, st.causal)

@@ -140,6 +140,24 @@ class LnIn:
         self.rk = rk          # with a RankOp: [2, 16] corrections of its gamma-scaled rank operand (PackPlan's ln output)
 
 
+class LnBwdStat:
+    """FFM_EPI_LNB_STAT (the dX product of c_proj, with a RankOp that carries `lgrad`): also leave the two row sums of the
+    LayerNorm backward that follows the NEXT dX product - part [tiles_n, M, 2] fp32 <- {sum_n c wg[n], sum_n c (aux - d[n])}
+    per column tile; wg = W gamma (LnIn's c), d = W beta + b (the folded forward's bias) of that LayerNorm-folded product."""
+
+    def __init__(self, wg: Tensor, d: Tensor, part: Tensor):
+        self.wg, self.d, self.part = wg, d, part
+
+
+class LnBwdApply:
+    """FFM_EPI_LNB_APPLY (the dX product of c_fc): store rstd (gamma g_h - c1/K - xhat c2/K) + res instead of g_h, with the
+    row sums from a LnBwdStat producer's `part` (np column tiles), x the LayerNorm's input, mean / rstd its saved statistics,
+    gamma its weight, rk [2, 16] the corrections {A^T gamma, A^T beta} (LnIn.rk of the forward), res the residual gradient."""
+
+    def __init__(self, part: Tensor, np_: int, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, rk: Tensor, res: Tensor):
+        self.part, self.np, self.x, self.gamma, self.mean, self.rstd, self.rk, self.res = part, np_, x, gamma, mean, rstd, rk, res
+
+
 def pack_b(w: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """Frozen 16-bit weight [N, K] -> MFMA-fragment order for the panel GEMM (ffm_pack_b)."""
     _dev(w, out)
@@ -156,7 +174,8 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
             gelu_out=None, dgelu_aux=None, rankop: Optional[RankOp] = None, b_packed: Optional[Tensor] = None,
             x3: bool = False, rowstats: Optional[Tensor] = None, ln_in: Optional["LnIn"] = None,
             colstats: Optional[Tensor] = None, gelu_deriv: bool = False, bnbwd=None,
-            sk_part: Optional[Tensor] = None) -> Tensor:
+            sk_part: Optional[Tensor] = None, lnb_stat: Optional[LnBwdStat] = None,
+            lnb_apply: Optional[LnBwdApply] = None) -> Tensor:
     """out = epilogue(a @ b.T);  a [M,K], b [N,K], out [M,N] (same dtype).  b_packed: pack_b(b), optional.
     x3 (float32 operands, at most 64 rows): FFM_F32_X3, the products as bf16 hi/lo pairs on the bf16 matrix cores; with
     `b` in float16: FFM_F32_X3_W16, the same on a weight rounded to IEEE half in memory (half the bytes).
@@ -238,10 +257,31 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
         assert _f32(bn_mean).numel() == N and _f32(bn_rstd).numel() == N
         flags |= L.EPI_BNBWD
         bnx = (L.ptr(bn_x), L.ptr(bn_mask), L.ptr(bn_mean), L.ptr(bn_rstd), L.ptr(bn_gout))
+    lnb = (None, None, None, 0, 0, None, None)
+    res_ptr = L.ptr(res)
+    if lnb_stat is not None:
+        _dev(lnb_stat.wg, lnb_stat.d, lnb_stat.part)
+        flags |= L.EPI_LNB_STAT
+        tn = gemm_tiles_n(M, N, K, flags, rank, a.dtype, b_packed is not None)
+        assert tn > 0 and (flags & L.EPI_LGRAD), "FFM_EPI_LNB_STAT rides on the FFM_EPI_LGRAD epilogue: ask gemm_tiles_n first"
+        assert _f32(lnb_stat.wg).numel() == N and _f32(lnb_stat.d).numel() == N and _f32(lnb_stat.part).numel() >= 2 * M * tn
+        lnb = (L.ptr(lnb_stat.wg), L.ptr(lnb_stat.d), L.ptr(lnb_stat.part), 0, 0, None, None)
+    if lnb_apply is not None:
+        la = lnb_apply
+        _dev(la.part, la.x, la.gamma, la.mean, la.rstd, la.rk, la.res)
+        assert res is None and ln_in is None and bias is None and ro is not None
+        flags |= L.EPI_LNB_APPLY
+        assert 0 < la.np <= 8 and _f32(la.part).numel() >= 2 * M * la.np and _f32(la.gamma).numel() == N
+        assert la.x.dtype == out.dtype and tuple(la.x.shape) == (M, N) and _ld(la.x) == _ld(out)
+        assert la.res.dtype == out.dtype and tuple(la.res.shape) == (M, N) and _ld(la.res) == _ld(out)
+        assert _f32(la.mean).numel() >= M and _f32(la.rstd).numel() >= M and _f32(la.rk).numel() == 32
+        lnb = (None, None, L.ptr(la.part), la.np, 0, L.ptr(la.x), L.ptr(la.gamma))
+        lnx = (None, None, L.ptr(la.mean), L.ptr(la.rstd), 0, int(gelu_deriv), L.ptr(la.rk))
+        res_ptr = L.ptr(la.res)
     args = L.GemmArgs(L.ptr(a), L.ptr(b), L.ptr(out), M, N, K, _ld(a), _ld(b), _ld(out), flags, rank,
-                      L.ptr(bias), L.ptr(ts), L.ptr(lw), L.ptr(res), L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
+                      L.ptr(bias), L.ptr(ts), L.ptr(lw), res_ptr, L.ptr(gelu_out), L.ptr(dgelu_aux), *extra,
                       L.ptr(b_packed), L.ptr(ro.lw_wide) if ro is not None else None, L.ptr(rowstats), *lnx,
-                      L.ptr(_f32(colstats)), *lgx, *bnx, L.ptr(_f32(sk_part)))
+                      L.ptr(_f32(colstats)), *lgx, *bnx, L.ptr(_f32(sk_part)), *lnb)
     if sk_part is not None:                        # x3 products split over K: scratch for the partial tiles (gemm_splitk_floats)
         _dev(sk_part)
         assert x3 and sk_part.numel() >= gemm_splitk_floats(M, N, K, w16)

@@ -52,7 +52,7 @@ extern "C" {
 #define FFM_MAX_GROUPS 8
 
 /* library / build identification: returns FFM_ABI_VERSION */
-#define FFM_ABI_VERSION 12  /* 12: ffm_gemm_args.sk_part + ffm_gemm_splitk_floats (text-tower products split over K), ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd / bn_gout), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
+#define FFM_ABI_VERSION 12  /* 12: FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY (LayerNorm backward folded into the dX products of the MLP; ffm_gemm_args.lnb_*), ffm_gemm_args.sk_part + ffm_gemm_splitk_floats (text-tower products split over K), ffm_scale_acc, ffm_loss_scale / ffm_unscale_check / ffm_sgd_momentum_gated (device-resident fp16 gradient scale); 11: FFM_EPI_BNBWD (ffm_gemm_args.bn_x / bn_mask / bn_mean / bn_rstd / bn_gout), ffm_bn_bwd part_rows; 10: ffm_lora_down_blocks is exact again, ffm_lora_down_blocks_max sizes buffers, ffm_slice_wgrad_blocks (wpart rows, no longer ffm_slice_blocks); 9: FFM_EPI_LGRAD (ffm_gemm_args.lg_v / lg_part_c / lg_part_a), ffm_gemm_lgrad_rows; 8: FFM_F16 (IEEE-half twins of every 16-bit kernel behind the same entry points), ffm_scale_check; 7: ffm_text_embed / ffm_text_tail_fwd / ffm_text_tail_bwd / ffm_text_ctx_grad; 6: FFM_F32_X3, ffm_gemm_args.lw_wide / LayerNorm folding fields, ffm_pack_desc.dst_wide, ffm_eval_counts_sorted, ffm_gemm_tiles_n, colstat_part / ffm_bn_fwd part_rows; 5: ffm_sgd_momentum_n; 4: ffm_reduce_partials_multi launch width (max_n), new entry points (conv3x3, eval counts, uint8) */
 int ffm_abi_version(void);
 
 /* ---- epilogue flags for ffm_gemm_nt ------------------------------------ */
@@ -73,6 +73,18 @@ int ffm_abi_version(void);
 #define FFM_EPI_LNIN      256 /* consumer: b / b_packed hold W', bias holds d, ln_c holds c; rows are normalised in the epilogue */
 #define FFM_EPI_LGRAD     512 /* with DGELU | RANKOP: also lg_part_c / lg_part_a, two rank-r gradient partial products (below) */
 #define FFM_EPI_BNBWD     1024 /* colstat_part receives the BatchNorm-BACKWARD column sums of the stored output (bn_* below) */
+/* ABI 12: LayerNorm's BACKWARD folded into the two dX products around it (the MLP's ln_2, clip/model.py:304-310, 354-357).
+ * With h = LayerNorm(x), pre = h W_eff^T + b and g_h = dpre W_eff, autograd's dL/dx = rstd (gamma g_h - c1/K - xhat c2/K)
+ * needs two row sums that are linear in what the dX product of c_proj holds per element:
+ *   c1 = sum_k g_h gamma      = sum_n dpre[n] (W gamma)[n]      + sum_j us[j] (A^T gamma)[j]
+ *   c2 = sum_k g_h gamma xhat = sum_n dpre[n] (pre[n] - d[n])   - sum_j us[j] (A^T beta)[j],     d = W beta + b
+ * (us = scaling s_b (dpre B^T), the rank vector the dX product of c_fc forms anyway; W gamma, d, A^T gamma, A^T beta are the
+ * vectors the forward's FFM_EPI_LNIN folding already builds).  FFM_EPI_LNB_STAT (producer, with DGELU | RANKOP | LGRAD): the
+ * dX product of c_proj leaves lnb_part[tn][m] = {sum_n c[m][n] lnb_wg[n], sum_n c[m][n] (aux[m][n] - lnb_d[n])} over its
+ * columns.  FFM_EPI_LNB_APPLY (consumer, with LORA | LORA_KR | RANKOP): the dX product of c_fc stores
+ * rstd (gamma g_h - c1/K - xhat c2/K) + res instead of g_h - one launch (ffm_layernorm_bwd) and a round trip of g_h fewer. */
+#define FFM_EPI_LNB_STAT  2048
+#define FFM_EPI_LNB_APPLY 4096
 
 typedef struct ffm_gemm_args {
     const void* a;      /* [M, K] dtype, row stride lda (elements) */
@@ -164,6 +176,19 @@ typedef struct ffm_gemm_args {
      * small launch sums them IN SLICE ORDER (deterministic) and applies the epilogue - instead of a handful of blocks each
      * walking the whole K.  NULL: the one-launch kernel. */
     float*       sk_part;
+    /* FFM_EPI_LNB_STAT: lnb_wg, lnb_d [N] fp32 (W gamma and W beta + b of the LayerNorm-folded FORWARD product whose dX this
+     * launch is followed by); lnb_part [ffm_gemm_tiles_n][M][2] fp32 is written.
+     * FFM_EPI_LNB_APPLY: lnb_part holds lnb_np (<= 8) such partial rows, lnb_x [M, N] (dtype, stride ldc) is the LayerNorm's
+     * input, lnb_gamma [N] its weight, ln_mean / ln_rstd [M] its saved statistics (inputs here), ln_rk [2][16] the
+     * corrections {A^T gamma, A^T beta} (as under FFM_EPI_LNIN | FFM_EPI_RANKOP), res the gradient that joins behind the
+     * LayerNorm (the residual path). */
+    const float* lnb_wg;
+    const float* lnb_d;
+    float*       lnb_part;
+    int          lnb_np;
+    int          lnb_pad_;
+    const void*  lnb_x;
+    const float* lnb_gamma;
 } ffm_gemm_args;
 
 /*

@@ -776,6 +776,115 @@ def test_skinny_gemm_split_over_k(M, N, K, w16, mode):
     assert rel(out, one) < 5e-6
 
 
+@pytest.mark.parametrize("M,r,G,use_attr", [(6304, 8, 3, True), (6250, 16, 2, False), (5000, 4, 3, True), (3000, 8, 3, True)])
+@H16
+def test_gemm_panel_layernorm_backward_fold(ops, M, r, G, use_attr, h16):
+    """FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY (ABI 12): ln_2's backward folded into the two dX products of the MLP.
+    (1) the dX product of c_proj leaves {sum_n dpre (W gamma), sum_n dpre (pre - d)} per row and column tile - float64 on the
+    16-bit rows it stored - and nothing else it writes moves; (2) the dX product of c_fc, fed those partial rows, stores
+    rstd (gamma g_h - c1/K - xhat c2/K) + res: held to float64 autograd THROUGH LayerNorm -> FairLoRA linear on the same
+    operands (the algebra of include/ffm_hip.h), and to the unfolded pair (plain dX product, then ffm_layernorm_bwd)."""
+    dt = h16
+    width, rps = 768, 197
+    N, K = 4 * width, width                                            # c_fc: x [M, 768] -> pre [M, 3072]
+    flags1 = 2 | 4 | 32 | 64 | 512 | 2048
+    tn = ops.gemm_tiles_n(M, N, K, flags1, r, dt, True)
+    nlg = ops.gemm_lgrad_rows(M, N, K, r, dt, True)
+    n2 = ops.gemm_tiles_n(M, K, N, 2 | 4 | 64 | 4096, r, dt, True)
+    if tn <= 0 or nlg <= 0 or n2 <= 0:
+        pytest.skip("no FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY kernel pair for this shape or tile mask (the engine then launches "
+                    "ffm_layernorm_bwd: FairLoRAEngine._fold_ln2_bwd asks the same two questions)")
+    g = lambda *sh, **k: rnd(*sh, **k)
+    # the LayerNorm-folded forward product: pre = LN(x) W_eff^T + b
+    x = g(M, K, dt=dt, seed=301)
+    gamma, beta = 1 + 0.1 * g(K, seed=302), 0.1 * g(K, seed=303)
+    Wfc = g(N, K, dt=dt, scale=K ** -0.5, seed=304)                     # frozen c_fc weight [3072, 768]
+    bfc = 0.1 * g(N, seed=305)
+    A, Bm, S = g(K, r, scale=0.1, seed=306), g(r, N, scale=0.1, seed=307), g(G, r, seed=308)
+    nsamp = (M + rps - 1) // rps
+    attr = torch.randint(0, G, (nsamp,), device="cuda", dtype=torch.int32) if use_attr else None
+    pi = mix(attr, G)
+    rows = torch.arange(M, device="cuda") // rps
+    sb = (pi[rows] if attr is not None else pi.expand(M, G)) @ S.double()                  # [M, r]
+    sigma = 0.25
+    xd = x.double().requires_grad_(True)
+    mu = xd.mean(-1, keepdim=True)
+    rstd = (xd.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    xh = (xd - mu) * rstd
+    h = xh * gamma.double() + beta.double()
+    pre64 = h @ Wfc.double().t() + bfc.double() + sigma * ((h @ A.double()) * sb) @ Bm.double()
+    pre = pre64.detach().to(dt)                                        # what the forward stored
+    # ---- launch 1: dX of c_proj (its own operands are arbitrary here: what matters is the dpre it stores)
+    gi = g(M, K, dt=dt, seed=310)
+    Wpt = g(N, K, dt=dt, scale=K ** -0.5, seed=311)
+    P2, S2, lw2 = g(K, r, scale=0.1, seed=312), g(G, r, seed=313), g(N, r, seed=314)
+    rk2 = torch.zeros(16, K, device="cuda", dtype=dt)
+    ops.PackPlan([(P2, False, rk2)], dt, "cuda").run()
+    nrows = ops.gemm_tiles_m(M, N, K, 2 | 4 | 32 | 64, r, dt, True)
+    ts1, t_fwd = g(M, r, seed=315), g(M, r, seed=316)
+    wg = (Wfc.double() @ gamma.double()).float()
+    dvec = (Wfc.double() @ beta.double() + bfc.double()).float()
+    bp = ops.pack_b(Wpt)
+
+    def run1(stat):
+        out = torch.empty(M, N, device="cuda", dtype=dt)
+        t, ts = torch.full((M, r), float("nan"), device="cuda"), torch.full((M, r), float("nan"), device="cuda")
+        dsp = torch.full((nrows, G, r), float("nan"), device="cuda")
+        pc, pa = torch.full((nlg, N, r), float("nan"), device="cuda"), torch.full((nlg, N, r), float("nan"), device="cuda")
+        ro = ops.RankOp(rk2, S2, attr, rps, sigma, 0.7, t_out=t, ts_out=ts, t_fwd=t_fwd, ds_part=dsp, lgrad=(ts1, pc, pa))
+        ops.gemm_nt(gi, Wpt, out, lw=lw2, lw_is_kr=True, rankop=ro, b_packed=bp, dgelu_aux=pre, lnb_stat=stat)
+        return out, t, ts, dsp, pc, pa
+
+    part = torch.full((tn, M, 2), float("nan"), device="cuda")
+    got = run1(ops.LnBwdStat(wg, dvec, part))
+    base = run1(None)
+    for a_, b_ in zip(got, base):
+        assert torch.equal(a_, b_), "FFM_EPI_LNB_STAT must not move anything else the launch writes"
+    dpre = got[0]
+    assert not torch.isnan(part).any()
+    P = part.double().sum(0)
+    ref1 = (dpre.double() * wg.double()).sum(-1)
+    ref2 = (dpre.double() * (pre.double() - dvec.double())).sum(-1)
+    check(P[:, 0], ref1, 2e-5, "sum dpre (W gamma)")
+    check(P[:, 1], ref2, 2e-5, "sum dpre (pre - d)")
+    # ---- launch 2: dX of c_fc with the LayerNorm backward applied
+    Wfct = Wfc.t().contiguous()                                        # [768, 3072]: the dX product's B operand
+    rk1 = torch.zeros(16, N, device="cuda", dtype=dt)
+    ops.PackPlan([(Bm.t().contiguous(), False, rk1)], dt, "cuda").run()    # u = dpre B^T: rank operand = B_fc [N, r]
+    gres = g(M, K, dt=dt, seed=320)
+    mean32, rstd32 = mu.detach().float().reshape(-1).contiguous(), rstd.detach().float().reshape(-1).contiguous()
+    ag = torch.zeros(2, 16, device="cuda")
+    ag[0, :r] = (A.double().t() @ gamma.double()).float()
+    ag[1, :r] = (A.double().t() @ beta.double()).float()
+    nrows2 = ops.gemm_tiles_m(M, K, N, 2 | 4 | 64, r, dt, True)
+    t_fwd1 = g(M, r, seed=321)
+    bp2 = ops.pack_b(Wfct)
+
+    def run2(apply):
+        out = torch.full((M, K), float("nan"), device="cuda", dtype=dt)
+        us = torch.full((M, r), float("nan"), device="cuda")
+        dsp = torch.full((nrows2, G, r), float("nan"), device="cuda")
+        ro = ops.RankOp(rk1, S, attr, rps, sigma, 0.7, ts_out=us, t_fwd=t_fwd1, ds_part=dsp)
+        ops.gemm_nt(dpre, Wfct, out, lw=A, lw_is_kr=True, rankop=ro, b_packed=bp2, lnb_apply=apply)
+        return out, us, dsp
+
+    g1, us, dsp = run2(ops.LnBwdApply(part, tn, x, gamma, mean32, rstd32, ag, gres))
+    gh, us0, dsp0 = run2(None)
+    assert torch.equal(us, us0) and torch.equal(dsp, dsp0)
+    assert not torch.isnan(g1.float()).any()
+    # float64 autograd through LayerNorm -> FairLoRA linear with the dpre the first launch stored
+    (pre64 * dpre.double()).sum().backward()
+    ref = xd.grad + gres.double()
+    check(g1, ref, tol(dt), "folded LayerNorm backward vs float64 autograd")
+    # the unfolded pair: plain dX product (g_h rounded to 16 bits), then ffm_layernorm_bwd with the residual
+    g1u = torch.empty(M, K, device="cuda", dtype=dt)
+    ops.layernorm_bwd(gh, x, gamma, mean32, rstd32, gres, g1u)
+    check(g1, g1u.double(), 2 * tol(dt), "against the unfolded pair")
+    # ... and the fold is the closer of the two to float64 (g_h is never rounded to 16 bits on its way)
+    err = lambda t_: float((t_.double() - ref).abs().max() / ref.abs().max())
+    print("LayerNorm backward fold: max error vs float64", err(g1), " unfolded pair", err(g1u))
+
+
 def test_skinny_x3_tiles_per_block_switch():
     """FFM_SKINNY_NT (read once per process): the text tower's X3 product with 1 / 2 / 4 column tiles per block
     (csrc/gemm_skinny.hip, gemm_skinny_nt_kernel: the tiles of a block share the activation fragments).  The partial sums
