@@ -100,6 +100,8 @@ SIGNATURES = {
     "ffm_scale_check": [_vp, _f32, _i64, _vp, _vp],
     "ffm_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "ffm_attention_bwd_lnstat_ok": [_i32, _i32, _i32],
+    "ffm_attention_bwd_lnstat": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "ffm_lora_down": [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
                       _i32, _vp],
     "ffm_lora_down_blocks": [_i32, _i32, _i32, _i32],

@@ -1100,7 +1100,7 @@ int dispatch_bwd(int nfp, const void* qkv, const void* out, const void* dout, co
 // attention3.hip
 int ffm_attn3_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int dtype, hipStream_t s);
 int ffm_attn3_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
-                  int dtype, hipStream_t s);
+                  int dtype, hipStream_t s, const float* ln_wg, const float* ln_d, float* ln_part);
 
 extern "C" int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int heads, int causal,
                                  int dtype, void* stream) {
@@ -1136,7 +1136,7 @@ extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* d
     const int nfp = (((L + 15) / 16) + 1) & ~1;
     hipStream_t s = (hipStream_t)stream;
     if ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed()) {
-        const int e = ffm_attn3_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, dtype, s);
+        const int e = ffm_attn3_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, dtype, s, nullptr, nullptr, nullptr);
         if (e != FFM_EUNSUP) return e;
     }
     if (dtype == FFM_BF16 && !causal && !attn_v1_forced()) {
@@ -1152,4 +1152,22 @@ extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* d
     if (dtype == FFM_BF16) return dispatch_bwd<bf16_t>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
     if (dtype == FFM_F32) return dispatch_bwd<float>(nfp, qkv, out, dout, lse, delta, dqkv, B, L, heads, causal, s);
     return FFM_EINVAL;
+}
+
+// ffm_attention_bwd that ALSO leaves the two row sums of the LayerNorm backward behind the in-projection's dX product
+// (include/ffm_hip.h): ln_part [2 heads][B L][2] - slot h: the q columns of head h (dQ kernel), slot heads + h: its k and v
+// columns (dK/dV kernel).  Served by the third-generation kernels only (16-bit storage, no mask, 65..256 tokens):
+// FFM_EUNSUP otherwise, and nothing is launched
+// (ffm_attention_bwd_lnstat_ok says so beforehand).
+extern "C" int ffm_attention_bwd_lnstat_ok(int L, int causal, int dtype) {
+    return ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed() && L > 64 && L <= 256) ? 1 : 0;
+}
+
+extern "C" int ffm_attention_bwd_lnstat(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                        const float* ln_wg, const float* ln_d, float* ln_part, int B, int L, int heads, int causal,
+                                        int dtype, void* stream) {
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv || !ln_wg || !ln_d || !ln_part || B <= 0 || L <= 0 || heads <= 0) return FFM_EINVAL;
+    if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)ln_wg | (uintptr_t)ln_d) & 15) return FFM_EINVAL;
+    if (!ffm_attention_bwd_lnstat_ok(L, causal, dtype)) return FFM_EUNSUP;
+    return ffm_attn3_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, dtype, (hipStream_t)stream, ln_wg, ln_d, ln_part);
 }

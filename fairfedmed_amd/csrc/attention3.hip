@@ -250,6 +250,42 @@ __device__ __forceinline__ void store_rows(T* __restrict__ row_ptr, const f32x16
         }
 }
 
+// The same store, also forming this lane's share of the two LayerNorm-backward row sums of ln_1 (include/ffm_hip.h,
+// FFM_EPI_LNB_*; the qkv product is LayerNorm-folded, so with dqkv the gradient of its output and x the stored qkv values
+//   c1 = sum_n dqkv[n] (W gamma)[n],   c2 = sum_n dqkv[n] (qkv[n] - d[n]),   d = W beta + b ):
+// the 16-byte chunk a lane stores (8 consecutive head dims 16 ks + 8 h ..) lines up with the fragment xf[ks] of the same row
+// it has held since the prologue; tab = {W gamma, d} of this 64-column slice in LDS ([2][64] floats).  s1 / s2 accumulate over
+// the lane's 32 head dims; the other 32 are in lane ^ 32.
+template <typename T>
+__device__ __forceinline__ void store_rows_stat(T* __restrict__ row_ptr, const f32x16 (&o)[2], float scale, int lane,
+                                                const typename A3<T>::frag (&xf)[4], const float* tab, float& s1, float& s2) {
+    const int hb = (lane >> 5) * 16;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            typedef __attribute__((ext_vector_type(8))) T t8;
+            t4 a = {(T)(o[dt][4 * i] * scale), (T)(o[dt][4 * i + 1] * scale), (T)(o[dt][4 * i + 2] * scale), (T)(o[dt][4 * i + 3] * scale)};
+            t4 b = {(T)(o[dt][4 * i + 4] * scale), (T)(o[dt][4 * i + 5] * scale), (T)(o[dt][4 * i + 6] * scale), (T)(o[dt][4 * i + 7] * scale)};
+            u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+            const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(row_ptr) + 64 * dt + 16 * i + hb) = v;
+            const t8 g8 = __builtin_bit_cast(t8, v);                    // the 8 values AS STORED: head dims 32 dt + 8 i + 8 h + 0..7
+            const int ks = 2 * dt + i / 2, d0 = 16 * ks + (hb >> 1);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(tab + d0), w1 = *reinterpret_cast<const f32x4*>(tab + d0 + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(tab + 64 + d0), e1 = *reinterpret_cast<const f32x4*>(tab + 64 + d0 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = (float)g8[j];
+                s1 += g * (j < 4 ? w0[j & 3] : w1[j & 3]);
+                s2 += g * ((float)xf[ks][j] - (j < 4 ? e0[j & 3] : e1[j & 3]));
+            }
+        }
+}
+
 template <int NT> struct Geo {
     static constexpr int NW = (NT + 1) / 2;                     // waves per block = 32-token tiles of the larger half
     static constexpr int NCH = (NT + 1) / 2;                    // DMA chunks of two swept tiles (64 rows = 8 pieces per operand)
@@ -445,13 +481,15 @@ void attn3_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __r
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
-                         const T* __restrict__ o_fwd, T* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, int BH, int map) {
+                         const T* __restrict__ o_fwd, T* __restrict__ dqkv, float* __restrict__ delta, int L, int heads, int BH, int map,
+                         const float* __restrict__ ln_wg, const float* __restrict__ ln_d, float* __restrict__ ln_part) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int R8 = (L + 7) & ~7, NP = R8 >> 3, rmax = R8 - 1;
     char* Ks = smem;
     char* Vs = smem + R8 * 128;
+    float* tabs = reinterpret_cast<float*>(smem + 2 * R8 * 128);                // ln_part: {W gamma, d} of this head's q columns, [2][64]
     int bh, part;
     unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
@@ -478,6 +516,12 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
         asm_load16<0>(ov[0], op); asm_load16<32>(ov[1], op); asm_load16<64>(ov[2], op); asm_load16<96>(ov[3], op);
         asm_load4(lq, lse + ((size_t)b * heads + hd) * L + qr);
     }
+    // ln_1's backward row sums (ln_part != NULL, uniform): threads 0..31 fetch the two 64-float tables of this head's q columns
+    u32x4 tabv = {0u, 0u, 0u, 0u};
+    if (ln_part) {
+        const int ti = threadIdx.x & 31;
+        asm_load16<0>(tabv, (ti < 16 ? ln_wg : ln_d) + hd * HD + 4 * (ti & 15));
+    }
     dma_chunk<T, NT>(0, base + E, ld, Ks, base + 2 * E, ld, Vs, L, NP, wave, lane);
     constexpr bool LOADS_ONLY = (FFM_ATTN3_ABL & 1) != 0;
     if constexpr (LOADS_ONLY || GE::NCH > 1) {
@@ -494,6 +538,10 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
                  : "n"(LOADS_ONLY ? 0 : GE::NCH > 1 ? 2 * GE::RC : 0)
                  : "memory");
     if constexpr (LOADS_ONLY) return;
+    // (the table load was issued behind the fragment loads and IN FRONT of the DMA pieces of chunks 0 / 1: the counted wait
+    // above has it too - vmcnt retires in order)
+    asm volatile("" : "+v"(tabv));
+    if (ln_part && threadIdx.x < 32) reinterpret_cast<u32x4*>(tabs)[threadIdx.x] = tabv;      // visible behind chunk 0's barrier
     frag qf[4], dof[4];
     float dl = 0.f;
 #pragma unroll
@@ -561,7 +609,19 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
     if constexpr (GE::NCH > 1) chunk(std::integral_constant<int, 1>{});
     if constexpr (GE::NCH > 2) chunk(std::integral_constant<int, 2>{});
     if constexpr (GE::NCH > 3) chunk(std::integral_constant<int, 3>{});
-    if (active && q < L) store_rows<T>(dqkv + ((size_t)b * L + q) * ld + hd * HD, dq, 0.125f, lane);
+    if (ln_part) {
+        float s1 = 0.f, s2 = 0.f;
+        if (active && q < L) store_rows_stat<T>(dqkv + ((size_t)b * L + q) * ld + hd * HD, dq, 0.125f, lane, qf, tabs, s1, s2);
+        s1 += xhalf(s1);
+        s2 += xhalf(s2);
+        // partial row [slot = head] of the q columns; the k and v columns' [heads + head] comes from the dK/dV kernel
+        if (active && q < L && h == 0) {
+            f32x2 o2 = {s1, s2};
+            *reinterpret_cast<f32x2*>(ln_part + ((size_t)hd * ((size_t)(BH / heads) * L) + (size_t)b * L + q) * 2) = o2;
+        }
+    } else if (active && q < L) {
+        store_rows<T>(dqkv + ((size_t)b * L + q) * ld + hd * HD, dq, 0.125f, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -573,7 +633,8 @@ void attn3_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, c
 template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
-                          const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH, int map) {
+                          const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH, int map,
+                          const float* __restrict__ ln_wg, const float* __restrict__ ln_d, float* __restrict__ ln_part) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -582,6 +643,7 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     char* dOs = smem + R8 * 128;
     float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);              // [32 NT]: -8 lse (-inf beyond L)
     float* del_s = lse_s + 32 * NT;                                             // [32 NT]: -delta (0 beyond L)
+    float* tabs = del_s + 32 * NT;                                              // ln_part: {W gamma, d} of the k | v columns, [2][2][64]
     int bh, part;
     unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
@@ -617,6 +679,11 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
             asm_load4(dv_[j], delta + o);
         }
     }
+    u32x4 tabv = {0u, 0u, 0u, 0u};
+    if (ln_part) {                                                              // threads 0..63: k tables, then v tables
+        const int ti = tid & 63, part_ = ti >> 5, tj = ti & 31;
+        asm_load16<0>(tabv, (tj < 16 ? ln_wg : ln_d) + (1 + part_) * E + hd * HD + 4 * (tj & 15));
+    }
     dma_chunk<T, NT>(0, base, ld, Qs, dob, E, dOs, L, NP, wave, lane);
     constexpr bool LOADS_ONLY = (FFM_ATTN3_ABL & 1) != 0;
     if constexpr (LOADS_ONLY || GE::NCH > 1) {
@@ -632,6 +699,8 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
                  : "n"(LOADS_ONLY ? 0 : GE::NCH > 1 ? 2 * GE::RC : 0)
                  : "memory");
     if constexpr (LOADS_ONLY) return;
+    asm volatile("" : "+v"(tabv));
+    if (ln_part && tid < 64) reinterpret_cast<u32x4*>(tabs)[tid] = tabv;         // [k: wg, d][v: wg, d], visible behind chunk 0's barrier
     A3_STAMP(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -713,7 +782,20 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     if constexpr (GE::NCH > 2) chunk(std::integral_constant<int, 2>{});
     if constexpr (GE::NCH > 3) chunk(std::integral_constant<int, 3>{});
     A3_STAMP(3);
-    if (active && key < L) {
+    if (ln_part) {
+        float s1 = 0.f, s2 = 0.f;
+        if (active && key < L) {
+            T* drow = dqkv + ((size_t)b * L + key) * ld + hd * HD;
+            store_rows_stat<T>(drow + E, dk, 0.125f, lane, kf, tabs, s1, s2);
+            store_rows_stat<T>(drow + 2 * E, dv, 1.0f, lane, vf, tabs + 128, s1, s2);
+        }
+        s1 += xhalf(s1);
+        s2 += xhalf(s2);
+        if (active && key < L && h == 0) {
+            f32x2 o2 = {s1, s2};
+            *reinterpret_cast<f32x2*>(ln_part + ((size_t)(heads + hd) * ((size_t)(BH / heads) * L) + (size_t)b * L + key) * 2) = o2;
+        }
+    } else if (active && key < L) {
         T* drow = dqkv + ((size_t)b * L + key) * ld + hd * HD;
         store_rows<T>(drow + E, dk, 0.125f, lane);
         store_rows<T>(drow + 2 * E, dv, 1.0f, lane);
@@ -747,8 +829,9 @@ int run_fwd3(const void* qkv, void* out, float* lse, int B, int L, int heads, hi
 }
 template <typename T, int NT>
 int run_bwd3(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
-             hipStream_t s) {
-    const int R8 = (L + 7) & ~7, lds_dq = 2 * R8 * 128, lds_dkv = 2 * R8 * 128 + 2 * 32 * NT * 4, BH = B * heads;
+             hipStream_t s, const float* ln_wg, const float* ln_d, float* ln_part) {
+    // (+ 512 / 1024 B: the LayerNorm-backward tables of the head; three blocks per CU still fit at 197 tokens)
+    const int R8 = (L + 7) & ~7, lds_dq = 2 * R8 * 128 + 512, lds_dkv = 2 * R8 * 128 + 2 * 32 * NT * 4 + 1024, BH = B * heads;
     int e = set_lds3(attn3_bwd_dq_kernel<T, NT>, lds_dq);
     if (e) return e;
     e = set_lds3(attn3_bwd_dkv_kernel<T, NT>, lds_dkv);
@@ -758,10 +841,10 @@ int run_bwd3(const void* qkv, const void* out, const void* dout, const float* ls
     // holding both kernels' blocks with delta recomputed in the dK/dV blocks: 4.74 against 4.72 ms per step, three alternating
     // pairs - nothing)
     hipLaunchKernelGGL((attn3_bwd_dq_kernel<T, NT>), grid, block, lds_dq, s, (const T*)qkv, (const T*)dout, lse, (const T*)out, (T*)dqkv,
-                       delta, L, heads, BH, a3_map());
+                       delta, L, heads, BH, a3_map(), ln_wg, ln_d, ln_part);
     FFM_CHECK_LAUNCH();
     hipLaunchKernelGGL((attn3_bwd_dkv_kernel<T, NT>), grid, block, lds_dkv, s, (const T*)qkv, (const T*)dout, lse, (const float*)delta,
-                       (T*)dqkv, L, heads, BH, a3_map());
+                       (T*)dqkv, L, heads, BH, a3_map(), ln_wg, ln_d, ln_part);
     FFM_CHECK_LAUNCH();
     return FFM_OK;
 }
@@ -792,16 +875,16 @@ int ffm_attn3_fwd(const void* qkv, void* out, float* lse, int B, int L, int head
     return FFM_EUNSUP;
 }
 int ffm_attn3_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
-                  int dtype, hipStream_t s) {
+                  int dtype, hipStream_t s, const float* ln_wg, const float* ln_d, float* ln_part) {
     if (L <= 64 || L > 256) return FFM_EUNSUP;
 #define BWD3(T)                                                                               \
     switch ((L + 31) / 32) {                                                                  \
-        case 3: return run_bwd3<T, 3>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
-        case 4: return run_bwd3<T, 4>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
-        case 5: return run_bwd3<T, 5>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
-        case 6: return run_bwd3<T, 6>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
-        case 7: return run_bwd3<T, 7>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
-        case 8: return run_bwd3<T, 8>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s);      \
+        case 3: return run_bwd3<T, 3>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
+        case 4: return run_bwd3<T, 4>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
+        case 5: return run_bwd3<T, 5>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
+        case 6: return run_bwd3<T, 6>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
+        case 7: return run_bwd3<T, 7>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
+        case 8: return run_bwd3<T, 8>(qkv, out, dout, lse, delta, dqkv, B, L, heads, s, ln_wg, ln_d, ln_part);      \
     }
     if (dtype == FFM_BF16) { BWD3(bf16_t) }
     if (dtype == FFM_F16) { BWD3(f16_t) }

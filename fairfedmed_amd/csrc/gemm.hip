@@ -986,8 +986,8 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     if (dtype == FFM_F32_X3 || dtype == FFM_F32_X3_W16) return FFM_EUNSUP;      // split-operand products: skinny shapes only
     if (a.flags & (FFM_EPI_LNB_STAT | FFM_EPI_LNB_APPLY)) {              // LayerNorm backward folded in: one panel tile each
         if ((a.flags & FFM_EPI_LNB_STAT) && (!a.lnb_wg || !a.lnb_d || !a.lnb_part)) return FFM_EINVAL;
-        if ((a.flags & FFM_EPI_LNB_APPLY) && (!a.lnb_part || a.lnb_np <= 0 || a.lnb_np > 8 || !a.lnb_x || ((uintptr_t)a.lnb_x & 15) ||
-                                             !a.lnb_gamma || !a.ln_mean || !a.ln_rstd || !a.ln_rk || !a.res || ((uintptr_t)a.res & 15)))
+        if ((a.flags & FFM_EPI_LNB_APPLY) && (!a.lnb_part || a.lnb_np <= 0 || a.lnb_np > (rk ? 8 : 24) || !a.lnb_x || ((uintptr_t)a.lnb_x & 15) ||
+                                             !a.lnb_gamma || !a.ln_mean || !a.ln_rstd || (rk && !a.ln_rk) || !a.res || ((uintptr_t)a.res & 15)))
             return FFM_EINVAL;
         const int cfgn = (a.b_packed && !a.colstat_part) ? ffm_panel_select(a.M, a.N, a.K, a.flags, a.rank, dtype, true) : -1;
         return cfgn >= 0 ? ffm_panel_launch(a, cfgn, s) : FFM_EUNSUP;

@@ -39,7 +39,8 @@ bool plain_flags_ok(int flags) {
         case FFM_EPI_BIAS:
         case FFM_EPI_BIAS | FFM_EPI_RESIDUAL:
         case FFM_EPI_BIAS | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS:      // out-proj forward leaving row sums for ln_2
-        case FFM_EPI_BIAS | FFM_EPI_LNIN: return true;                 // qkv forward with ln_1 folded in
+        case FFM_EPI_BIAS | FFM_EPI_LNIN:                              // qkv forward with ln_1 folded in
+        case FFM_EPI_LNB_APPLY: return true;                           // dX of qkv applying ln_1's backward
     }
     return false;
 }
@@ -99,7 +100,7 @@ int ffm_panel_select(int M, int N, int K, int flags, int rank, int dtype, bool p
         if (c == 5 || c == 6 || c == 9) continue;              // measured in round 3, lost, no longer instantiated
         if (cf.ks && K % 256) continue;                       // the K-split loop is unrolled by four K64 steps
         if ((flags & FFM_EPI_LGRAD) && c != 7) continue;      // instantiated for the 8-wave 208x384 tile only
-        if ((flags & FFM_EPI_LNB_APPLY) && c != 8) continue;  // ... and for the 4-wave 160x128 FairLoRA tile only
+        if ((flags & FFM_EPI_LNB_APPLY) && c != (rk ? 8 : 2)) continue;  // ... and for the 4-wave 160x128 tiles only
         if ((flags & FFM_EPI_ROWSTATS) && ((2 * cf.nf) & (2 * cf.nf - 1))) continue;   // row sums: power-of-two lanes per row
         // measured (tools/bench_panel.py): with a plain epilogue and a short K the 256-wide tile does not pay for the
         // un-overlapped prologue / store burst of a single round (qkv, K = 768: 34.6 us against 32.5 us)
@@ -151,6 +152,9 @@ int ffm_panel_launch(const ffm_gemm_args& a, int cfg, hipStream_t s) {
         PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_RESIDUAL)
         PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_RESIDUAL | FFM_EPI_ROWSTATS)
         PANEL_CASE(FFM_EPI_BIAS | FFM_EPI_LNIN)
+        case FFM_EPI_LNB_APPLY:                                        // dX of the in-projection applying ln_1's backward
+            if (cfg == 2) return ffm_panel::launch_panel<10, 2, false, FFM_EPI_LNB_APPLY>(a, s);
+            return FFM_EINVAL;
     }
     return FFM_EINVAL;
 }

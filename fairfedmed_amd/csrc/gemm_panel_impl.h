@@ -150,8 +150,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // rstd (gamma g_h - c1/K - xhat c2/K) + res to its rows instead of storing g_h
     constexpr bool LNBS = (FL & FFM_EPI_LNB_STAT) != 0, LNBA = (FL & FFM_EPI_LNB_APPLY) != 0;
     static_assert(!LNBS || LGRAD, "LNB_STAT rides on the LGRAD epilogue (its chunk loop holds dpre and pre)");
-    static_assert(!LNBA || (RK && !KS && !(FL & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU | FFM_EPI_GELU | FFM_EPI_LNIN | FFM_EPI_ROWSTATS | FFM_EPI_BIAS))),
-                  "LNB_APPLY: the plain FairLoRA dX epilogue");
+    static_assert(!LNBA || (!KS && !(FL & (FFM_EPI_RESIDUAL | FFM_EPI_DGELU | FFM_EPI_GELU | FFM_EPI_LNIN | FFM_EPI_ROWSTATS | FFM_EPI_BIAS))),
+                  "LNB_APPLY: a dX epilogue without anything else in it (FairLoRA: c_fc; plain: the in-projection)");
     static_assert(RK || !(flags & FFM_EPI_LORA), "the panel kernel only has the in-kernel (RANKOP) LoRA epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -304,14 +304,16 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // LNIN: the partial row sums of this thread's tile row are requested FIRST: behind the ring fills each of these
     // small loads waits ~150 cycles for an issue slot (3 us per block, tools/panel_stamps.py)
     constexpr bool LNIN_ = (FL & FFM_EPI_LNIN) != 0;
-    f32x2 lnpv[8];
+    // (LNB_APPLY on the plain product: up to 24 partial rows - two per head from the attention backward kernels)
+    constexpr int NPV = (LNBA && !RK) ? 24 : 8;
+    f32x2 lnpv[NPV];
     float lnb_mu = 0.f, lnb_rs = 0.f;
     if constexpr (LNBA) {
         // LNB_APPLY: the producer's partial row sums {P1, P2} and the LayerNorm's saved statistics of this thread's tile row
         static_assert(16 * MF <= PT, "one tile row per thread");
         const int gm = (m0 + tid) < p.M ? (m0 + tid) : (p.M - 1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NPV; ++q) {
             const int qq = q < p.lnb_np ? q : 0;
             const float* src = p.lnb_part + ((size_t)qq * p.M + gm) * 2;
             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(lnpv[q]) : "v"(src) : "memory");
@@ -536,12 +538,12 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     }
     if constexpr (LNBA) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(lnpv[q]));
+        for (int q = 0; q < NPV; ++q) asm volatile("" : "+v"(lnpv[q]));
         asm volatile("" : "+v"(lnb_mu), "+v"(lnb_rs));
         if (tid < BMp) {
             float p1 = 0.f, p2 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {                  // fixed order over the producer's column tiles
+            for (int q = 0; q < NPV; ++q) {                // fixed order over the producer's column tiles
                 if (q < p.lnb_np) {
                     p1 += lnpv[q][0];
                     p2 += lnpv[q][1];

@@ -246,8 +246,10 @@ class _Stack:
         self.rowp2 = [f(8 * T * 2) for _ in range(layers)] if (rank and _is16(dtype)) else None   # ... of xm (ln_2)
         # ln_2's BACKWARD folded into dX(c_proj) / dX(c_fc) (FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY): the producer's partial row
         # sums, consumed by the very next launch - one buffer per tower; rows -> column tiles of the producer (0: not folded)
-        self.lnb_part = f(8 * T * 2) if (rank and _is16(dtype)) else None
+        # (ln_1's: two partial rows per head from the attention backward kernels, consumed by dX(qkv))
+        self.lnb_part = f(max(8, 2 * heads) * T * 2) if (rank and _is16(dtype)) else None
         self.foldb = {}
+        self.foldb1 = {}
         self.fold = {}                                       # rows -> (np of the c_proj forward, ok) decision cache
         self.fold2 = {}                                      # rows -> np of the out-proj forward (ln_2 into c_fc)
         if rank:
@@ -645,6 +647,20 @@ class FairLoRAEngine:
             st.foldb[rows] = n
         return st.foldb[rows]
 
+    def _fold_ln1_bwd(self, st: _Stack, rows: int) -> int:
+        """ln_1's BACKWARD folded into the attention backward (row sums per head: ffm_attention_bwd_lnstat) and the dX product
+        of the in-projection (FFM_EPI_LNB_APPLY on the plain panel tile): 0, or the number of partial rows (2 heads)."""
+        if st.lnb_part is None or os.environ.get("FFM_LNB_FOLD", "1") == "0" or os.environ.get("FFM_LNB_FOLD1", "1") == "0":
+            return 0
+        if rows not in st.foldb1:
+            w = st.width
+            n = 0
+            if self._fold_ln1(st, rows) and 2 * st.heads <= 24 and ops.attention_bwd_lnstat_ok(st.L, st.causal, st.dtype):
+                if ops.gemm_tiles_n(rows, w, 3 * w, L.EPI_LNB_APPLY, 0, st.dtype, True) > 0:
+                    n = 2 * st.heads
+            st.foldb1[rows] = n
+        return st.foldb1[rows]
+
     def _stack_forward(self, st: _Stack, rows: int, images: int, attr: Optional[Tensor], rows_per_sample: int,
                        save: bool = True) -> Tensor:
         """x[0][:rows] holds the tower input; returns the tower output view."""
@@ -827,12 +843,20 @@ class FairLoRAEngine:
             if not lnb:
                 ops.layernorm_bwd(st.dh[:rows], xm, blk.ln2_w, st.st2[i][0], st.st2[i][1], gi, g1)
             gemm(g1, blk.w_out_t, st.do[:rows], b_packed=blk.pk("w_out_t"))
+            # ln_1's backward: its two row sums leave with the attention backward (two partial rows per head), and the dX
+            # product of the in-projection stores dL/d x = LayerNorm backward(g_h) + g1 directly
+            lnb1 = self._fold_ln1_bwd(st, rows) if r else 0
             ops.attention_bwd(st.qkv[i][:rows], st.o[i][:rows], st.do[:rows], st.lse[i], st.delta, st.dqkv[:rows],
-                              images, st.L, st.heads, st.causal)
+                              images, st.L, st.heads, st.causal,
+                              ln_stat=(blk.c_in, blk.d_in, st.lnb_part) if lnb1 else None)
             if r and red_at == 1:
                 reductions()
-            gemm(st.dqkv[:rows], blk.w_in_t, st.dh[:rows], b_packed=blk.pk("w_in_t"))
-            ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
+            if lnb1:
+                gemm(st.dqkv[:rows], blk.w_in_t, gout, b_packed=blk.pk("w_in_t"),
+                     lnb_apply=ops.LnBwdApply(st.lnb_part, lnb1, x, blk.ln1_w, st.st1[i][0], st.st1[i][1], None, g1))
+            else:
+                gemm(st.dqkv[:rows], blk.w_in_t, st.dh[:rows], b_packed=blk.pk("w_in_t"))
+                ops.layernorm_bwd(st.dh[:rows], x, blk.ln1_w, st.st1[i][0], st.st1[i][1], g1, gout)
             if r and red_at == 2:
                 reductions()
         if r:

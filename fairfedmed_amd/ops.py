@@ -269,12 +269,12 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     if lnb_apply is not None:
         la = lnb_apply
         _dev(la.part, la.x, la.gamma, la.mean, la.rstd, la.rk, la.res)
-        assert res is None and ln_in is None and bias is None and ro is not None
+        assert res is None and ln_in is None and bias is None
         flags |= L.EPI_LNB_APPLY
-        assert 0 < la.np <= 8 and _f32(la.part).numel() >= 2 * M * la.np and _f32(la.gamma).numel() == N
+        assert 0 < la.np <= (8 if ro is not None else 24) and _f32(la.part).numel() >= 2 * M * la.np and _f32(la.gamma).numel() == N
         assert la.x.dtype == out.dtype and tuple(la.x.shape) == (M, N) and _ld(la.x) == _ld(out)
         assert la.res.dtype == out.dtype and tuple(la.res.shape) == (M, N) and _ld(la.res) == _ld(out)
-        assert _f32(la.mean).numel() >= M and _f32(la.rstd).numel() >= M and _f32(la.rk).numel() == 32
+        assert _f32(la.mean).numel() >= M and _f32(la.rstd).numel() >= M and (ro is None or _f32(la.rk).numel() == 32)
         lnb = (None, None, L.ptr(la.part), la.np, 0, L.ptr(la.x), L.ptr(la.gamma))
         lnx = (None, None, L.ptr(la.mean), L.ptr(la.rstd), 0, int(gelu_deriv), L.ptr(la.rk))
         res_ptr = L.ptr(la.res)
@@ -590,11 +590,25 @@ def attention_fwd(qkv: Tensor, out: Tensor, lse: Optional[Tensor], B: int, Ltok:
     return out
 
 
+def attention_bwd_lnstat_ok(Ltok: int, causal: bool, dtype: torch.dtype) -> bool:
+    """Whether attention_bwd(ln_stat=...) is served for this shape (ffm_attention_bwd_lnstat_ok)."""
+    return L.is16(dtype) and bool(L.load().ffm_attention_bwd_lnstat_ok(Ltok, int(causal), L.dtype_code(dtype)))
+
+
 def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, delta: Tensor, dqkv: Tensor, B: int,
-                  Ltok: int, heads: int, causal: bool = False) -> Tensor:
+                  Ltok: int, heads: int, causal: bool = False, ln_stat: Optional[tuple] = None) -> Tensor:
+    """ln_stat = (wg [3E], d [3E], part [2 heads, B Ltok, 2]): also leave ln_1's backward row sums (ffm_attention_bwd_lnstat)."""
     _dev(qkv, out, dout, lse, delta, dqkv)
     for t in (qkv, out, dout, dqkv):
         assert t.is_contiguous() and t.dtype == qkv.dtype
+    if ln_stat is not None:
+        wg, d, part = ln_stat
+        _dev(wg, d, part)
+        E3 = 3 * heads * 64
+        assert _f32(wg).numel() == E3 and _f32(d).numel() == E3 and _f32(part).numel() >= 2 * heads * B * Ltok * 2
+        _call("ffm_attention_bwd_lnstat", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(_f32(lse)), L.ptr(_f32(delta)), L.ptr(dqkv),
+              L.ptr(wg), L.ptr(d), L.ptr(part), B, Ltok, heads, int(causal), L.dtype_code(qkv.dtype), L.stream_ptr())
+        return dqkv
     _call("ffm_attention_bwd", L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(_f32(lse)), L.ptr(_f32(delta)),
                                        L.ptr(dqkv), B, Ltok, heads, int(causal), L.dtype_code(qkv.dtype),
                                        L.stream_ptr())

@@ -178,7 +178,8 @@ typedef struct ffm_gemm_args {
     float*       sk_part;
     /* FFM_EPI_LNB_STAT: lnb_wg, lnb_d [N] fp32 (W gamma and W beta + b of the LayerNorm-folded FORWARD product whose dX this
      * launch is followed by); lnb_part [ffm_gemm_tiles_n][M][2] fp32 is written.
-     * FFM_EPI_LNB_APPLY: lnb_part holds lnb_np (<= 8) such partial rows, lnb_x [M, N] (dtype, stride ldc) is the LayerNorm's
+     * FFM_EPI_LNB_APPLY: lnb_part holds lnb_np such partial rows (<= 8 with FFM_EPI_RANKOP; <= 24 on the plain product, whose
+     * producer is ffm_attention_bwd_lnstat and whose rank-r corrections do not exist: ln_rk is not read), lnb_x [M, N] (dtype, stride ldc) is the LayerNorm's
      * input, lnb_gamma [N] its weight, ln_mean / ln_rstd [M] its saved statistics (inputs here), ln_rk [2][16] the
      * corrections {A^T gamma, A^T beta} (as under FFM_EPI_LNIN | FFM_EPI_RANKOP), res the gradient that joins behind the
      * LayerNorm (the residual path). */
@@ -391,6 +392,19 @@ int ffm_attention_fwd(const void* qkv, void* out, float* lse, int B, int L, int 
 int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                       float* delta, void* dqkv, int B, int L, int heads, int causal,
                       int dtype, void* stream);
+/*
+ * ABI 12: the same, ALSO leaving the two row sums of the LayerNorm backward that follows the in-projection's dX product
+ * (ln_1 of a ResidualAttentionBlock, clip/model.py:354-357; FFM_EPI_LNB_* above, no rank-r terms: the in-projection is
+ * frozen): ln_part [2 heads][B L][2] fp32 <- {sum_n dqkv[n] ln_wg[n], sum_n dqkv[n] (qkv[n] - ln_d[n])} over 64-column
+ * slices - slot h: the q columns of head h, slot heads + h: its k and v columns; ln_wg = W gamma, ln_d = W beta + b of the
+ * LayerNorm-folded in-projection [3 heads 64].  The dX product of qkv then takes them as FFM_EPI_LNB_APPLY's lnb_part with
+ * lnb_np = 2 heads (<= 24).  16-bit storage, no mask, 65..256 tokens only: ffm_attention_bwd_lnstat_ok says whether a
+ * shape is served (1) or ffm_attention_bwd_lnstat returns FFM_EUNSUP (0).
+ */
+int ffm_attention_bwd_lnstat_ok(int L, int causal, int dtype);
+int ffm_attention_bwd_lnstat(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                             const float* ln_wg, const float* ln_d, float* ln_part, int B, int L, int heads, int causal,
+                             int dtype, void* stream);
 
 /*
  * Rank-r down projection with the group-mixed singular values applied

@@ -885,6 +885,67 @@ def test_gemm_panel_layernorm_backward_fold(ops, M, r, G, use_attr, h16):
     print("LayerNorm backward fold: max error vs float64", err(g1), " unfolded pair", err(g1u))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,L,heads", [(32, 197, 12), (5, 197, 12), (3, 130, 4), (2, 256, 12)])
+def test_attention_backward_layernorm_row_sums_and_plain_apply(ops, dt, B, L, heads):
+    """ln_1's backward folded (ABI 12): ffm_attention_bwd_lnstat leaves, per head, {sum dqkv (W gamma), sum dqkv (qkv - d)} over
+    the head's q columns (dQ kernel) and its k and v columns (dK/dV kernel) - float64 on the 16-bit dqkv it stored, which must
+    be bit-identical to the plain call's; the dX product of the in-projection with FFM_EPI_LNB_APPLY then stores
+    rstd (gamma g_h - c1/K - xhat c2/K) + res: held to float64 autograd through LayerNorm -> in-projection."""
+    E, M = heads * 64, B * L
+    assert ops.attention_bwd_lnstat_ok(L, False, dt)
+    x = rnd(M, E, dt=dt, seed=401)
+    gamma, beta = 1 + 0.1 * rnd(E, seed=402), 0.1 * rnd(E, seed=403)
+    W = rnd(3 * E, E, dt=dt, scale=E ** -0.5, seed=404)
+    bias = 0.1 * rnd(3 * E, seed=405)
+    xd = x.double().requires_grad_(True)
+    mu = xd.mean(-1, keepdim=True)
+    rstd = (xd.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    h = (xd - mu) * rstd * gamma.double() + beta.double()
+    qkv64 = h @ W.double().t() + bias.double()
+    qkv = qkv64.detach().to(dt).contiguous()
+    out = torch.empty(M, E, device="cuda", dtype=dt)
+    lse = torch.empty(B, heads, L, device="cuda")
+    ops.attention_fwd(qkv, out, lse, B, L, heads, False)
+    dout = rnd(M, E, dt=dt, seed=406)
+    delta = torch.empty(B, heads, L, device="cuda")
+    dq0 = torch.full((M, 3 * E), float("nan"), device="cuda", dtype=dt)
+    ops.attention_bwd(qkv, out, dout, lse, delta, dq0, B, L, heads, False)
+    wg = (W.double() @ gamma.double()).float().contiguous()
+    dvec = (W.double() @ beta.double() + bias.double()).float().contiguous()
+    part = torch.full((2 * heads, M, 2), float("nan"), device="cuda")
+    dqkv = torch.full((M, 3 * E), float("nan"), device="cuda", dtype=dt)
+    ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, L, heads, False, ln_stat=(wg, dvec, part))
+    assert torch.equal(dqkv, dq0), "the row sums must not move dqkv"
+    assert not torch.isnan(part).any()
+    g64 = dqkv.double()
+    t1, t2 = g64 * wg.double(), g64 * (qkv.double() - dvec.double())
+    for hh in range(heads):
+        sl = slice(hh * 64, hh * 64 + 64)
+        check(part[hh, :, 0], t1[:, sl].sum(-1), 1e-5, f"q columns of head {hh}: sum dqkv (W gamma)")
+        check(part[hh, :, 1], t2[:, sl].sum(-1), 1e-5, f"q columns of head {hh}: sum dqkv (qkv - d)")
+        kv = lambda t_: t_[:, E + hh * 64:E + hh * 64 + 64].sum(-1) + t_[:, 2 * E + hh * 64:2 * E + hh * 64 + 64].sum(-1)
+        check(part[heads + hh, :, 0], kv(t1), 1e-5, f"k, v columns of head {hh}: sum dqkv (W gamma)")
+        check(part[heads + hh, :, 1], kv(t2), 1e-5, f"k, v columns of head {hh}: sum dqkv (qkv - d)")
+    # the consumer: dX of the in-projection, [M, 3E] x [E, 3E]^T
+    if E % 128 or ops.gemm_tiles_n(M, E, 3 * E, 4096, 0, dt, True) <= 0:
+        return                                                          # (no plain panel tile for this shape: the engine asks too)
+    Wt = W.t().contiguous()
+    gres = rnd(M, E, dt=dt, seed=407)
+    mean32, rstd32 = mu.detach().float().reshape(-1).contiguous(), rstd.detach().float().reshape(-1).contiguous()
+    g1 = torch.full((M, E), float("nan"), device="cuda", dtype=dt)
+    ops.gemm_nt(dqkv, Wt, g1, b_packed=ops.pack_b(Wt),
+                lnb_apply=ops.LnBwdApply(part, 2 * heads, x, gamma, mean32, rstd32, None, gres))
+    (qkv64 * dqkv.double()).sum().backward()
+    ref = xd.grad + gres.double()
+    check(g1, ref, tol(dt), "folded ln_1 backward vs float64 autograd")
+    gh = torch.empty(M, E, device="cuda", dtype=dt)
+    ops.gemm_nt(dqkv, Wt, gh, b_packed=ops.pack_b(Wt))
+    g1u = torch.empty(M, E, device="cuda", dtype=dt)
+    ops.layernorm_bwd(gh, x, gamma, mean32, rstd32, gres, g1u)
+    check(g1, g1u.double(), 2 * tol(dt), "against the unfolded pair")
+
+
 def test_skinny_x3_tiles_per_block_switch():
     """FFM_SKINNY_NT (read once per process): the text tower's X3 product with 1 / 2 / 4 column tiles per block
     (csrc/gemm_skinny.hip, gemm_skinny_nt_kernel: the tiles of a block share the activation fragments).  The partial sums
