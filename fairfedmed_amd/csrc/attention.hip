@@ -1160,7 +1160,8 @@ extern "C" int ffm_attention_bwd(const void* qkv, const void* out, const void* d
 // FFM_EUNSUP otherwise, and nothing is launched
 // (ffm_attention_bwd_lnstat_ok says so beforehand).
 extern "C" int ffm_attention_bwd_lnstat_ok(int L, int causal, int dtype) {
-    return ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed() && L > 64 && L <= 256) ? 1 : 0;
+    // (97..256 tokens: the dK/dV kernel lays its four 64-float tables over the row constants of at least four 32-token tiles)
+    return ((dtype == FFM_BF16 || dtype == FFM_F16) && !causal && attn3_allowed() && L > 96 && L <= 256) ? 1 : 0;
 }
 
 extern "C" int ffm_attention_bwd_lnstat(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,

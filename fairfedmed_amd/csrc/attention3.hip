@@ -634,7 +634,7 @@ template <typename T, int NT>
 __global__ __launch_bounds__(64 * Geo<NT>::NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, const float* __restrict__ lse,
                           const float* __restrict__ delta, T* __restrict__ dqkv, int L, int heads, int BH, int map,
-                          const float* __restrict__ ln_wg, const float* __restrict__ ln_d, float* __restrict__ ln_part) {
+                          const float* __restrict__ ln_wg, const float* __restrict__ ln_d, float* ln_part) {
     typedef typename A3<T>::frag frag;
     typedef Geo<NT> GE;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -643,7 +643,12 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     char* dOs = smem + R8 * 128;
     float* lse_s = reinterpret_cast<float*>(smem + 2 * R8 * 128);              // [32 NT]: -8 lse (-inf beyond L)
     float* del_s = lse_s + 32 * NT;                                             // [32 NT]: -delta (0 beyond L)
-    float* tabs = del_s + 32 * NT;                                              // ln_part: {W gamma, d} of the k | v columns, [2][2][64]
+    // ln_part: {W gamma, d} of the k | v columns, [2][2][64] floats = 1 KB - laid over lse_s / del_s once the last tile is done
+    // (32 NT >= 128 floats each): a block of its own would take the kernel from three blocks per CU to two (LDS is dealt in
+    // 1280-byte units: 52 992 B -> 42 units, 54 016 B -> 43), which cost 4.8 us per launch when it was tried
+    float* tabs = lse_s;
+    constexpr bool LN_OK = 2 * 32 * NT >= 256;                                   // (NT = 3: not served - ffm_attention_bwd_lnstat_ok)
+    if (!LN_OK) ln_part = nullptr;
     int bh, part;
     unit_of_block(blockIdx.x, bh, part, map);
     if (bh >= BH) return;
@@ -699,8 +704,7 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
                  : "n"(LOADS_ONLY ? 0 : GE::NCH > 1 ? 2 * GE::RC : 0)
                  : "memory");
     if constexpr (LOADS_ONLY) return;
-    asm volatile("" : "+v"(tabv));
-    if (ln_part && tid < 64) reinterpret_cast<u32x4*>(tabs)[tid] = tabv;         // [k: wg, d][v: wg, d], visible behind chunk 0's barrier
+    asm volatile("" : "+v"(tabv));                                               // (kept in 4 registers until the tiles are done)
     A3_STAMP(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -783,6 +787,10 @@ void attn3_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o, 
     if constexpr (GE::NCH > 3) chunk(std::integral_constant<int, 3>{});
     A3_STAMP(3);
     if (ln_part) {
+        block_sync();                                                           // every wave is done with lse_s / del_s
+        asm volatile("" : "+v"(tabv));
+        if (tid < 64) reinterpret_cast<u32x4*>(tabs)[tid] = tabv;               // [k: wg, d][v: wg, d]
+        block_sync();
         float s1 = 0.f, s2 = 0.f;
         if (active && key < L) {
             T* drow = dqkv + ((size_t)b * L + key) * ld + hd * HD;
@@ -830,8 +838,9 @@ int run_fwd3(const void* qkv, void* out, float* lse, int B, int L, int heads, hi
 template <typename T, int NT>
 int run_bwd3(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int L, int heads,
              hipStream_t s, const float* ln_wg, const float* ln_d, float* ln_part) {
-    // (+ 512 / 1024 B: the LayerNorm-backward tables of the head; three blocks per CU still fit at 197 tokens)
-    const int R8 = (L + 7) & ~7, lds_dq = 2 * R8 * 128 + 512, lds_dkv = 2 * R8 * 128 + 2 * 32 * NT * 4 + 1024, BH = B * heads;
+    // (+ 512 B in the dQ kernel: the LayerNorm-backward tables of the head - 51 712 B is still 41 of the 1280-byte LDS units,
+    // three blocks per CU; the dK/dV kernel lays its 1 KB over the row constants at its end, see there)
+    const int R8 = (L + 7) & ~7, lds_dq = 2 * R8 * 128 + 512, lds_dkv = 2 * R8 * 128 + 2 * 32 * NT * 4, BH = B * heads;
     int e = set_lds3(attn3_bwd_dq_kernel<T, NT>, lds_dq);
     if (e) return e;
     e = set_lds3(attn3_bwd_dkv_kernel<T, NT>, lds_dkv);

@@ -1153,27 +1153,17 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                 // LNB_STAT: this chunk's share of the two row sums, on the values AS STORED (d8s) and the pre-activation
                 // chunk in hand: {sum dpre (W gamma), sum dpre (pre - d)}; the row's CPR chunks meet in the wave's own
                 // (dead) LoRA-matrix slab right behind the chunk loop
-                // (one address register for the three vectors - they sit BNp floats apart behind the bias; four columns at
-                // a time: the tile has no registers to spare)
-                const uint32_t va = (uint32_t)(uintptr_t)&Bias[colw * WN + ch * 8];
+                // (one address register for the three vectors - they sit BNp floats apart behind the bias;
+                // four LDS reads in flight behind ONE wait: the first cut waited out two round trips per chunk, 42 per block)
+                const float* vb = &Bias[colw * WN + ch * 8];
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(vb + BNp), w1 = *reinterpret_cast<const f32x4*>(vb + BNp + 4);
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(vb + 2 * BNp), e1 = *reinterpret_cast<const f32x4*>(vb + 2 * BNp + 4);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x4 wq, eq;
-                    if (h == 0) {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq) : "v"(va), "n"(BNp * 4) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(eq) : "v"(va), "n"(BNp * 8) : "memory");
-                    } else {
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq) : "v"(va), "n"(BNp * 4 + 16) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(eq) : "v"(va), "n"(BNp * 8 + 16) : "memory");
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq), "+v"(eq)::"memory");
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float x = (float)d8s[4 * h + c];
-                        s1 += x * wq[c];
-                        s2 += x * ((float)rpre[rg % PF][i][4 * h + c] - eq[c]);
-                    }
+                for (int c = 0; c < 8; ++c) {
+                    const float x = (float)d8s[c];
+                    s1 += x * (c < 4 ? w0[c & 3] : w1[c & 3]);
+                    s2 += x * ((float)rpre[rg % PF][i][c] - (c < 4 ? e0[c & 3] : e1[c & 3]));
                 }
                 f32x2 sq = {s1, s2};
                 // chunk (row, ch) has index row * CPR + ch = lane + 64 i in the group's table

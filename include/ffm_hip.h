@@ -398,7 +398,7 @@ int ffm_attention_bwd(const void* qkv, const void* out, const void* dout, const 
  * frozen): ln_part [2 heads][B L][2] fp32 <- {sum_n dqkv[n] ln_wg[n], sum_n dqkv[n] (qkv[n] - ln_d[n])} over 64-column
  * slices - slot h: the q columns of head h, slot heads + h: its k and v columns; ln_wg = W gamma, ln_d = W beta + b of the
  * LayerNorm-folded in-projection [3 heads 64].  The dX product of qkv then takes them as FFM_EPI_LNB_APPLY's lnb_part with
- * lnb_np = 2 heads (<= 24).  16-bit storage, no mask, 65..256 tokens only: ffm_attention_bwd_lnstat_ok says whether a
+ * lnb_np = 2 heads (<= 24).  16-bit storage, no mask, 97..256 tokens only: ffm_attention_bwd_lnstat_ok says whether a
  * shape is served (1) or ffm_attention_bwd_lnstat returns FFM_EUNSUP (0).
  */
 int ffm_attention_bwd_lnstat_ok(int L, int causal, int dtype);
