@@ -602,6 +602,16 @@ def main():
                 "all_gemm_launches": {"launches_per_step": n_all // args.steps, "achieved": fl_all / (ms_all * 1e-3) / 1e12,
                                       "gemm_ms_per_step": ms_all / args.steps,
                                       "note": "includes the text tower's 96 latency-bound launches on 40 rows (4 prompts x 10 tokens)"},
+                # the whole step against the same peak: SURVEY section 8(d)'s 72.0 GFLOP per image and train step (vision
+                # forward + LoRA-only backward + text tower) x images per step / the timed step - every kernel, boundary and
+                # side stream included (configs[1] only: the figure is that workload's)
+                "whole_step": ({"gflop_per_image": 72.0, "achieved": 72.0e9 * wl.units / (dt / args.steps) / 1e12,
+                                "frac": 72.0e9 * wl.units / (dt / args.steps) / 1e12 / peak} if args.config == "c2" and args.rank == 8 else None),
+                # since round 6 the dX launches of c_proj / c_fc / qkv also carry the two LayerNorm backwards of a block
+                # (FFM_EPI_LNB_STAT / FFM_EPI_LNB_APPLY: 22 layernorm_bwd launches of 9.9 us folded into 33 of these 96
+                # launches); their flops are not counted, so `frac` prices the launches' whole duration against the GEMM
+                # flops alone - it moved 0.241 -> 0.230 while the step got 2.4 % shorter
+                "note": "launch durations include the LayerNorm-backward work folded into dX(c_proj) / dX(c_fc) / dX(qkv) (uncounted flops)",
                 "measured": "HIP events around every ffm_gemm_nt launch, second pass over the same K steps with the "
                             "side streams folded into the main stream (one kernel at a time); value comes from the "
                             "un-instrumented overlapped pass"}
