@@ -186,8 +186,8 @@ typedef struct ffm_gemm_args {
     const float* lnb_wg;
     const float* lnb_d;
     float*       lnb_part;
-    int          lnb_np;
-    int          lnb_pad_;
+    int32_t      lnb_np;
+    int32_t      lnb_pad_;
     const void*  lnb_x;
     const float* lnb_gamma;
 } ffm_gemm_args;

@@ -88,6 +88,18 @@ def test_gemm_args_mirror_the_header_field_by_field():
     assert l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.BF16, 1) == 31 == l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.F16, 1)
     assert l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 8, _lib.BF16, 0) < 0 and l.ffm_gemm_lgrad_rows(6304, 3072, 768, fl, 6, _lib.BF16, 1) < 0
     assert l.ffm_gemm_lgrad_rows(6304, 768, 3072, fl, 8, _lib.BF16, 1) < 0
+    # the LayerNorm-backward folds (ABI 12): the queries the engine decides by.  Bench shape: eight column tiles of the dX
+    # product of c_proj leave the row sums; the dX products of c_fc (FairLoRA tile) and of the in-projection (plain tile) apply
+    # them; 3D OCT's 19 700 rows are not single-round tiles there; float32 storage is never served; the attention backward
+    # leaves its row sums for 97..256 unmasked tokens in 16-bit storage
+    f1 = fl | _lib.EPI_LGRAD | _lib.EPI_LNB_STAT
+    f2 = _lib.EPI_LORA | _lib.EPI_LORA_KR | _lib.EPI_RANKOP | _lib.EPI_LNB_APPLY
+    assert l.ffm_gemm_tiles_n(6304, 3072, 768, f1, 8, _lib.BF16, 1) == 8 == l.ffm_gemm_tiles_n(6304, 3072, 768, f1, 8, _lib.F16, 1)
+    assert l.ffm_gemm_tiles_n(6304, 768, 3072, f2, 8, _lib.BF16, 1) == 6 and l.ffm_gemm_tiles_n(6304, 768, 2304, _lib.EPI_LNB_APPLY, 0, _lib.BF16, 1) == 6
+    assert l.ffm_gemm_tiles_n(19700, 768, 3072, f2, 16, _lib.BF16, 1) < 0 and l.ffm_gemm_tiles_n(6304, 768, 3072, f2, 8, _lib.F32, 1) < 0
+    assert l.ffm_gemm_tiles_n(6304, 768, 3072, f2, 8, _lib.BF16, 0) < 0
+    assert l.ffm_attention_bwd_lnstat_ok(197, 0, _lib.BF16) == 1 == l.ffm_attention_bwd_lnstat_ok(256, 0, _lib.F16)
+    assert l.ffm_attention_bwd_lnstat_ok(96, 0, _lib.BF16) == 0 == l.ffm_attention_bwd_lnstat_ok(197, 1, _lib.BF16) == l.ffm_attention_bwd_lnstat_ok(197, 0, _lib.F32)
 
 
 def test_registry_semantics():
