@@ -46,7 +46,7 @@ class GemmArgs(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("K", _i32), ("r", _i32), ("layout_rk", _i32), ("pad_", _i32),
-                ("dst_wide", _vp), ("gamma", _vp), ("beta", _vp), ("ln_rk", _vp)]
+                ("dst_wide", _vp), ("gamma", _vp), ("beta", _vp), ("ln_rk", _vp), ("row14", _vp), ("row15", _vp)]
 
 
 class ReduceDesc(C.Structure):

@@ -913,6 +913,8 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const ffm_pack_desc* __r
         float v = 0.f;
         if (j < d.r) v = d.layout_rk ? d.src[(size_t)j * d.K + k] : d.src[(size_t)k * d.r + j];
         if (d.gamma) v *= d.gamma[k];                      // LayerNorm folded into the product (ffm_gemm_args.ln_rk)
+        if (j == 14 && d.row14) v = d.row14[k];            // two caller vectors beside the r <= 14 rank rows (ffm_pack_desc.row14)
+        if (j == 15 && d.row15) v = d.row15[k];
         dst[i] = Elem<T>::from_f(v);
     }
     if (d.dst_wide) {                                      // [K][32]: the `lw` tile form of the panel GEMM's rank-r update
@@ -985,7 +987,8 @@ extern "C" int ffm_gemm_nt(const ffm_gemm_args* args, int dtype, void* stream) {
     }
     if (dtype == FFM_F32_X3 || dtype == FFM_F32_X3_W16) return FFM_EUNSUP;      // split-operand products: skinny shapes only
     if (a.flags & (FFM_EPI_LNB_STAT | FFM_EPI_LNB_APPLY)) {              // LayerNorm backward folded in: one panel tile each
-        if ((a.flags & FFM_EPI_LNB_STAT) && (!a.lnb_wg || !a.lnb_d || !a.lnb_part)) return FFM_EINVAL;
+        if ((a.flags & FFM_EPI_LNB_STAT) && !a.lnb_part) return FFM_EINVAL;
+        if ((a.flags & FFM_EPI_LNB_APPLY) && rk && a.rank > 14) return FFM_EUNSUP;   // rows 14 / 15 of rk carry W gamma and d
         if ((a.flags & FFM_EPI_LNB_APPLY) && (!a.lnb_part || a.lnb_np <= 0 || a.lnb_np > (rk ? 8 : 24) || !a.lnb_x || ((uintptr_t)a.lnb_x & 15) ||
                                              !a.lnb_gamma || !a.ln_mean || !a.ln_rstd || (rk && !a.ln_rk) || !a.res || ((uintptr_t)a.res & 15)))
             return FFM_EINVAL;

@@ -48,7 +48,7 @@ bool plain_flags_ok(int flags) {
 bool rk_flags_ok(int flags, int rank) {
     if (rank <= 0 || rank > 16) return false;
     if (flags & FFM_EPI_LNB_APPLY)                             // LayerNorm backward applied: the dX epilogue of c_fc only
-        return (flags & ~FFM_EPI_RANKOP) == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_LNB_APPLY);
+        return (flags & ~FFM_EPI_RANKOP) == (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_LNB_APPLY) && rank <= 14;   // (rows 14 / 15 of rk: W gamma, d)
     if (flags & FFM_EPI_LGRAD) {                               // the gradient partial products: the dX epilogue of c_proj only
         // (... which may also leave LayerNorm-backward row sums: FFM_EPI_LNB_STAT rides on the LGRAD epilogue)
         if ((flags & ~(FFM_EPI_RANKOP | FFM_EPI_LNB_STAT)) != (FFM_EPI_LORA | FFM_EPI_LORA_KR | FFM_EPI_DGELU | FFM_EPI_LGRAD) || rank % 4) return false;

@@ -113,8 +113,8 @@ __host__ __device__ constexpr int stage_pitch(int nf) { return 16 * nf + 4; }   
 // | (LNB_STAT) W gamma [BN], W beta + b [BN] f32      | (LNB_APPLY: the LNIN block - gamma in c's place - and c1, c2 [BM] f32)
 __host__ __device__ constexpr int persist_bytes(int mf, int nf, bool rk, bool lnin = false, int pw = 4, bool lgrad = false, bool lnbs = false,
                                                 bool lnba = false) {
-    // (LNB_STAT's two vectors sit right behind the bias: one address register serves all three in the chunk loop)
-    return pw * 16 * nf * 4 + (lnbs ? 2 * pw * 16 * nf * 4 : 0) + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) +
+    // (lnbs: no persistent operands since the sums against W gamma and d moved into the consumer's rank operand)
+    return pw * 16 * nf * 4 + (rk ? pw * 16 * nf * 64 + (256 + 16) * 4 + 16 * mf * 4 : 0) +
            (lnin ? pw * 16 * nf * 4 + 2 * 16 * mf * 4 : 0) + (lgrad ? 16 * mf * 64 : 0) + (lnba ? 2 * 16 * mf * 4 : 0);
 }
 
@@ -339,10 +339,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int PARTB = KS ? CW * (MF * NF + (RK ? TI : 0)) * 1024 : 0;
     constexpr int PBASE = PARTB > G::RING ? PARTB : G::RING;
     float* Bias = reinterpret_cast<float*>(smem + PBASE);
-    constexpr bool LNBS_ = (FL & FFM_EPI_LNB_STAT) != 0, LNBA_ = (FL & FFM_EPI_LNB_APPLY) != 0;
-    float* Wgv = Bias + BNp;                                  // LNB_STAT: W gamma [BN]
-    float* Dvv = Wgv + BNp;                                   //           W beta + b [BN]
-    bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + (LNBS_ ? 3 : 1) * BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
+    constexpr bool LNBS_ = (FL & FFM_EPI_LNB_STAT) != 0;
+    bf16_t* LwB = reinterpret_cast<bf16_t*>(Bias + BNp);      // [BN][32]: LoRA matrix tile, rank slots >= r zero
     float* Sg = reinterpret_cast<float*>(LwB + BNp * 32);     // lora_S [G][r]
     float* Ssum = Sg + 256;                                   // sum_g lora_S[g][j]
     int* Ga = reinterpret_cast<int*>(Ssum + 16);              // group id of each tile row (-1: uniform mix)
@@ -359,7 +357,7 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     // vmcnt(0) below.  As compiler-visible loads each of them (a conditional load followed by its LDS store) was answered
     // with its own s_waitcnt vmcnt(0) behind the ring fills: four to six memory round trips in a row in every launch.
     constexpr int NBI = (BNp + PT - 1) / PT, NGI = (BMp + PT - 1) / PT;
-    float biasv[NBI], cvv[NBI], wgv[NBI], dvv[NBI], sgv = 0.f;
+    float biasv[NBI], cvv[NBI], sgv = 0.f;
     int gav[NGI];
     auto ldgf = [](const float* q) -> float {
         float v;
@@ -369,14 +367,10 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
 #pragma unroll
     for (int it = 0; it < NBI; ++it) {
         const int i = tid + it * PT, ic = i < BNp ? i : BNp - 1;
-        biasv[it] = cvv[it] = wgv[it] = dvv[it] = 0.f;
+        biasv[it] = cvv[it] = 0.f;
         if constexpr ((flags & FFM_EPI_BIAS) != 0) biasv[it] = ldgf(p.bias + n0 + ic);
         if constexpr (LNIN) cvv[it] = ldgf(p.ln_c + n0 + ic);
         if constexpr (LNBA) cvv[it] = ldgf(p.lnb_gamma + n0 + ic);
-        if constexpr (LNBS) {
-            wgv[it] = ldgf(p.lnb_wg + n0 + ic);
-            dvv[it] = ldgf(p.lnb_d + n0 + ic);
-        }
     }
 #pragma unroll
     for (int it = 0; it < NGI; ++it) gav[it] = -1;
@@ -490,15 +484,11 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     asm volatile("" : "+v"(sgv));
 #pragma unroll
     for (int it = 0; it < NBI; ++it) {
-        asm volatile("" : "+v"(biasv[it]), "+v"(cvv[it]), "+v"(wgv[it]), "+v"(dvv[it]));
+        asm volatile("" : "+v"(biasv[it]), "+v"(cvv[it]));
         const int i = tid + it * PT;
         if (i < BNp) {
             Bias[i] = biasv[it];
             if constexpr (LNX) Cv[i] = cvv[it];
-            if constexpr (LNBS) {
-                Wgv[i] = wgv[it];
-                Dvv[i] = dvv[it];
-            }
         }
     }
     if constexpr (RK) {
@@ -738,6 +728,9 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
     constexpr int NRG = (MF + 1) / 2;                 // 32-row groups
     // row groups of residual / pre-activation rows kept in flight (two waves per SIMD: the register budget is 256)
     constexpr int PFMAX = (PW == 8 && NF >= 3) ? 2 : 3;
+    // (measured in round 6 and not kept: ALL five row groups of the LNB_APPLY tiles' two operand streams requested up front -
+    // 20 loads per lane in flight, no counted wait behind the first - 4.517 against 4.500 ms per step for the three-deep version,
+    // profiles/r06_pfall_ab.txt)
     constexpr int PF = NRG < PFMAX ? NRG : PFMAX;
     // RANKOP: per-wave dS sums at smem + 0 (DsP below), then
     bf16_t* TsA = reinterpret_cast<bf16_t*>(smem + BMp * 64);         // ts tile [BM][32] bf16, zero padded
@@ -864,7 +857,8 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
                     // the 16 slots of a row sit in one 16-lane group: four butterfly steps, fixed order
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float k1 = tsv[e] * lncj, k2 = tsv[e] * lndj;
+                        // (rank slots 14 / 15 of the operand hold W gamma and d: the raw t there IS sum_n dpre (W gamma) / sum_n dpre d)
+                        float k1 = tsv[e] * lncj + (j == 14 ? tacc[i][e] : 0.f), k2 = tsv[e] * lndj + (j == 15 ? tacc[i][e] : 0.f);
 #pragma unroll
                         for (int o = 1; o < 16; o <<= 1) {
                             k1 += __shfl_xor(k1, o, 64);
@@ -1150,20 +1144,26 @@ __attribute__((amdgpu_waves_per_eu(panel_waves_per_eu<MF, NF, RK, PWV>(), panel_
             }
             // (behind the stores: v, the activation chunk and the images' operands are dead here - the tile has 128 registers)
             if constexpr (LNBS) {
-                // LNB_STAT: this chunk's share of the two row sums, on the values AS STORED (d8s) and the pre-activation
-                // chunk in hand: {sum dpre (W gamma), sum dpre (pre - d)}; the row's CPR chunks meet in the wave's own
-                // (dead) LoRA-matrix slab right behind the chunk loop
-                // (one address register for the three vectors - they sit BNp floats apart behind the bias;
-                // four LDS reads in flight behind ONE wait: the first cut waited out two round trips per chunk, 42 per block)
-                const float* vb = &Bias[colw * WN + ch * 8];
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(vb + BNp), w1 = *reinterpret_cast<const f32x4*>(vb + BNp + 4);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(vb + 2 * BNp), e1 = *reinterpret_cast<const f32x4*>(vb + 2 * BNp + 4);
+                // LNB_STAT: this chunk's share of sum_n dpre[n] pre[n], on the 16-bit values AS STORED (d8s) and the
+                // pre-activation chunk in hand: four packed dot products (v_dot2c_f32_bf16 / v_dot2_f32_f16: exact products,
+                // fp32 sum) - no conversions, no per-column operands.  The two sums against the fixed vectors W gamma and
+                // d = W beta + b are not formed here at all: they ride in the CONSUMER's rank operand as rows 14 / 15
+                // (ffm_pack_desc.row14 / row15) and come out of its matrix cores.  The row's CPR chunks meet in the wave's
+                // own (dead) LoRA-matrix slab right behind the chunk loop.
+                typedef bf16_t h16x2 __attribute__((ext_vector_type(2)));
                 float s1 = 0.f, s2 = 0.f;
+                {
+                    const uint32_t* da = reinterpret_cast<const uint32_t*>(&d8s);
+                    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&rpre[rg % PF][i]);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float x = (float)d8s[c];
-                    s1 += x * (c < 4 ? w0[c & 3] : w1[c & 3]);
-                    s2 += x * ((float)rpre[rg % PF][i][c] - (c < 4 ? e0[c & 3] : e1[c & 3]));
+                    for (int c = 0; c < 4; ++c) {
+                        const h16x2 x2 = __builtin_bit_cast(h16x2, da[c]), p2 = __builtin_bit_cast(h16x2, pa[c]);
+#ifdef FFM_TWIN_F16
+                        s2 = __builtin_amdgcn_fdot2(x2, p2, s2, false);
+#else
+                        s2 = __builtin_amdgcn_fdot2_f32_bf16(x2, p2, s2, false);
+#endif
+                    }
                 }
                 f32x2 sq = {s1, s2};
                 // chunk (row, ch) has index row * CPR + ch = lane + 64 i in the group's table

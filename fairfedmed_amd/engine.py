@@ -476,7 +476,11 @@ class FairLoRAEngine:
                     if _is16(dtype) else {}
                 self.lw_wide.append(wd)
                 for role, buf in pk.items():
-                    ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf, wd.get(role)))
+                    # ln_2's backward fold (_fold_ln2_bwd): the rank operand of dX(c_fc) carries W gamma and W beta + b as rows
+                    # 14 / 15 - its t[14] / t[15] are the two row sums against those vectors, out of the matrix cores; every
+                    # consumer masks the slots beyond r (rank <= 14)
+                    extra = (blk.c_fc, blk.d_fc) if (role == "fc_B" and _is16(dtype) and blk.c_fc is not None and cfg.lora.rank <= 14) else None
+                    ent.append((self.params.view(blk.lora[role]), role.endswith("_B"), buf, wd.get(role), None, extra))
                 if _is16(dtype):
                     # ln_2 folded into c_fc: the rank operand gamma-scaled, and its two correction rows (ops.LnIn.rk)
                     pk["fc_A_ln"] = torch.zeros(16, w, device=dev, dtype=dtype)
@@ -638,7 +642,7 @@ class FairLoRAEngine:
         if rows not in st.foldb:
             w, r = st.width, st.rank
             n = 0
-            if self._fold_ln2(st, rows) and self._lgrad_rows(st, rows, blk) > 0:
+            if self._fold_ln2(st, rows) and self._lgrad_rows(st, rows, blk) > 0 and r <= 14:
                 f1 = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_DGELU | L.EPI_RANKOP | L.EPI_LGRAD | L.EPI_LNB_STAT
                 f2 = L.EPI_LORA | L.EPI_LORA_KR | L.EPI_RANKOP | L.EPI_LNB_APPLY
                 n1 = ops.gemm_tiles_n(rows, 4 * w, w, f1, r, st.dtype, True)
@@ -764,7 +768,7 @@ class FairLoRAEngine:
                                     lgrad=(st.ts1[i][:rows], pt["fc_B"], pt["proj_A"]) if lg else None)
                     gemm(gi, blk.w_proj_t, dpre, lw=self._lora_view(blk, "proj_A"), lw_is_kr=True,
                                 dgelu_aux=pre, rankop=ro, b_packed=blk.pk("w_proj_t"),
-                                lnb_stat=ops.LnBwdStat(blk.c_fc, blk.d_fc, st.lnb_part) if lnb else None)
+                                lnb_stat=ops.LnBwdStat(st.lnb_part) if lnb else None)
                 else:
                     ops.lora_down(gi, self._lora_view(blk, "proj_B"), True, self._S(i, "proj"), attr, r, G,
                                   rows_per_sample, lo.scaling, lo.lambda_group, u, us2, st.t2[i][:rows], pt["proj_S"])

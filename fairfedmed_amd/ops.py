@@ -142,11 +142,12 @@ class LnIn:
 
 class LnBwdStat:
     """FFM_EPI_LNB_STAT (the dX product of c_proj, with a RankOp that carries `lgrad`): also leave the two row sums of the
-    LayerNorm backward that follows the NEXT dX product - part [tiles_n, M, 2] fp32 <- {sum_n c wg[n], sum_n c (aux - d[n])}
-    per column tile; wg = W gamma (LnIn's c), d = W beta + b (the folded forward's bias) of that LayerNorm-folded product."""
+    LayerNorm backward that follows the NEXT dX product - part [tiles_n, M, 2] fp32 <- {0, sum_n c aux} per column tile.  The
+    sums against the fixed vectors W gamma (LnIn's c) and d = W beta + b (the folded forward's bias) come out of the CONSUMER's
+    rank operand: rows 14 / 15 of the rk it is packed with (PackPlan entry element 6)."""
 
-    def __init__(self, wg: Tensor, d: Tensor, part: Tensor):
-        self.wg, self.d, self.part = wg, d, part
+    def __init__(self, part: Tensor):
+        self.part = part
 
 
 class LnBwdApply:
@@ -260,12 +261,12 @@ def gemm_nt(a: Tensor, b: Tensor, out: Tensor, *, bias=None, ts=None, lw=None, l
     lnb = (None, None, None, 0, 0, None, None)
     res_ptr = L.ptr(res)
     if lnb_stat is not None:
-        _dev(lnb_stat.wg, lnb_stat.d, lnb_stat.part)
+        _dev(lnb_stat.part)
         flags |= L.EPI_LNB_STAT
         tn = gemm_tiles_n(M, N, K, flags, rank, a.dtype, b_packed is not None)
         assert tn > 0 and (flags & L.EPI_LGRAD), "FFM_EPI_LNB_STAT rides on the FFM_EPI_LGRAD epilogue: ask gemm_tiles_n first"
-        assert _f32(lnb_stat.wg).numel() == N and _f32(lnb_stat.d).numel() == N and _f32(lnb_stat.part).numel() >= 2 * M * tn
-        lnb = (L.ptr(lnb_stat.wg), L.ptr(lnb_stat.d), L.ptr(lnb_stat.part), 0, 0, None, None)
+        assert _f32(lnb_stat.part).numel() >= 2 * M * tn
+        lnb = (None, None, L.ptr(lnb_stat.part), 0, 0, None, None)
     if lnb_apply is not None:
         la = lnb_apply
         _dev(la.part, la.x, la.gamma, la.mean, la.rstd, la.rk, la.res)
@@ -652,7 +653,8 @@ class PackPlan:
     def __init__(self, entries, dtype, device):
         # entries: (src fp32 tensor [K,r] or [r,K], layout_rk, dst [16,K] dtype[, wide [K,32] dtype[, ln]]);
         # ln = (gamma [K], beta [K], ln_rk [2,16]): a LayerNorm folded into the product dst rides in (layout_rk False):
-        # dst is gamma-scaled and ln_rk receives its corrections (ffm_lora_pack_ln)
+        # dst is gamma-scaled and ln_rk receives its corrections (ffm_lora_pack_ln); optional 6th element (row14 [K], row15 [K]):
+        # two caller vectors as rows 14 / 15 of dst (r <= 14; ffm_pack_desc.row14 / row15)
         arr = (L.PackDesc * len(entries))()
         self.keep, self.max_K, self.dtype = entries, 0, dtype
         self.any_ln = False
@@ -671,7 +673,11 @@ class PackPlan:
                 _dev(*ln)
                 lnp = tuple(t.data_ptr() for t in ln)
                 self.any_ln = True
-            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0, L.ptr(wide), *lnp)
+            rows = ent[5] if len(ent) > 5 and ent[5] is not None else (None, None)
+            if rows[0] is not None:
+                _dev(*rows)
+                assert r <= 14 and _f32(rows[0]).numel() == K and _f32(rows[1]).numel() == K
+            arr[i] = L.PackDesc(src.data_ptr(), dst.data_ptr(), K, r, int(layout_rk), 0, L.ptr(wide), *lnp, L.ptr(rows[0]), L.ptr(rows[1]))
             self.max_K = max(self.max_K, K)
         self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.n = len(entries)

@@ -80,8 +80,9 @@ int ffm_abi_version(void);
  *   c2 = sum_k g_h gamma xhat = sum_n dpre[n] (pre[n] - d[n])   - sum_j us[j] (A^T beta)[j],     d = W beta + b
  * (us = scaling s_b (dpre B^T), the rank vector the dX product of c_fc forms anyway; W gamma, d, A^T gamma, A^T beta are the
  * vectors the forward's FFM_EPI_LNIN folding already builds).  FFM_EPI_LNB_STAT (producer, with DGELU | RANKOP | LGRAD): the
- * dX product of c_proj leaves lnb_part[tn][m] = {sum_n c[m][n] lnb_wg[n], sum_n c[m][n] (aux[m][n] - lnb_d[n])} over its
- * columns.  FFM_EPI_LNB_APPLY (consumer, with LORA | LORA_KR | RANKOP): the dX product of c_fc stores
+ * dX product of c_proj leaves lnb_part[tn][m] = {0, sum_n c[m][n] aux[m][n]} over its columns (packed 16-bit dot products on
+ * the rows as stored); the two sums against the fixed vectors W gamma and d ride in the consumer's rank operand as rows 14 and
+ * 15 (ffm_pack_desc.row14 / row15: t[14] = sum_n c (W gamma), t[15] = sum_n c d come out of its matrix cores for free).  FFM_EPI_LNB_APPLY (consumer, with LORA | LORA_KR | RANKOP): the dX product of c_fc stores
  * rstd (gamma g_h - c1/K - xhat c2/K) + res instead of g_h - one launch (ffm_layernorm_bwd) and a round trip of g_h fewer. */
 #define FFM_EPI_LNB_STAT  2048
 #define FFM_EPI_LNB_APPLY 4096
@@ -176,13 +177,12 @@ typedef struct ffm_gemm_args {
      * small launch sums them IN SLICE ORDER (deterministic) and applies the epilogue - instead of a handful of blocks each
      * walking the whole K.  NULL: the one-launch kernel. */
     float*       sk_part;
-    /* FFM_EPI_LNB_STAT: lnb_wg, lnb_d [N] fp32 (W gamma and W beta + b of the LayerNorm-folded FORWARD product whose dX this
-     * launch is followed by); lnb_part [ffm_gemm_tiles_n][M][2] fp32 is written.
+    /* FFM_EPI_LNB_STAT: lnb_part [ffm_gemm_tiles_n][M][2] fp32 is written (lnb_wg / lnb_d: reserved, not read).
      * FFM_EPI_LNB_APPLY: lnb_part holds lnb_np such partial rows (<= 8 with FFM_EPI_RANKOP; <= 24 on the plain product, whose
      * producer is ffm_attention_bwd_lnstat and whose rank-r corrections do not exist: ln_rk is not read), lnb_x [M, N] (dtype, stride ldc) is the LayerNorm's
      * input, lnb_gamma [N] its weight, ln_mean / ln_rstd [M] its saved statistics (inputs here), ln_rk [2][16] the
      * corrections {A^T gamma, A^T beta} (as under FFM_EPI_LNIN | FFM_EPI_RANKOP), res the gradient that joins behind the
-     * LayerNorm (the residual path). */
+     * LayerNorm (the residual path).  With FFM_EPI_RANKOP (rank <= 14) rows 14 / 15 of rk hold W gamma and W beta + b. */
     const float* lnb_wg;
     const float* lnb_d;
     float*       lnb_part;
@@ -237,6 +237,11 @@ typedef struct ffm_pack_desc {
     const float* gamma;
     const float* beta;
     float* ln_rk;
+    /* optional (ABI 12, r <= 14): two more rows of the packed operand from caller vectors, dst[14][k] = row14[k],
+     * dst[15][k] = row15[k] - the rank slots beyond r are masked by every consumer, so the product's t[14] / t[15] are free
+     * row-wise dot products with two fixed vectors (FFM_EPI_LNB_APPLY takes W gamma and W beta + b there) */
+    const float* row14;
+    const float* row15;
 } ffm_pack_desc;
 int ffm_lora_pack_multi(const ffm_pack_desc* descs_dev, int ndesc, int max_K, int dtype, void* stream);
 /* second pass for the descriptors that carry gamma / beta / ln_rk (others return at once): the ln_rk sums, which read
