@@ -605,6 +605,41 @@ def test_sgd_matches_torch(ops):
         check(p, ref_p.detach(), 1e-6, f"sgd step {step}")
 
 
+def test_fedavg_aggregator_gpu_equals_cpu():
+    """fedavg.FedAvgAggregator (the ONE round boundary of the FL rank driver and of bench.py): a rank that holds two clients of
+    a round - begin / add / add / finish - on the HIP kernels against the host-tensor path the gloo tests run.  The weighted sum
+    (ffm_scale_by, ffm_scale_acc: product and sum rounded separately, compiled without FMA contraction) is BIT-identical; behind
+    shared_half_s and the EMA the two agree to one rounding of the (1 - beta) coefficient (the host forms it in double)."""
+    from fairfedmed_amd.fedavg import FedAvgAggregator
+    G, r = 3, 8
+    offsets = {"prompt_learner.ctx": (0, (2, 4, 16)), "a.lora_S.weight": (128, (G, r)), "a.lora_A.weight": (152, (40, r)),
+               "b.lora_S.weight": (472, (G, r)), "b.lora_S_global.weight": (496, (r,))}
+    n = 504
+    g = torch.Generator().manual_seed(7)
+    flat0 = torch.randn(n, generator=g)
+    clients = [torch.randn(n, generator=g) for _ in range(4)]
+    n_client, by_attr = [40, 80], [[10, 20, 10], [30, 25, 25]]
+    res = {}
+    for dev in ("cpu", "cuda"):
+        agg = FedAvgAggregator(flat0.to(dev).clone(), offsets, G, r, shared_half_s=True)
+        sums, outs = [], []
+        for rnd in range(2):
+            agg.begin()
+            agg.add(clients[2 * rnd].to(dev), 0, [0, 1], n_client, by_attr)
+            agg.add(clients[2 * rnd + 1].to(dev), 1, [0, 1], n_client, by_attr)
+            sums.append(agg.buf.cpu().clone())
+            outs.append(agg.finish(rnd, 2, grouped=True).cpu().clone())
+        res[dev] = (sums, outs)
+    for a, b in zip(res["cpu"][0], res["cuda"][0]):
+        assert torch.equal(a, b), "the weighted sum of a rank's clients: bit-identical"
+    for a, b in zip(res["cpu"][1], res["cuda"][1]):
+        assert float((a - b).abs().max()) <= 2e-7 * float(a.abs().max())
+    assert not torch.equal(res["cpu"][1][0], res["cpu"][1][1])
+    # the [G, r] blocks' first half is the column mean on every device, the 1-D lora_S_global is left alone
+    blk = res["cuda"][1][0][128:128 + G * r].view(G, r)
+    assert torch.equal(blk[0, : r // 2], blk[1, : r // 2]) and not torch.equal(blk[0, r // 2:], blk[1, r // 2:])
+
+
 def test_fedavg_helpers(ops):
     G, r, n = 3, 8, 1000
     p, w = rnd(n, seed=40), torch.rand(n, device="cuda")
