@@ -102,6 +102,16 @@ def test_gemm_args_mirror_the_header_field_by_field():
     assert l.ffm_attention_bwd_lnstat_ok(96, 0, _lib.BF16) == 0 == l.ffm_attention_bwd_lnstat_ok(197, 1, _lib.BF16) == l.ffm_attention_bwd_lnstat_ok(197, 0, _lib.F32)
 
 
+def test_integration_md_stub_mirrors_gemm_args():
+    """The ctypes stub a maintainer would paste from INTEGRATION.md lists ffm_gemm_args' fields in the header's order (a stub
+    that lags the header shifts every later pointer)."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = md[md.index("class GemmArgs(ctypes.Structure):"):md.index("lib.ffm_gemm_nt.argtypes")]
+    names = re.findall(r'\("(\w+)",\s*ctypes\.c_(\w+)\)', body)
+    kinds = {"void_p": ctypes.c_void_p, "int32": ctypes.c_int32, "float": ctypes.c_float}
+    assert [(n, kinds[k]) for n, k in names] == [(n, t) for n, t in _lib.GemmArgs._fields_]
+
+
 def test_registry_semantics():
     r = Registry("T")
 
